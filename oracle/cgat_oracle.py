@@ -1,0 +1,450 @@
+"""ORACLE -- test infrastructure, not product.
+
+CPU (torch, fp32/fp64) restatement of the hyllios/CGAT edge-attention hot path, op for op
+in the reference's own operation order, with the reference's `state_dict` layout.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+file; nothing under `cgat_amd/` does.
+
+Pinning: checked by `tests/test_oracle_golden.py` against `tests/golden/{tiny,base}.npz`,
+which were produced by running the unmodified reference in the authoring container
+(`tests/golden/make_golden.py`).  The reference holds no tests or golden vectors of its
+own, and its three segment primitives live in un-vendored third-party packages
+(torch_geometric 2.0.3 `utils.softmax`, `nn.MessagePassing.propagate`; torch_scatter 2.0.9
+`scatter_add/scatter_max`; README.md:7-8) -- that third-party boundary is restated from the
+packages' documented behaviour (functions `seg_*` and `propagate_add` below) and is
+**unpinned upstream**; everything above it is pinned by the fixtures.
+
+Each block cites the reference lines it follows (paths relative to /root/reference).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------
+# third-party segment primitives (documented semantics; see module docstring)
+# ----------------------------------------------------------------------------------------
+def _bcast(index, like):
+    return index.reshape((-1,) + (1,) * (like.dim() - 1)).expand_as(like)
+
+
+def seg_sum(src, index, n):
+    """torch_scatter.scatter_add(src, index, dim=0, dim_size=n)."""
+    return src.new_zeros((n,) + tuple(src.shape[1:])).scatter_add_(0, _bcast(index, src), src)
+
+
+def seg_max(src, index, n):
+    """torch_scatter.scatter_max(src, index, dim=0, dim_size=n)[0]; empty segments are never read."""
+    out = src.new_zeros((n,) + tuple(src.shape[1:]))
+    return out.scatter_reduce(0, _bcast(index, src), src, reduce="amax", include_self=False)
+
+
+def seg_softmax(src, index, n):
+    """torch_geometric.utils.softmax along dim 0: exp(a - segmax) / (segsum + 1e-16)."""
+    e = (src - seg_max(src, index, n)[index]).exp()
+    return e / (seg_sum(e, index, n)[index] + 1e-16)
+
+
+# ----------------------------------------------------------------------------------------
+# MLP blocks  (CGAT/message_changed.py:31-138, CGAT/roost_message.py:324-355)
+# ----------------------------------------------------------------------------------------
+class SimpleNetwork(nn.Module):
+    """Linear -> LeakyReLU(0.01) per hidden layer, then Linear (message_changed.py:36-63)."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dims):
+        super().__init__()
+        dims = [input_dim] + list(hidden_layer_dims)
+        self.fcs = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.acts = nn.ModuleList(nn.LeakyReLU() for _ in dims[1:])
+        self.fc_out = nn.Linear(dims[-1], output_dim)
+
+    def forward(self, fea):
+        for fc in self.fcs:
+            fea = F.leaky_relu(fc(fea), 0.01)
+        return self.fc_out(fea)
+
+
+class Rezero(nn.Module):
+    """alpha * x, alpha initialised to 0 (message_changed.py:69-75)."""
+
+    def __init__(self):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return self.alpha * x
+
+
+class ResidualNetwork(nn.Module):
+    """fea = [rez](relu(fc(fea))) + res_fc(fea); fc_out unless last_layer=False
+    (message_changed.py:86-135)."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dims, if_rezero=False):
+        super().__init__()
+        dims = [input_dim] + list(hidden_layer_dims)
+        pairs = list(zip(dims[:-1], dims[1:]))
+        self.fcs = nn.ModuleList(nn.Linear(a, b) for a, b in pairs)
+        self.res_fcs = nn.ModuleList(nn.Linear(a, b, bias=False) if a != b else nn.Identity() for a, b in pairs)
+        self.acts = nn.ModuleList(nn.ReLU() for _ in pairs)
+        self.fc_out = nn.Linear(dims[-1], output_dim)
+        self.if_rezero = if_rezero
+        if if_rezero:
+            self.rezeros = nn.ModuleList(Rezero() for _ in pairs)
+
+    def forward(self, fea, *, last_layer=True):
+        for k, (fc, res) in enumerate(zip(self.fcs, self.res_fcs)):
+            h = torch.relu(fc(fea))
+            if self.if_rezero:
+                h = self.rezeros[k](h)
+            fea = h + res(fea)
+        return self.fc_out(fea) if last_layer else fea
+
+
+# ----------------------------------------------------------------------------------------
+# hypernetwork  (CGAT/Hypernetworksmp.py:24-313)
+# ----------------------------------------------------------------------------------------
+class FCLayer(nn.Module):
+    """Linear + Tanh (Hypernetworksmp.py:24-33)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(in_features, out_features), nn.Tanh())
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _kaiming(m):
+    if isinstance(m, nn.Linear):
+        nn.init.kaiming_normal_(m.weight, a=0.0, nonlinearity="leaky_relu", mode="fan_in")
+
+
+class FCBlock(nn.Module):
+    """FCLayer(in->hid), n x FCLayer(hid->hid), Linear(hid->out) if outermost_linear
+    (Hypernetworksmp.py:36-83)."""
+
+    def __init__(self, hidden_ch, num_hidden_layers, in_features, out_features, outermost_linear=False):
+        super().__init__()
+        layers = [FCLayer(in_features, hidden_ch)]
+        layers += [FCLayer(hidden_ch, hidden_ch) for _ in range(num_hidden_layers)]
+        layers.append(nn.Linear(hidden_ch, out_features) if outermost_linear else FCLayer(hidden_ch, out_features))
+        self.net = nn.Sequential(*layers)
+        self.net.apply(_kaiming)
+
+    def __getitem__(self, item):
+        return self.net[item]
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class HyperLinear(nn.Module):
+    """Predict (W [.., out, in], b [.., 1, out]) from the hyper input and return the batch-linear
+    map y = x W^T + b (Hypernetworksmp.py:188-254)."""
+
+    def __init__(self, in_ch, out_ch, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch):
+        super().__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.hypo_params = FCBlock(hyper_hidden_ch, hyper_num_hidden_layers, hyper_in_ch,
+                                   in_ch * out_ch + out_ch, outermost_linear=True)
+        last = self.hypo_params[-1]
+        _kaiming(last)
+        last.weight.data *= 1e-1                                   # last_hyper_layer_init, 212-219
+
+    def predict(self, hyper_input):
+        p = self.hypo_params(hyper_input)                          # [.., in*out + out]   (244)
+        io = self.in_ch * self.out_ch
+        W = p[..., :io].reshape(*p.shape[:-1], self.out_ch, self.in_ch)     # 247, 252
+        b = p[..., io:io + self.out_ch].reshape(*p.shape[:-1], 1, self.out_ch)  # 248-251
+        return W, b
+
+    @staticmethod
+    def apply_predicted(W, b, x):
+        return x.matmul(W.transpose(-1, -2)) + b                   # BatchLinear.forward, 205-209
+
+
+class HyperLayer(nn.Module):
+    """HyperLinear followed by LayerNorm(no affine, eps 1e-5) + Tanh (Hypernetworksmp.py:86-114)."""
+
+    def __init__(self, in_ch, out_ch, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch):
+        super().__init__()
+        self.hyper_linear = HyperLinear(in_ch, out_ch, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch)
+        self.norm_nl = nn.Sequential(nn.LayerNorm([out_ch], elementwise_affine=False), nn.Tanh())
+
+
+class HyperFC(nn.Module):
+    """[HyperLayer(in->hid)] + n x [HyperLayer(hid->hid)] + [HyperLinear(hid->out)]
+    (Hypernetworksmp.py:117-185; callers always pass outermost_linear=True, 274/305)."""
+
+    def __init__(self, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch, hidden_ch, num_hidden_layers,
+                 in_ch, out_ch, outermost_linear=False):
+        super().__init__()
+        hk = (hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch)
+        self.layers = nn.ModuleList([HyperLayer(in_ch, hidden_ch, *hk)])
+        for _ in range(num_hidden_layers):
+            self.layers.append(HyperLayer(hidden_ch, hidden_ch, *hk))
+        self.layers.append(HyperLinear(hidden_ch, out_ch, *hk) if outermost_linear
+                           else HyperLayer(hidden_ch, out_ch, *hk))
+
+    def run(self, hyper_input, x):
+        """Predict every layer from `hyper_input`, then push x [n,1,in] through them."""
+        for layer in self.layers:
+            if isinstance(layer, HyperLayer):
+                W, b = layer.hyper_linear.predict(hyper_input)
+                x = layer.norm_nl(HyperLinear.apply_predicted(W, b, x))
+            else:
+                W, b = layer.predict(hyper_input)
+                x = HyperLinear.apply_predicted(W, b, x)
+        return x
+
+
+class H_Net_0(nn.Module):
+    """NN = Hyper(h_0); NN(x)   (Hypernetworksmp.py:257-285)."""
+
+    def __init__(self, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch, hidden_ch, num_hidden_layers,
+                 in_ch, out_ch, outermost_linear=True):
+        super().__init__()
+        self.Hyper = HyperFC(hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch, hidden_ch,
+                             num_hidden_layers, in_ch, out_ch, outermost_linear=True)
+        self.out_ch = out_ch
+
+    def forward(self, h_0, x):
+        return self.Hyper.run(h_0, x.view(x.shape[0], 1, x.shape[1])).view(x.shape[0], self.out_ch)
+
+
+class H_Net(nn.Module):
+    """damping clamped to [0,1] in place, hyper input = d*h_0 + (1-d)*x, h_t unused
+    (Hypernetworksmp.py:288-313)."""
+
+    def __init__(self, hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch, hidden_ch, num_hidden_layers,
+                 in_ch, out_ch, outermost_linear=True):
+        super().__init__()
+        self.Hyper = HyperFC(hyper_in_ch, hyper_num_hidden_layers, hyper_hidden_ch, hidden_ch,
+                             num_hidden_layers, in_ch, out_ch, outermost_linear=True)
+        self.damping = nn.Parameter(torch.rand(1))
+        self.out_ch = out_ch
+
+    def forward(self, h_0, h_t, x):
+        with torch.no_grad():
+            self.damping.data = self.damping.data.clamp(0.0, 1.0)
+        hin = self.damping * h_0 + (1 - self.damping) * x
+        return self.Hyper.run(hin, x.view(x.shape[0], 1, x.shape[1])).view(x.shape[0], self.out_ch)
+
+
+# ----------------------------------------------------------------------------------------
+# attention layers  (CGAT/CGAT.py:14-340)
+# ----------------------------------------------------------------------------------------
+class MultiHeadNetwork(nn.Module):
+    """H independent D->Hd->out MLPs as repeat + grouped 1x1 Conv1d, LeakyReLU(0.01)
+    (CGAT.py:65-112).  Kept in that exact op sequence so that timing this class is timing
+    the reference CPU path."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dim, nb_heads, view=True):
+        super().__init__()
+        self.input_dim, self.nb_heads, self.output_dim, self.view = input_dim, nb_heads, output_dim, view
+        self.fc_in = nn.Conv1d(input_dim * nb_heads, hidden_layer_dim * nb_heads, kernel_size=1, groups=nb_heads)
+        self.acts = nn.LeakyReLU()
+        self.fc_out = nn.Conv1d(hidden_layer_dim * nb_heads, output_dim * nb_heads, kernel_size=1, groups=nb_heads)
+
+    def forward(self, fea):
+        fea = fea.reshape(-1, self.input_dim, 1).repeat(1, self.nb_heads, 1)      # 105/107
+        fea = F.leaky_relu(self.fc_in(fea), 0.01)
+        return self.fc_out(fea).view(-1, self.nb_heads, self.output_dim)          # 109
+
+
+class MHAttention(nn.Module):
+    """Per-crystal attention pooling (CGAT.py:14-62)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, vector_attention=False):
+        super().__init__()
+        self.heads, self.out_channels = heads, out_channels
+        self.MH_A = MultiHeadNetwork(2 * in_channels, out_channels if vector_attention else 1,
+                                     in_channels, heads, view=False)
+        self.MH_M = MultiHeadNetwork(in_channels, out_channels, in_channels, heads)
+
+    def forward(self, fea, cry_fea, index, size=None):
+        size = int(index[-1]) + 1 if size is None else size                       # 52
+        m = self.MH_M(fea)
+        pair = torch.stack([fea, cry_fea[index]]).transpose(1, 0)                 # 55-57
+        alpha = seg_softmax(self.MH_A(pair), index, size)                         # 58-59
+        return seg_sum((alpha * m).view(-1, self.heads * self.out_channels), index, size)  # 60-61
+
+
+def _edge_nets(in_channels, out_channels, nbr_channels, heads, vector_attention):
+    D = 2 * in_channels + nbr_channels
+    Hd = int(D / 1.5)
+    return (MultiHeadNetwork(D, out_channels if vector_attention else 1, Hd, heads),
+            MultiHeadNetwork(D, out_channels, Hd, heads))
+
+
+class GATConvEdges(nn.Module):
+    """Edge update (CGAT.py:115-230).  With no_hyper=True the attention result is computed and
+    then discarded (224-225) -- kept here, since this is the reference CPU path."""
+
+    def __init__(self, in_channels, out_channels, nbr_channels, heads=1, concat=True, negative_slope=0.2,
+                 dropout=0, bias=True, vector_attention=False, first=False, no_hyper=True, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.nbr_channels = in_channels, out_channels, nbr_channels
+        self.heads, self.vector_attention, self.first, self.no_hyper = heads, vector_attention, first, no_hyper
+        self.MH_A, self.MH_M = _edge_nets(in_channels, out_channels, nbr_channels, heads, vector_attention)
+        if no_hyper:
+            self.Pooling_NN = SimpleNetwork(out_channels, out_channels, [out_channels])
+        else:
+            cls = H_Net_0 if first else H_Net
+            self.Pooling_NN = cls(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+
+    def forward(self, x, edge_index, edge_attr, x_0, size=None):
+        m = torch.cat([x[edge_index[0]], edge_attr, x[edge_index[1]]], dim=-1)    # 209-211
+        alpha = self.MH_A(m).exp()                                                # 212, 214
+        m = self.MH_M(m)
+        alpha = alpha / alpha.sum(dim=1, keepdim=True)                            # 216-219 (over heads)
+        aggr = (m * alpha).mean(dim=1)                                            # 222-223
+        if self.no_hyper:
+            return self.Pooling_NN(edge_attr)                                     # 224-225
+        if self.first:
+            return self.Pooling_NN(edge_attr, aggr)                               # 226-227
+        return self.Pooling_NN(x_0, edge_attr, aggr)                              # 228-229
+
+
+class GATConvNodes(nn.Module):
+    """Node update (CGAT.py:233-340) with PyG `propagate` unrolled: x_j = x[ei[0]],
+    x_i = x[ei[1]], softmax and scatter-add keyed by ei[1]."""
+
+    def __init__(self, in_channels, out_channels, nbr_channels, heads=1, concat=False, negative_slope=0.2,
+                 dropout=0, bias=True, final=False, vector_attention=False, first=False, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.nbr_channels = in_channels, out_channels, nbr_channels
+        self.heads, self.final, self.first = heads, final, first
+        self.MH_A, self.MH_M = _edge_nets(in_channels, out_channels, nbr_channels, heads, vector_attention)
+        if not final:
+            cls = H_Net_0 if first else H_Net
+            self.Pooling_NN = cls(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+
+    def message(self, x_i, x_j, edge_attr, edge_index_i, n):
+        m = torch.cat([x_i, edge_attr, x_j], dim=-1)                              # 320
+        alpha = seg_softmax(self.MH_A(m), edge_index_i, n)                        # 321, 323
+        return self.MH_M(m) * alpha                                               # 322, 326
+
+    def forward(self, x, edge_index, edge_attr, x_0, size=None):
+        n = x.shape[0]
+        j, i = edge_index[0], edge_index[1]
+        msg = self.message(x[i], x[j], edge_attr, i, n)
+        aggr = seg_sum(msg, i, n).mean(dim=1)                                     # aggregate + 329
+        if self.final:
+            return aggr
+        if self.first:
+            return self.Pooling_NN(x, aggr)                                       # 330-331
+        return self.Pooling_NN(x_0, x, aggr)                                      # 332-333
+
+
+# ----------------------------------------------------------------------------------------
+# Roost branch  (CGAT/roost_message.py:88-321)
+# ----------------------------------------------------------------------------------------
+class WeightedAttention(nn.Module):
+    """(w ** pow) * exp(gate - segmax) / (segsum + 1e-13) attention (roost_message.py:286-317)."""
+
+    def __init__(self, gate_nn, message_nn, num_heads=1):
+        super().__init__()
+        self.gate_nn, self.message_nn = gate_nn, message_nn
+        self.pow = nn.Parameter(torch.randn(1))
+
+    def forward(self, fea, index, weights):
+        n = int(index.max()) + 1
+        gate = self.gate_nn(fea)
+        gate = gate - seg_max(gate, index, n)[index]                              # 307
+        gate = (weights ** self.pow) * gate.exp()                                 # 308
+        gate = gate / (seg_sum(gate, index, n)[index] + 1e-13)                    # 311
+        return seg_sum(gate * self.message_nn(fea), index, n)                     # 313-315
+
+
+class MessageLayer(nn.Module):
+    """roost_message.py:88-153."""
+
+    def __init__(self, fea_len, num_heads=1):
+        super().__init__()
+        self.pooling = nn.ModuleList(
+            WeightedAttention(gate_nn=SimpleNetwork(2 * fea_len, 1, [256]),
+                              message_nn=SimpleNetwork(2 * fea_len, fea_len, [256]))
+            for _ in range(num_heads))
+
+    def forward(self, elem_weights, elem_in_fea, self_fea_idx, nbr_fea_idx):
+        fea = torch.cat([elem_in_fea[self_fea_idx], elem_in_fea[nbr_fea_idx]], dim=1)   # 138-140
+        w = elem_weights[nbr_fea_idx]
+        heads = [att(fea=fea, index=self_fea_idx, weights=w) for att in self.pooling]
+        return torch.stack(heads).mean(dim=0) + elem_in_fea                      # 151-153
+
+
+class Roost(nn.Module):
+    """roost_message.py:159-264."""
+
+    def __init__(self, orig_elem_fea_len, elem_fea_len, n_graph):
+        super().__init__()
+        self.embedding = nn.Linear(orig_elem_fea_len, elem_fea_len - 1)          # 189
+        self.graphs = nn.ModuleList(MessageLayer(elem_fea_len, 1) for _ in range(n_graph))
+        self.cry_pool = nn.ModuleList(
+            [WeightedAttention(gate_nn=SimpleNetwork(elem_fea_len, 1, [256]), message_nn=nn.Identity())])
+
+    def forward(self, elem_weights, orig_elem_fea, self_fea_idx, nbr_fea_idx, crystal_elem_idx):
+        fea = torch.cat([self.embedding(orig_elem_fea), elem_weights], dim=1)    # 240-245
+        for g in self.graphs:
+            fea = g(elem_weights, fea, self_fea_idx, nbr_fea_idx)
+        heads = [att(fea=fea, index=crystal_elem_idx, weights=elem_weights) for att in self.cry_pool]
+        return torch.stack(heads).mean(dim=0)                                    # 259
+
+
+# ----------------------------------------------------------------------------------------
+# the stack  (CGAT/CGAT.py:343-613)
+# ----------------------------------------------------------------------------------------
+class CGAtNet(nn.Module):
+    """Only the update_edges=True structure exists (the False branch of the reference raises,
+    SURVEY 3.2)."""
+
+    def __init__(self, orig_elem_fea_len, elem_fea_len, n_graph, nbr_embedding_size=128, neighbor_number=12,
+                 mean_pooling=True, rezero=False, msg_heads=3, update_edges=False, vector_attention=False,
+                 global_vector_attention=False, n_graph_roost=3, no_hyper=True):
+        super().__init__()
+        if not update_edges:
+            raise NotImplementedError("reference CGAtNet(update_edges=False) is broken (CGAT.py:408-421)")
+        self.mean_pooling, self.update_edges, self.no_hyper = mean_pooling, update_edges, no_hyper
+        self.embedding = nn.Linear(orig_elem_fea_len, elem_fea_len, bias=False)
+        self.nbr_embedding = nn.Embedding(neighbor_number + 1, nbr_embedding_size)
+        layers = []
+        for k in range(n_graph):
+            layers.append(nn.ModuleDict({
+                "Node": GATConvNodes(elem_fea_len, elem_fea_len, nbr_embedding_size, msg_heads, concat=True,
+                                     vector_attention=vector_attention, first=(k == 0)),
+                "Edge": GATConvEdges(elem_fea_len, nbr_embedding_size, nbr_embedding_size, msg_heads, concat=True,
+                                     vector_attention=vector_attention, first=(k == 0), no_hyper=no_hyper)}))
+        self.graphs = nn.ModuleList(layers)
+        self.roost = Roost(orig_elem_fea_len, elem_fea_len, n_graph_roost)
+        self.cry_pool = MHAttention(elem_fea_len, elem_fea_len, heads=msg_heads,
+                                    vector_attention=global_vector_attention)
+        self.msg_heads, self.elem_fea_len = msg_heads, elem_fea_len
+        self.output_nn = ResidualNetwork(elem_fea_len if mean_pooling else elem_fea_len * msg_heads, 2,
+                                         [1024, 1024, 512, 512, 256, 256, 128], if_rezero=rezero)
+
+    def forward(self, batch, roost, *, last_layer=True, return_graph_embedding=False):
+        ei = batch.edge_index
+        edge_attr = self.nbr_embedding(batch.edge_attr)                           # 569
+        fea = self.embedding(batch.x)                                             # 570
+        fea0, edge0 = fea.clone(), edge_attr.clone()
+        for g in self.graphs:                                                     # 580-585
+            node_update = g["Node"](fea, ei, edge_attr, fea0)
+            edge_attr = edge_attr + g["Edge"](fea, ei, edge_attr, edge0)
+            fea = fea + node_update
+        crys = self.cry_pool(fea, self.roost(*roost), batch.batch)                # 587-588
+        if self.mean_pooling:
+            crys = crys.view(-1, self.msg_heads, self.elem_fea_len).mean(dim=1)   # 591-592
+        if return_graph_embedding:
+            return crys
+        return self.output_nn(crys, last_layer=last_layer)
+
+    def get_output_parameters(self):
+        return self.output_nn.parameters()
+
+    def get_hidden_parameters(self):
+        import itertools
+        return itertools.chain(self.embedding.parameters(), self.nbr_embedding.parameters(),
+                               self.graphs.parameters(), self.roost.parameters(), self.cry_pool.parameters())
