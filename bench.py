@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X:
+    "edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch".
+
+One step = one GATConvNodes.forward (message MLPs, softmax over incoming edges, scatter-add,
+head mean, H_Net hypernetwork update; reference CGAT.py:307-335) plus its full backward
+(gradients wrt x, edge_attr, x_0 and all 9.48 M layer parameters) over one synthetic batch of
+4167 crystals x 20 atoms x 12 neighbours = 83 340 atoms, 1 000 080 edges, C = Ce = 128, H = 3,
+fp32.  Inputs are resident in HBM before the timed region.  With N > 1 every rank runs its own
+batch of that size (graphs are independent; weak scaling) and the step ends with the gradient
+mean across ranks (RCCL all-reduce), as Lightning DDP does for the reference.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+C_FEA, HEADS, K_NBR, ATOMS = 128, 3, 12, 20
+GRAPHS = 4167                       # -> E = 1 000 080
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32 matrix peak (= vector peak)
+
+
+def make_inputs(graphs, seed, device):
+    import cgat_amd as P
+    b, _ = P.synthetic_batch(graphs, ATOMS, K_NBR, seed=seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x = torch.randn(N, C_FEA, generator=g).to(device)
+    e = torch.randn(E, C_FEA, generator=g).to(device)
+    x0 = torch.randn(N, C_FEA, generator=g).to(device)
+    cot = torch.randn(N, C_FEA, generator=g).to(device)
+    return b.edge_index.to(device), x, e, x0, cot
+
+
+def cpu_baseline(n_graphs=100, reps=3):
+    """The oracle (op-for-op restatement of the reference's CPU path: cat -> head repeat -> grouped
+    Conv1d -> LeakyReLU -> conv -> segment softmax -> scatter-add -> Linear(C -> C*C+C) hypernet ->
+    bmm -> LayerNorm -> tanh) timed on this box's host cores, same layer, fwd+bwd, on a bounded
+    sample of the same synthetic workload."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    torch.manual_seed(1)
+    layer = O.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True)
+    ei, x, e, x0, cot = make_inputs(n_graphs, 0, "cpu")
+    times = []
+    for r in range(reps + 1):
+        xx, ee, xx0 = (t.clone().requires_grad_(True) for t in (x, e, x0))
+        t0 = time.perf_counter()
+        y = layer(xx, ei, ee, xx0)
+        torch.autograd.grad((y * cot).sum(), [xx, ee, xx0] + list(layer.parameters()))
+        dt = time.perf_counter() - t0
+        if r > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    E = ei.shape[1]
+    return {"value": E / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_graphs} crystals ({E} edges) of the same synthetic workload, same layer fwd+bwd, "
+                      f"fp32, median of {reps} after 1 warm-up ({med:.2f} s per pass); per-edge cost is "
+                      "batch-size independent (SURVEY §8d)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graphs", type=int, default=GRAPHS, help="crystals per rank (default: the 1M-edge batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    from cgat_amd.dist import GradientAverager, init_from_env
+
+    rank, world, device = init_from_env()
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X (cuda device); there is no CPU path to measure")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    torch.manual_seed(1)                                   # identical parameters on every rank
+    layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
+    params = list(layer.parameters())
+    ei, x, e, x0, cot = make_inputs(args.graphs, rank, device)     # each rank: its own crystals
+    N, E = x.shape[0], ei.shape[1]
+    x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
+    averager = GradientAverager(params) if world > 1 else None
+
+    def step():
+        for p in params:
+            p.grad = None
+        x.grad = e.grad = x0.grad = None
+        y = layer(x, ei, e, x0)
+        y.backward(cot)
+        if averager is not None:
+            averager.finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.prof_reset()
+    ops.prof_enable(True)                                  # HIP events around the kernel launches, on their stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        n_l, ms_l = ops.prof_get("bilinear_rows")
+        flops_per_launch = 2.0 * N * C_FEA ** 3           # 2*C^3 flop per row (C*(C*C)*2)
+        roof = None
+        if n_l:
+            avg_ms = ms_l / n_l
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "bilinear_rows128_kernel", "achieved": round(ach, 2),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": n_l / args.steps, "avg_launch_ms": round(avg_ms, 4),
+                    "flops_per_launch": flops_per_launch}
+        shares = {}
+        for tag in ("bilinear_rows", "bilinear_wgrad", "gemm_f32"):
+            n_t, ms_t = ops.prof_get(tag)
+            shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
+        out = {
+            "metric": "edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch",
+            "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
+                                   f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention",
+                       "edges_per_rank": E, "parallelism": f"dp{world} (graphs sharded, gradient all-reduce)"},
+            "roofline": roof, "kernel_ms_per_step": shares,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+"""cgat_amd -- MI355X (gfx950) implementation of the hyllios/CGAT edge-attention hot path.
+
+`CGAtNet` and the layer classes keep the reference's constructor / forward API and
+state_dict layout, so `--version cgat_amd` plugs into the reference LightningModule
+(lightning_module.py:165-176).  Importing this package loads libcgat_hip.so and raises if
+it is missing: there is no CPU or PyTorch-eager fallback.
+"""
+from . import _lib  # noqa: F401  (loads the shared library, fails loudly)
+from .hypernet import H_Net, H_Net_0, HyperFC
+from .mlp import ResidualNetwork, Rezero, SimpleNetwork
+from .nets import CGAtNet, GATConvEdges, GATConvNodes, MHAttention, MultiHeadNetwork
+from .roost import MessageLayer, Roost, WeightedAttention
+from .graph import GraphBatch, synthetic_batch
+
+__all__ = ["CGAtNet", "GATConvNodes", "GATConvEdges", "MultiHeadNetwork", "MHAttention", "H_Net", "H_Net_0",
+           "HyperFC", "SimpleNetwork", "ResidualNetwork", "Rezero", "Roost", "MessageLayer", "WeightedAttention",
+           "GraphBatch", "synthetic_batch"]

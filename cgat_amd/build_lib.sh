@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds cgat_amd/libcgat_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+OUT="$HERE/libcgat_hip.so"
+SRCS=(api gemm bilinear rowops segment plan layers)
+OBJS=()
+mkdir -p "$HERE/csrc/build"
+for s in "${SRCS[@]}"; do
+  src="$HERE/csrc/$s.hip"; obj="$HERE/csrc/build/$s.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/kernels.h" -nt "$obj" ] || [ "$HERE/csrc/common.h" -nt "$obj" ] || [ "$HERE/../include/cgat_hip.h" -nt "$obj" ]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" ${CGAT_HIPCC_FLAGS} &
+  fi
+  OBJS+=("$obj")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
+echo "built $OUT"

@@ -1,0 +1,198 @@
+// Public C ABI glue: error string, launch-timing registry, and the thin entry points that map
+// one-to-one onto a kernel family (dense layer, segment softmax / sum, CSR plan).
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cgat_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+// ---- error ----
+static thread_local char g_err[1024] = "";
+void cgat_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* cgat_last_error(void) { return g_err; }
+extern "C" int cgat_abi_version(void) { return CGAT_ABI_VERSION; }
+
+// ---- launch timing ----
+struct ProfRec {
+  std::string tag;
+  hipEvent_t beg, end;
+};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static bool g_prof_on = false;
+
+ProfScope::ProfScope(const char* tag, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.tag = tag;
+  if (hipEventCreate(&r.beg) != hipSuccess || hipEventCreate(&r.end) != hipSuccess) return;
+  (void)hipEventRecord(r.beg, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].end, stream);
+}
+extern "C" void cgat_prof_enable(int on) { g_prof_on = on != 0; }
+extern "C" void cgat_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
+}
+extern "C" int cgat_prof_get(const char* tag, int* count, float* total_ms) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  float tot = 0.f;
+  for (auto& r : g_prof) {
+    if (r.tag != tag) continue;
+    if (hipEventSynchronize(r.end) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.beg, r.end) == hipSuccess) {
+      tot += ms;
+      ++n;
+    }
+  }
+  if (count) *count = n;
+  if (total_ms) *total_ms = tot;
+  return CGAT_OK;
+}
+
+// ---- CSR plan ----
+size_t csr_ws_bytes(int S);
+extern "C" size_t cgat_plan_workspace_bytes(int32_t E, int32_t N) { return plan_ws_bytes(E, N) + 256; }
+extern "C" int cgat_plan_build(const int64_t* edge_index, int32_t E, int32_t N, int32_t* dst_rowptr, int32_t* dst_perm,
+                               int32_t* dst_sorted, int32_t* src_sorted, int32_t* src_rowptr, int32_t* src_pos,
+                               void* ws, size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(E >= 0 && N >= 0, "plan_build: negative size");
+  return plan_build_launch(edge_index, E, N, dst_rowptr, dst_perm, dst_sorted, src_sorted, src_rowptr, src_pos, ws,
+                           ws_bytes, (hipStream_t)stream);
+}
+extern "C" size_t cgat_csr_workspace_bytes(int32_t S) { return csr_ws_bytes(S) + 256; }
+extern "C" int cgat_csr_from_keys(const int32_t* keys, int32_t n, int32_t S, int32_t* rowptr, int32_t* perm, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  return csr_from_keys_launch(keys, n, S, rowptr, perm, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- dense layer ----
+extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                   float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* stream) {
+  CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0, "linear_forward: negative size");
+  GemmParams g = gemm_params(M, N, K, x, ldx, w, ldw, y, ldy);
+  g.bias = bias;
+  g.act = act;
+  return gemm_launch(g, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N) {
+  int splits = gemm_pick_splits(N, K, M);
+  size_t a = splits > 1 ? ws_round((size_t)splits * N * K, 4) : 0;
+  size_t b = colsum_ws_bytes(M, N);
+  return (a > b ? a : b) + 256;
+}
+
+extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
+                                    int64_t ldy, const float* g_y, int64_t ldgy, float* gpre, float* g_x,
+                                    int64_t ldgx, int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b,
+                                    int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0, "linear_backward: negative size");
+  const float* gp = g_y;
+  long ldgp = ldgy;
+  if (act != CGAT_ACT_NONE) {
+    CGAT_CHECK_ARG(gpre && ldy == N && ldgy == N, "linear_backward: activation backward needs dense y, g_y and a gpre buffer");
+    CGAT_TRY(act_bwd_launch(y, g_y, gpre, (long)M * N, act, s));
+    gp = gpre;
+    ldgp = N;
+  }
+  if (g_x) {  // g_x = gpre @ W
+    GemmParams g = gemm_params(M, K, N, gp, ldgp, w, ldw, g_x, ldgx);
+    g.b_kmajor = 1;
+    g.beta = accumulate_gx ? 1.f : 0.f;
+    CGAT_TRY(gemm_launch(g, nullptr, 0, s));
+  }
+  if (g_w) {  // g_W = gpre^T @ x
+    GemmParams g = gemm_params(N, K, M, gp, ldgp, x, ldx, g_w, ldgw);
+    g.a_kmajor = 1;
+    g.b_kmajor = 1;
+    g.splits = gemm_pick_splits(N, K, M);
+    CGAT_TRY(gemm_launch(g, ws, ws_bytes, s));
+  }
+  if (g_b) CGAT_TRY(colsum_launch(gp, ldgp, M, N, g_b, 1.f, ws, ws_bytes, s));
+  return CGAT_OK;
+}
+
+// ---- segment ops ----
+extern "C" int cgat_segment_softmax_forward(const float* a, const float* mult, const int32_t* rowptr, int32_t S,
+                                            int32_t F, float eps, float* alpha, void* stream) {
+  return seg_softmax_fwd_launch(a, mult, rowptr, S, F, eps, alpha, nullptr, (hipStream_t)stream);
+}
+extern "C" int cgat_segment_softmax_backward(const float* alpha, const float* g_alpha, const float* mult,
+                                             const int32_t* rowptr, int32_t S, int32_t F, float* g_a, float* g_mult,
+                                             void* stream) {
+  return seg_softmax_bwd_launch(alpha, g_alpha, nullptr, mult, rowptr, S, F, g_a, g_mult, (hipStream_t)stream);
+}
+extern "C" int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx, const int32_t* rowptr, int32_t S,
+                                int32_t F, float* out, int64_t ldo, void* stream) {
+  return seg_wsum_launch(x, ldx, ridx, nullptr, 0, 1, rowptr, S, F, CGAT_ACT_NONE, out, ldo, (hipStream_t)stream);
+}
+
+// ---- kernel-level primitives ----
+static GemmParams from_desc(const cgat_gemm_desc* d) {
+  GemmParams g = gemm_params(d->M, d->N, d->K, d->A, d->lda, d->B, d->ldb, d->C, d->ldc);
+  g.a_kmajor = d->a_kmajor; g.a_rgather = d->a_rgather;
+  g.b_kmajor = d->b_kmajor; g.b_kgather = d->b_kgather;
+  g.c_scatter = d->c_scatter;
+  g.alpha = d->alpha; g.beta = d->beta; g.bias = d->bias;
+  g.add1 = d->add1; g.add1_idx = d->add1_idx; g.add2 = d->add2; g.add2_idx = d->add2_idx; g.ld_add = d->ld_add;
+  g.act = d->act;
+  g.splits = d->splits > 0 ? d->splits : gemm_pick_splits(d->M, d->N, d->K);
+  if (g.c_scatter || g.add1 || g.add2) g.splits = 1;
+  return g;
+}
+extern "C" size_t cgat_gemm_workspace_bytes(const cgat_gemm_desc* d) {
+  GemmParams g = from_desc(d);
+  return gemm_ws_bytes(g) + 256;
+}
+extern "C" int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(d, "gemm: null descriptor");
+  CGAT_CHECK_ARG(!(d->a_kmajor && d->a_rgather), "gemm: a_rgather needs a_kmajor == 0");
+  CGAT_CHECK_ARG(!(!d->b_kmajor && d->b_kgather), "gemm: b_kgather needs b_kmajor == 1");
+  return gemm_launch(from_desc(d), ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T,
+                                  const float* init, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA,
+                                  int32_t NB, int32_t NC, void* stream) {
+  return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, (hipStream_t)stream);
+}
+extern "C" size_t cgat_bilinear_wgrad_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
+  return bilinear_wgrad_ws_bytes(rows, NA, NB, NC) + 256;
+}
+extern "C" int cgat_bilinear_wgrad(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* r,
+                                   int64_t ldr, float* out, int32_t rows, int32_t NA, int32_t NB, int32_t NC, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  return bilinear_wgrad_launch(p, ldp, q, ldq, r, ldr, out, rows, NA, NB, NC, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int cgat_layernorm_tanh_forward(const float* u, float* y, int32_t rows, int32_t W, float eps, void* stream) {
+  return layernorm_tanh_fwd_launch(u, y, rows, W, eps, (hipStream_t)stream);
+}
+extern "C" int cgat_layernorm_tanh_backward(const float* u, const float* y, const float* g_y, float* g_u, int32_t rows,
+                                            int32_t W, float eps, void* stream) {
+  return layernorm_tanh_bwd_launch(u, y, g_y, g_u, rows, W, eps, (hipStream_t)stream);
+}

@@ -1,0 +1,393 @@
+// The hypernetwork contraction without ever materialising the predicted weights.
+//
+// Reference (CGAT/Hypernetworksmp.py:236-254, 205-209): per row n a Linear(C -> C*C + C) emits
+// a C x C matrix W_n and bias b_n (66 KB per row at C = 128), then y_n = W_n v_n + b_n.
+// With T[o,i,k] = weight[(o*C + i), k] this is the trilinear form
+//        y[n,o] = sum_{i,k} T[o,i,k] v[n,i] z[n,k]  (+ bias-row terms handled by plain GEMMs)
+// which is a GEMM whose A operand is the row-wise outer product v (x) z, generated on the fly
+// in registers: one v_mul per MFMA.  The three backward products have the same shape under a
+// permutation of T's indices, so one kernel serves forward, d/dv and d/dz:
+//
+//   bilinear_rows :  out[n,c]   = init[n,c] + sum_{a,b} p[n,a] q[n,b] T[a,b,c]
+//   bilinear_wgrad:  out[a,b,c] = sum_n p[n,a] q[n,b] r[n,c]
+//
+// Fast path (NB = NC = 128): 128 rows per workgroup, wave w owns rows 32w..32w+31 and all 128
+// output columns (4 accumulator blocks); q lives in 64 VGPRs per lane for the whole kernel, p
+// is fetched one scalar per 256 MFMAs, T streams through LDS in 16 KB chunks (contiguous
+// 512-byte rows, double-buffered).  MFMA-bound by construction: 32 768 v_mfma_f32_32x32x2_f32
+// per wave per 128 rows, 2*C^3 flop per row.
+#include "common.h"
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* __restrict__ p, long ldp,
+                                                                  const float* __restrict__ q, long ldq,
+                                                                  const float* __restrict__ T,
+                                                                  const float* __restrict__ init, long ldi,
+                                                                  float* __restrict__ out, long ldo, int nrows,
+                                                                  int NA) {
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * 128 + wave * 32;
+  const int myrow = row0 + r;
+  const long rowc = myrow < nrows ? myrow : nrows - 1;
+
+  // q[row, 64*hi .. 64*hi+63] stays in registers
+  float qreg[64];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(q + rowc * ldq + 64 * hi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float4 t = qp[j];
+      qreg[4 * j] = t.x; qreg[4 * j + 1] = t.y; qreg[4 * j + 2] = t.z; qreg[4 * j + 3] = t.w;
+    }
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float v = 0.f;
+      if (init) {
+        int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+        if (orow < nrows) v = init[(long)orow * ldi + cb * 32 + r];
+      }
+      acc[cb][t] = v;
+    }
+
+  // chunk (a, jc): T rows  a*128 + 64*kk + 16*jc + jj,  kk in {0,1}, jj < 16   -> LDS row kk*16 + jj
+  // per-thread constant part of the four 16-byte pieces it moves per chunk
+  const int f_row = tid >> 5, f_cq = tid & 31;            // piece i covers LDS row f_row + 8*i
+  const long t_off = (long)(64 * (f_row >> 4) + (f_row & 15)) * 128 + 4 * f_cq;   // i adds 8 rows (same kk for i<2 / i>=2)
+  float4 pre0, pre1, pre2, pre3;
+#define BIL_GLOAD(a_, jc_)                                                              \
+  {                                                                                     \
+    const float* tb = T + ((long)(a_) * 128 + 16 * (jc_)) * 128 + t_off;                \
+    pre0 = *reinterpret_cast<const float4*>(tb);                                        \
+    pre1 = *reinterpret_cast<const float4*>(tb + 8 * 128);                              \
+    pre2 = *reinterpret_cast<const float4*>(tb + 64 * 128);                            \
+    pre3 = *reinterpret_cast<const float4*>(tb + (64 + 8) * 128);                       \
+  }
+#define BIL_LSTORE(buf_)                                                                \
+  {                                                                                     \
+    float* lb = &Bs[buf_][f_row * 128 + 4 * f_cq];                                      \
+    *reinterpret_cast<float4*>(lb) = pre0;                                              \
+    *reinterpret_cast<float4*>(lb + 8 * 128) = pre1;                                    \
+    *reinterpret_cast<float4*>(lb + 16 * 128) = pre2;                                   \
+    *reinterpret_cast<float4*>(lb + 24 * 128) = pre3;                                   \
+  }
+  BIL_GLOAD(0, 0);
+  BIL_LSTORE(0);
+  float pa = p[rowc * ldp];
+  __syncthreads();
+  for (int a = 0; a < NA; ++a) {
+    const int an = (a + 1 < NA) ? a + 1 : a;  // the prefetch after the last chunk re-reads a valid chunk, unused
+    float pa_next = p[rowc * ldp + an];
+    // two-level summation: the 128 products of one `a` go into fresh accumulators, which are then
+    // added to the totals -- the error growth of the reference's (W_n = T z ; y = W_n v) order,
+    // instead of one 16 384-term fp32 chain
+    f32x16 part[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) part[cb][t] = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) {
+      const int cur = jc & 1;
+      if (jc < 3) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0);
+      const float* bs = &Bs[cur][(hi * 16) * 128 + r];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        float av = pa * qreg[16 * jc + jj];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          part[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bs[jj * 128 + cb * 32], part[cb], 0, 0, 0);
+      }
+      BIL_LSTORE(cur ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb];
+    pa = pa_next;
+  }
+#undef BIL_GLOAD
+#undef BIL_LSTORE
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+      if (orow < nrows) out[(long)orow * ldo + cb * 32 + r] = acc[cb][t];
+    }
+}
+
+// any NA, NB, NC: one thread per output element (used for widths other than 128 and as a
+// cross-check of the MFMA kernel in the tests)
+__global__ void bilinear_rows_generic_kernel(const float* __restrict__ p, long ldp, const float* __restrict__ q,
+                                             long ldq, const float* __restrict__ T, const float* __restrict__ init,
+                                             long ldi, float* __restrict__ out, long ldo, int nrows, int NA, int NB,
+                                             int NC) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nrows * NC) return;
+  int n = (int)(i / NC), c = (int)(i % NC);
+  float s = init ? init[(long)n * ldi + c] : 0.f;
+  for (int a = 0; a < NA; ++a) {
+    float pa = p[(long)n * ldp + a];
+    float t = 0.f;
+    for (int b = 0; b < NB; ++b) t = fmaf(q[(long)n * ldq + b], T[((long)a * NB + b) * NC + c], t);
+    s = fmaf(pa, t, s);
+  }
+  out[(long)n * ldo + c] = s;
+}
+
+static bool force_generic() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CGAT_FORCE_GENERIC");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
+                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, hipStream_t stream) {
+  if (nrows <= 0) return CGAT_OK;
+  bool fast = NB == 128 && NC == 128 && (ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)T) & 15) == 0 &&
+              !force_generic();
+  if (fast) {
+    CGAT_PROF("bilinear_rows", stream);
+    hipLaunchKernelGGL(bilinear_rows128_kernel, dim3(cdiv(nrows, 128)), dim3(256), 0, stream, p, ldp, q, ldq, T, init,
+                       ldi, out, ldo, nrows, NA);
+  } else {
+    CGAT_PROF("bilinear_rows_generic", stream);
+    hipLaunchKernelGGL(bilinear_rows_generic_kernel, dim3(cdiv((long)nrows * NC, 256)), dim3(256), 0, stream, p, ldp,
+                       q, ldq, T, init, ldi, out, ldo, nrows, NA, NB, NC);
+  }
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: out[a,b,c] = sum_n p[n,a] q[n,b] r[n,c]
+// grid (NA, splits): one 128(b) x 128(c) output tile per workgroup over a slice of rows
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void bilinear_wgrad128_kernel(const float* __restrict__ p, long ldp,
+                                                                const float* __restrict__ q, long ldq,
+                                                                const float* __restrict__ rr, long ldr,
+                                                                float* __restrict__ slab, int nrows,
+                                                                int rows_per_split, int NA) {
+  __shared__ __attribute__((aligned(16))) float qs[2][32 * 128];
+  __shared__ __attribute__((aligned(16))) float rs[2][32 * 128];
+  __shared__ float ps[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int a = blockIdx.x, z = blockIdx.y;
+  const int nbeg = z * rows_per_split;
+  const int nend = min(nrows, nbeg + rows_per_split);
+  const int wb = (wave >> 1) * 64, wc = (wave & 1) * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+  // staging registers (named, not an array captured by a lambda: that form went to scratch)
+  float4 vq0, vq1, vq2, vq3, vr0, vr1, vr2, vr3;
+  float vp = 0.f;
+  const int f_n = tid >> 5, f_cq = tid & 31;  // piece i covers chunk row f_n + 8*i
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define WG_LOAD1(i_, vq_, vr_)                                                  \
+  {                                                                             \
+    int n = n0_ + f_n + 8 * (i_);                                               \
+    if (n < nend) {                                                             \
+      vq_ = *reinterpret_cast<const float4*>(q + (long)n * ldq + 4 * f_cq);     \
+      vr_ = *reinterpret_cast<const float4*>(rr + (long)n * ldr + 4 * f_cq);    \
+    } else {                                                                    \
+      vq_ = zero4;                                                              \
+      vr_ = zero4;                                                              \
+    }                                                                           \
+  }
+#define WG_GLOAD(n0)                                                            \
+  {                                                                             \
+    const int n0_ = (n0);                                                       \
+    WG_LOAD1(0, vq0, vr0) WG_LOAD1(1, vq1, vr1) WG_LOAD1(2, vq2, vr2) WG_LOAD1(3, vq3, vr3) \
+    if (tid < 32) vp = (n0_ + tid < nend) ? p[(long)(n0_ + tid) * ldp + a] : 0.f; \
+  }
+#define WG_LSTORE(buf)                                                          \
+  {                                                                             \
+    float* dq = &qs[buf][f_n * 128 + 4 * f_cq];                                 \
+    float* dr = &rs[buf][f_n * 128 + 4 * f_cq];                                 \
+    *reinterpret_cast<float4*>(dq) = vq0;                                       \
+    *reinterpret_cast<float4*>(dq + 8 * 128) = vq1;                             \
+    *reinterpret_cast<float4*>(dq + 16 * 128) = vq2;                            \
+    *reinterpret_cast<float4*>(dq + 24 * 128) = vq3;                            \
+    *reinterpret_cast<float4*>(dr) = vr0;                                       \
+    *reinterpret_cast<float4*>(dr + 8 * 128) = vr1;                             \
+    *reinterpret_cast<float4*>(dr + 16 * 128) = vr2;                            \
+    *reinterpret_cast<float4*>(dr + 24 * 128) = vr3;                            \
+    if (tid < 32) ps[buf][tid] = vp;                                            \
+  }
+
+  // two-level summation over the (long) row dimension: partial sums of 512 rows
+  f32x16 tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) tot[i][j][t] = 0.f;
+  const int nchunks = (nend - nbeg + 31) / 32;
+  if (nchunks > 0) {
+    WG_GLOAD(nbeg);
+    WG_LSTORE(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) WG_GLOAD(nbeg + (c + 1) * 32);
+    if ((c & 15) == 0 && c > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = 2 * i + hi;
+      float pv = ps[cur][n];
+      float a0 = pv * qs[cur][n * 128 + wb + r];
+      float a1 = pv * qs[cur][n * 128 + wb + 32 + r];
+      float b0 = rs[cur][n * 128 + wc + r];
+      float b1 = rs[cur][n * 128 + wc + 32 + r];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) WG_LSTORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef WG_LOAD1
+#undef WG_GLOAD
+#undef WG_LSTORE
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] += tot[i][j];
+  float* o = slab + ((long)z * NA + a) * 128 * 128;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      int b = wb + bi * 32 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) o[(long)b * 128 + wc + bj * 32 + r] = acc[bi][bj][t];
+    }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slab, int splits, long n, float* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slab[(long)z * n + i];
+  out[i] = s;
+}
+
+__global__ void bilinear_wgrad_generic_kernel(const float* __restrict__ p, long ldp, const float* __restrict__ q,
+                                              long ldq, const float* __restrict__ rr, long ldr,
+                                              float* __restrict__ out, int nrows, int NA, int NB, int NC) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)NA * NB * NC) return;
+  int c = (int)(i % NC);
+  int b = (int)((i / NC) % NB);
+  int a = (int)(i / ((long)NC * NB));
+  float s = 0.f;
+  for (int n = 0; n < nrows; ++n) s = fmaf(p[(long)n * ldp + a] * q[(long)n * ldq + b], rr[(long)n * ldr + c], s);
+  out[i] = s;
+}
+
+static int wgrad_splits(int nrows, int NA) {
+  int s = cdiv(512, NA);                 // aim at >= 2 workgroups per CU
+  int maxs = nrows / 256;                // at least 8 chunks of 32 rows per split
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  return s;
+}
+
+static bool wgrad_fast(const float* q, long ldq, const float* r, long ldr, int NB, int NC) {
+  return NB == 128 && NC == 128 && (ldq % 4) == 0 && (ldr % 4) == 0 && (((uintptr_t)q) & 15) == 0 &&
+         (((uintptr_t)r) & 15) == 0 && !force_generic();
+}
+
+size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
+  if (NB == 128 && NC == 128) return ws_round((size_t)wgrad_splits(nrows, NA) * NA * NB * NC, 4);
+  return 0;
+}
+
+int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
+                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (wgrad_fast(q, ldq, r, ldr, NB, NC)) {
+    int splits = wgrad_splits(nrows, NA);
+    size_t need = ws_round((size_t)splits * NA * NB * NC, 4);
+    if (!ws || ws_bytes < need) {
+      cgat_set_error("bilinear_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+      return CGAT_ERR_WORKSPACE;
+    }
+    int rps = cdiv(nrows, splits);
+    rps = ((rps + 31) / 32) * 32;
+    splits = cdiv(nrows, rps);
+    if (splits < 1) splits = 1;
+    {
+      CGAT_PROF("bilinear_wgrad", stream);
+      hipLaunchKernelGGL(bilinear_wgrad128_kernel, dim3(NA, splits), dim3(256), 0, stream, p, ldp, q, ldq, r, ldr,
+                         (float*)ws, nrows, rps, NA);
+    }
+    CGAT_LAUNCH_CHECK();
+    long n = (long)NA * NB * NC;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, splits, n, out);
+    CGAT_LAUNCH_CHECK();
+  } else {
+    CGAT_PROF("bilinear_wgrad_generic", stream);
+    long n = (long)NA * NB * NC;
+    hipLaunchKernelGGL(bilinear_wgrad_generic_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, ldp, q, ldq, r, ldr,
+                       out, nrows, NA, NB, NC);
+    CGAT_LAUNCH_CHECK();
+  }
+  return CGAT_OK;
+}
+
+// dst = src with its three indices permuted: dst dims are (n[perm0], n[perm1], n[perm2])
+__global__ void permute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2,
+                                int perm0, int perm1, int perm2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)n0 * n1 * n2;
+  if (i >= total) return;
+  int dims[3] = {n0, n1, n2};
+  int d0 = dims[perm0], d1 = dims[perm1], d2 = dims[perm2];
+  (void)d0;
+  int z = (int)(i % d2);
+  int y = (int)((i / d2) % d1);
+  int x = (int)(i / ((long)d2 * d1));
+  int idx[3];
+  idx[perm0] = x; idx[perm1] = y; idx[perm2] = z;
+  dst[i] = src[((long)idx[0] * n1 + idx[1]) * n2 + idx[2]];
+}
+
+int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
+                    hipStream_t stream) {
+  long total = (long)n0 * n1 * n2;
+  if (total <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(permute3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, dst, n0, n1, n2, perm0, perm1,
+                     perm2);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}

@@ -1,0 +1,93 @@
+// Internal launch interface between the kernel files and the layer orchestrators.
+#pragma once
+#include "common.h"
+
+#define CGAT_ACT_NONE 0
+#define CGAT_ACT_TANH 1
+#define CGAT_ACT_LEAKY 2  // LeakyReLU, slope 0.01 (nn.LeakyReLU() default; reference CGAT.py:95)
+#define CGAT_ACT_RELU 3
+
+struct GemmParams {
+  int M, N, K;
+  const float* A;
+  long lda;
+  int a_kmajor;          // 0: A(m,k)=A[row(m)*lda+k]   1: A(m,k)=A[k*lda+m]
+  const int* a_rgather;  // a_kmajor==0 only: row(m)=a_rgather[m]
+  const float* B;
+  long ldb;
+  int b_kmajor;          // 0: B(k,n)=B[n*ldb+k] (torch Linear weight)   1: B(k,n)=B[krow(k)*ldb+n]
+  const int* b_kgather;  // b_kmajor==1 only: krow(k)=b_kgather[k]
+  float* C;
+  long ldc;
+  const int* c_scatter;  // output row = c_scatter[m]
+  float alpha, beta;     // C = act(alpha*acc + bias + adds) + beta*C
+  const float* bias;     // [N]
+  const float* add1;     // rows gathered by add1_idx[m], leading dim ld_add
+  const int* add1_idx;
+  const float* add2;
+  const int* add2_idx;
+  long ld_add;
+  int act;
+  int splits;            // >1: split the K range, partial slabs in workspace, then reduce
+  // filled by gemm_launch
+  int k_per_split, a_vec, b_vec;
+  float* slab;
+};
+
+static inline GemmParams gemm_params(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                                     long ldc) {
+  GemmParams p = {};
+  p.M = M; p.N = N; p.K = K;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.alpha = 1.f; p.beta = 0.f; p.splits = 1;
+  return p;
+}
+
+int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream);
+int gemm_pick_splits(int M, int N, int K);
+size_t gemm_ws_bytes(const GemmParams& p);
+
+// ---- bilinear (hypernetwork) contractions, bilinear.hip ----
+// out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T[(a*NB+b)*NC + c]
+int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
+                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, hipStream_t stream);
+// out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c]      (workspace: slabs)
+size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
+int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
+                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream);
+// dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
+int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
+                    hipStream_t stream);
+
+// ---- elementwise / row kernels, rowops.hip ----
+int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float eps, hipStream_t s);
+int layernorm_tanh_bwd_launch(const float* u, const float* y, const float* gy, float* gu, int rows, int W, float eps,
+                              hipStream_t s);
+int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act, hipStream_t s);  // in terms of post-activation y
+int colsum_launch(const float* x, long ldx, int rows, int cols, float* out, float alpha, void* ws, size_t ws_bytes,
+                  hipStream_t s);
+size_t colsum_ws_bytes(int rows, int cols);
+int mix_launch(const float* a, const float* b, const float* d, float* out, long n, hipStream_t s);  // out = d*a + (1-d)*b
+int mix_bwd_launch(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb_accum,
+                   float* gd, long n, void* ws, size_t ws_bytes, hipStream_t s);
+int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s);  // y += alpha*x
+int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t s);
+int fill_launch(float* p, float v, long n, hipStream_t s);
+
+// ---- segment kernels (rows sorted by segment, rowptr[S+1]), segment.hip ----
+int seg_softmax_fwd_launch(const float* a, const float* mult, const int* rowptr, int S, int F, float eps, float* alpha,
+                           float* ssum, hipStream_t s);
+int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float* gssum, const float* mult,
+                           const int* rowptr, int S, int F, float* ga, float* gmult, hipStream_t s);
+// out[s, f] = sum_{r in seg s} w[r, f / fw] * act(x[r or ridx[r], f])      (w nullable, fw = features per weight)
+int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
+                    int F, int act, float* out, long ldo, hipStream_t s);
+// per-row, per-head dot:  out[r,h] = sum_j act(x[r, h*Hd+j]) * v[(vrow(r)) * ldv + h*Hd + j] + bias[h] (+ addv[vrow(r)*H + h])
+int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, const int* vrow, const float* bias,
+                  const float* addv, int rows, int H, int Hd, float* out, hipStream_t s);
+
+// ---- CSR plan, plan.hip ----
+size_t plan_ws_bytes(int E, int N);
+int plan_build_launch(const int64_t* edge_index, int E, int N, int* dst_rowptr, int* dst_perm, int* dst_sorted,
+                      int* src_sorted, int* src_rowptr, int* src_pos, void* ws, size_t ws_bytes, hipStream_t s);
+int csr_from_keys_launch(const int* keys, int n, int S, int* rowptr, int* perm, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,530 @@
+// Layer orchestrators: the sequence of kernel launches behind each C-ABI entry point.
+// Host code only decides shapes, carves the caller's workspace and enqueues on the caller's
+// stream -- no allocation, no synchronisation.
+#include <string.h>
+
+#include "../../include/cgat_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// launch context: persistent workspace carve-outs + one scratch region shared (in stream
+// order) by split-K slabs / column-sum partials.  `dry` only measures.
+// ---------------------------------------------------------------------------------------
+struct Ctx {
+  Workspace w;
+  bool dry;
+  hipStream_t s;
+  size_t scratch_need;
+  char* scratch;
+  size_t scratch_bytes;
+  Ctx(void* ws, size_t bytes, bool dry_, hipStream_t st)
+      : w(dry_ ? nullptr : ws, dry_ ? (size_t)-1 / 2 : bytes), dry(dry_), s(st), scratch_need(0), scratch(nullptr),
+        scratch_bytes(0) {}
+  template <typename T>
+  T* take(size_t n) { return w.take<T>(n); }
+  void seal() {  // everything after the persistent carve-outs is scratch
+    if (!dry) {
+      scratch = w.base + w.off;
+      scratch_bytes = w.cap > w.off ? w.cap - w.off : 0;
+    }
+  }
+  size_t total() const { return w.off + scratch_need + 256; }
+  void need(size_t b) { if (b > scratch_need) scratch_need = b; }
+
+  int gemm(GemmParams p, bool auto_split = false) {
+    if (auto_split) p.splits = gemm_pick_splits(p.M, p.N, p.K);
+    if (p.splits > 1) need(ws_round((size_t)p.splits * p.M * p.N, 4));
+    if (dry) return CGAT_OK;
+    return gemm_launch(p, scratch, scratch_bytes, s);
+  }
+  int colsum(const float* x, long ldx, int rows, int cols, float* out, float alpha) {
+    need(colsum_ws_bytes(rows, cols));
+    if (dry) return CGAT_OK;
+    return colsum_launch(x, ldx, rows, cols, out, alpha, scratch, scratch_bytes, s);
+  }
+  int wgrad(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out, int rows, int NA,
+            int NB, int NC) {
+    need(bilinear_wgrad_ws_bytes(rows, NA, NB, NC));
+    if (dry) return CGAT_OK;
+    return bilinear_wgrad_launch(p, ldp, q, ldq, r, ldr, out, rows, NA, NB, NC, scratch, scratch_bytes, s);
+  }
+  int mix_bwd(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb, float* gd, long n) {
+    need(4096);
+    if (dry) return CGAT_OK;
+    return mix_bwd_launch(g, a, b, d, ga, gb, gd, n, scratch, scratch_bytes, s);
+  }
+};
+
+#define RUN(expr) do { if (!c.dry) CGAT_TRY(expr); } while (0)
+
+static int check_ws(const Ctx& c, const char* who) {
+  if (c.dry) return CGAT_OK;
+  if (!c.w.ok || c.scratch_bytes < c.scratch_need) {
+    cgat_set_error("%s: workspace too small (have %zu bytes, need %zu)", who, c.w.cap, c.total());
+    return CGAT_ERR_WORKSPACE;
+  }
+  return CGAT_OK;
+}
+
+// =======================================================================================
+// GATConvNodes message / softmax / aggregate
+// =======================================================================================
+// In-place-free edge backward: gZ[t, :] from Z[t, :], plus per-chunk partial column sums of
+// g_a * leaky(zA) for the gradient of MH_A.fc_out.weight.
+#define GZ_ROWS 64
+__global__ void edge_gz_kernel(const float* __restrict__ Z, float* __restrict__ gZ, const float* __restrict__ ga,
+                               const float* __restrict__ alpha, const float* __restrict__ gS,
+                               const int* __restrict__ dst, const float* __restrict__ wA_out, int E, int H, int Hd,
+                               float* __restrict__ partial) {
+  const int HHd = H * Hd, W2 = 2 * HHd;
+  const int chunk = blockIdx.x;
+  const int t0 = chunk * GZ_ROWS, t1 = min(E, t0 + GZ_ROWS);
+  for (int col = threadIdx.x; col < W2; col += blockDim.x) {
+    const bool isA = col < HHd;
+    const int cc = isA ? col : col - HHd;
+    const int h = cc / Hd;
+    const float wv = isA ? wA_out[cc] : 0.f;
+    float psum = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      float z = Z[(long)t * W2 + col];
+      float d = z > 0.f ? 1.f : 0.01f;
+      float g;
+      if (isA) {
+        float gav = ga[(long)t * H + h];
+        g = gav * wv * d;
+        psum += gav * (z > 0.f ? z : 0.01f * z);
+      } else {
+        g = alpha[(long)t * H + h] * gS[(long)dst[t] * HHd + cc] * d;
+      }
+      gZ[(long)t * W2 + col] = g;
+    }
+    if (isA) partial[(long)chunk * HHd + cc] = psum;
+  }
+}
+
+struct AttnDims {
+  int N, E, C, Ce, H, Hd, D, HHd, W2;
+};
+static AttnDims attn_dims(const cgat_plan* plan, const cgat_attn_params* p) {
+  AttnDims d;
+  d.N = plan->N; d.E = plan->E; d.C = p->C; d.Ce = p->Ce; d.H = p->H; d.Hd = p->Hd;
+  d.D = 2 * p->C + p->Ce; d.HHd = p->H * p->Hd; d.W2 = 2 * d.HHd;
+  return d;
+}
+
+struct AttnSaved {
+  float *Z, *alpha, *S, *ssum;
+};
+static AttnSaved attn_saved(float* saved, const AttnDims& d) {
+  AttnSaved s;
+  s.Z = saved;
+  s.alpha = s.Z + (size_t)d.E * d.W2;
+  s.S = s.alpha + (size_t)d.E * d.H;
+  s.ssum = s.S + (size_t)d.N * d.HHd;
+  return s;
+}
+
+extern "C" size_t cgat_nodes_attention_saved_floats(int32_t N, int32_t E, int32_t H, int32_t Hd) {
+  size_t HHd = (size_t)H * Hd;
+  return (size_t)E * 2 * HHd + (size_t)E * H + (size_t)N * HHd + (size_t)N * H;
+}
+
+static int stack_in_weights(Ctx& c, const cgat_attn_params* p, const AttnDims& d, float* Wcat, float* bcat) {
+  RUN(copy2d_launch(p->A_in_w, d.D, Wcat, d.D, d.HHd, d.D, c.s));
+  RUN(copy2d_launch(p->M_in_w, d.D, Wcat + (size_t)d.HHd * d.D, d.D, d.HHd, d.D, c.s));
+  if (bcat) {
+    RUN(copy2d_launch(p->A_in_b, d.HHd, bcat, d.HHd, 1, d.HHd, c.s));
+    RUN(copy2d_launch(p->M_in_b, d.HHd, bcat + d.HHd, d.HHd, 1, d.HHd, c.s));
+  }
+  return CGAT_OK;
+}
+
+static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_params* p, const float* x, const float* e,
+                             float* aggr, float* saved) {
+  const AttnDims d = attn_dims(plan, p);
+  float* Wcat = c.take<float>((size_t)d.W2 * d.D);
+  float* bcat = c.take<float>((size_t)d.W2);
+  float* Pi = c.take<float>((size_t)d.N * d.W2);
+  float* Pj = c.take<float>((size_t)d.N * d.W2);
+  float* a = c.take<float>((size_t)d.E * d.H);
+  c.seal();
+  AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(saved, d);
+
+  CGAT_TRY(stack_in_weights(c, p, d, Wcat, bcat));
+  // first conv layer split by operand: W_in [x_i;e;x_j] = W_i x_i + W_e e + W_j x_j
+  {
+    GemmParams g = gemm_params(d.N, d.W2, d.C, x, d.C, Wcat, d.D, Pi, d.W2);
+    g.bias = bcat;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.N, d.W2, d.C, x, d.C, Wcat + d.C + d.Ce, d.D, Pj, d.W2);
+    CGAT_TRY(c.gemm(g));
+  }
+  {  // Z[t] = W_e e[perm[t]] + Pi[dst[t]] + Pj[src[t]]      (x_i = x[edge_index[1]], x_j = x[edge_index[0]])
+    GemmParams g = gemm_params(d.E, d.W2, d.Ce, e, d.Ce, Wcat + d.C, d.D, sv.Z, d.W2);
+    g.a_rgather = plan->dst_perm;
+    g.add1 = Pi; g.add1_idx = plan->dst_sorted;
+    g.add2 = Pj; g.add2_idx = plan->src_sorted;
+    g.ld_add = d.W2;
+    CGAT_TRY(c.gemm(g));
+  }
+  // attention logits a[t,h] = fc_out_A(leaky(zA))
+  RUN(rowdot_launch(sv.Z, d.W2, CGAT_ACT_LEAKY, p->A_out_w, 0, nullptr, p->A_out_b, nullptr, d.E, d.H, d.Hd, a, c.s));
+  RUN(seg_softmax_fwd_launch(a, nullptr, plan->dst_rowptr, d.N, d.H, 1e-16f, sv.alpha, sv.ssum, c.s));
+  // S[n,h,:] = sum_{t -> n} alpha[t,h] leaky(zM[t,h,:])  -- fc_out of MH_M commutes with the weighted sum
+  RUN(seg_wsum_launch(sv.Z + d.HHd, d.W2, nullptr, sv.alpha, d.H, d.Hd, plan->dst_rowptr, d.N, d.HHd, CGAT_ACT_LEAKY,
+                      sv.S, d.HHd, c.s));
+  for (int h = 0; h < d.H; ++h) {
+    GemmParams g = gemm_params(d.N, d.C, d.Hd, sv.S + (size_t)h * d.Hd, d.HHd, p->M_out_w + (size_t)h * d.C * d.Hd,
+                               d.Hd, aggr, d.C);
+    g.alpha = 1.f / d.H;
+    g.beta = h > 0 ? 1.f : 0.f;
+    CGAT_TRY(c.gemm(g));
+  }
+  {  // + (1/H) sum_h ssum[n,h] * fc_out bias
+    GemmParams g = gemm_params(d.N, d.C, d.H, sv.ssum, d.H, p->M_out_b, d.C, aggr, d.C);
+    g.b_kmajor = 1;
+    g.alpha = 1.f / d.H;
+    g.beta = 1.f;
+    CGAT_TRY(c.gemm(g));
+  }
+  return check_ws(c, "nodes_attention_forward");
+}
+
+static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_params* p, const float* x, const float* e,
+                              const float* saved, const float* g_aggr, float* g_x, float* g_e,
+                              const cgat_attn_grads* gr) {
+  const AttnDims d = attn_dims(plan, p);
+  const int chunks = cdiv(d.E > 0 ? d.E : 1, GZ_ROWS);
+  float* Wcat = c.take<float>((size_t)d.W2 * d.D);
+  float* gWcat = c.take<float>((size_t)d.W2 * d.D);
+  float* gbcat = c.take<float>((size_t)d.W2);
+  float* gS = c.take<float>((size_t)d.N * d.HHd);
+  float* gs = c.take<float>((size_t)d.N * d.H);
+  float* tt = c.take<float>((size_t)d.E * d.H);
+  float* ga = c.take<float>((size_t)d.E * d.H);
+  float* gZ = c.take<float>((size_t)d.E * d.W2);
+  float* partial = c.take<float>((size_t)chunks * d.HHd);
+  float* Gi = c.take<float>((size_t)d.N * d.W2);
+  float* Gj = c.take<float>((size_t)d.N * d.W2);
+  c.seal();
+  AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(const_cast<float*>(saved), d);
+  const float invH = 1.f / d.H;
+
+  CGAT_TRY(stack_in_weights(c, p, d, Wcat, nullptr));
+  for (int h = 0; h < d.H; ++h) {
+    const float* Wo = p->M_out_w + (size_t)h * d.C * d.Hd;
+    {  // gS[:,h,:] = (1/H) g_aggr @ fc_out_M[h]
+      GemmParams g = gemm_params(d.N, d.Hd, d.C, g_aggr, d.C, Wo, d.Hd, gS + (size_t)h * d.Hd, d.HHd);
+      g.b_kmajor = 1;
+      g.alpha = invH;
+      CGAT_TRY(c.gemm(g));
+    }
+    {  // grad fc_out_M[h] = (1/H) g_aggr^T S[:,h,:]
+      GemmParams g = gemm_params(d.C, d.Hd, d.N, g_aggr, d.C, sv.S + (size_t)h * d.Hd, d.HHd,
+                                 gr->M_out_w + (size_t)h * d.C * d.Hd, d.Hd);
+      g.a_kmajor = 1; g.b_kmajor = 1;
+      g.alpha = invH;
+      CGAT_TRY(c.gemm(g, true));
+    }
+  }
+  {  // gs[n,h] = (1/H) g_aggr[n,:] . bias_M[h,:]
+    GemmParams g = gemm_params(d.N, d.H, d.C, g_aggr, d.C, p->M_out_b, d.C, gs, d.H);
+    g.alpha = invH;
+    CGAT_TRY(c.gemm(g));
+    // grad bias_M[h,c] = (1/H) sum_n ssum[n,h] g_aggr[n,c]
+    g = gemm_params(d.H, d.C, d.N, sv.ssum, d.H, g_aggr, d.C, gr->M_out_b, d.C);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.alpha = invH;
+    CGAT_TRY(c.gemm(g, true));
+  }
+  // g_alpha[t,h] = leaky(zM[t,h,:]) . gS[dst,h,:] + gs[dst,h]
+  RUN(rowdot_launch(sv.Z + d.HHd, d.W2, CGAT_ACT_LEAKY, gS, d.HHd, plan->dst_sorted, nullptr, gs, d.E, d.H, d.Hd, tt,
+                    c.s));
+  RUN(seg_softmax_bwd_launch(sv.alpha, tt, nullptr, nullptr, plan->dst_rowptr, d.N, d.H, ga, nullptr, c.s));
+  CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
+  if (!c.dry && d.E > 0) {
+    hipLaunchKernelGGL(edge_gz_kernel, dim3(chunks), dim3(256), 0, c.s, sv.Z, gZ, ga, sv.alpha, gS, plan->dst_sorted,
+                       p->A_out_w, d.E, d.H, d.Hd, partial);
+    CGAT_LAUNCH_CHECK();
+  }
+  CGAT_TRY(c.colsum(partial, d.HHd, d.E > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
+  {  // grad edge_attr[perm[t]] = gZ[t] @ W_e
+    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, d.W2, Wcat + d.C, d.D, g_e, d.Ce);
+    g.b_kmajor = 1;
+    g.c_scatter = plan->dst_perm;
+    CGAT_TRY(c.gemm(g));
+    // grad W_e = gZ^T @ e[perm]
+    g = gemm_params(d.W2, d.Ce, d.E, gZ, d.W2, e, d.Ce, gWcat + d.C, d.D);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.b_kgather = plan->dst_perm;
+    CGAT_TRY(c.gemm(g, true));
+  }
+  // segment sums of gZ by destination (x_i side) and by source (x_j side)
+  RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s));
+  RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
+                      c.s));
+  {
+    GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
+    g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.N, d.C, d.W2, Gj, d.W2, Wcat + d.C + d.Ce, d.D, g_x, d.C);
+    g.b_kmajor = 1;
+    g.beta = 1.f;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.W2, d.C, d.N, Gi, d.W2, x, d.C, gWcat, d.D);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g, true));
+    g = gemm_params(d.W2, d.C, d.N, Gj, d.W2, x, d.C, gWcat + d.C + d.Ce, d.D);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g, true));
+  }
+  CGAT_TRY(c.colsum(Gi, d.W2, d.N, d.W2, gbcat, 1.f));
+  RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
+  RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
+  RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));
+  RUN(copy2d_launch(gbcat + d.HHd, d.HHd, gr->M_in_b, d.HHd, 1, d.HHd, c.s));
+  return check_ws(c, "nodes_attention_backward");
+}
+
+static int attn_check(const cgat_plan* plan, const cgat_attn_params* p) {
+  CGAT_CHECK_ARG(plan && p, "nodes_attention: null plan/params");
+  CGAT_CHECK_ARG(plan->N >= 0 && plan->E >= 0, "nodes_attention: negative N/E");
+  CGAT_CHECK_ARG(p->C > 0 && p->Ce > 0 && p->H > 0 && p->Hd > 0, "nodes_attention: bad dims C=%d Ce=%d H=%d Hd=%d",
+                 p->C, p->Ce, p->H, p->Hd);
+  return CGAT_OK;
+}
+
+extern "C" size_t cgat_nodes_attention_forward_workspace_bytes(const cgat_plan* plan, const cgat_attn_params* p) {
+  Ctx c(nullptr, 0, true, nullptr);
+  attn_forward_impl(c, plan, p, nullptr, nullptr, nullptr, nullptr);
+  return c.total();
+}
+extern "C" size_t cgat_nodes_attention_backward_workspace_bytes(const cgat_plan* plan, const cgat_attn_params* p) {
+  Ctx c(nullptr, 0, true, nullptr);
+  cgat_attn_grads g = {};
+  attn_backward_impl(c, plan, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &g);
+  return c.total();
+}
+extern "C" int cgat_nodes_attention_forward(const cgat_plan* plan, const cgat_attn_params* p, const float* x,
+                                            const float* edge_attr, float* aggr, float* saved, void* ws,
+                                            size_t ws_bytes, void* stream) {
+  CGAT_TRY(attn_check(plan, p));
+  {
+    Ctx dry(nullptr, 0, true, nullptr);
+    attn_forward_impl(dry, plan, p, nullptr, nullptr, nullptr, nullptr);
+    if (ws_bytes < dry.total()) {
+      cgat_set_error("nodes_attention_forward: workspace too small (%zu < %zu)", ws_bytes, dry.total());
+      return CGAT_ERR_WORKSPACE;
+    }
+    Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+    c.scratch_need = dry.scratch_need;
+    return attn_forward_impl(c, plan, p, x, edge_attr, aggr, saved);
+  }
+}
+extern "C" int cgat_nodes_attention_backward(const cgat_plan* plan, const cgat_attn_params* p, const float* x,
+                                             const float* edge_attr, const float* saved, const float* g_aggr,
+                                             float* g_x, float* g_edge_attr, const cgat_attn_grads* g, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  CGAT_TRY(attn_check(plan, p));
+  CGAT_CHECK_ARG(g, "nodes_attention_backward: null grads");
+  Ctx dry(nullptr, 0, true, nullptr);
+  attn_backward_impl(dry, plan, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g);
+  if (ws_bytes < dry.total()) {
+    cgat_set_error("nodes_attention_backward: workspace too small (%zu < %zu)", ws_bytes, dry.total());
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  c.scratch_need = dry.scratch_need;
+  return attn_backward_impl(c, plan, p, x, edge_attr, saved, g_aggr, g_x, g_edge_attr, g);
+}
+
+// =======================================================================================
+// hypernetwork Pooling_NN  (H_Net_0 / H_Net)
+// =======================================================================================
+struct HnetSaved {  // acts[l][s] (s < n_fc), u[l], vin[l] (l >= 1), hin
+  float* base;
+  size_t rw;  // rows * W
+  int n_fc, n_hyper;
+  float* act(int l, int s) const { return base + ((size_t)l * n_fc + s) * rw; }
+  float* u(int l) const { return base + ((size_t)n_hyper * n_fc + l) * rw; }
+  float* vin(int l) const { return base + ((size_t)n_hyper * n_fc + n_hyper + l) * rw; }  // l >= 1 used
+  float* hin() const { return base + ((size_t)n_hyper * n_fc + 2 * (size_t)n_hyper) * rw; }
+};
+extern "C" size_t cgat_hnet_saved_floats(int32_t rows, const cgat_hnet_params* p) {
+  return ((size_t)p->n_hyper * p->n_fc + 2 * (size_t)p->n_hyper + 1) * (size_t)rows * p->W;
+}
+static HnetSaved hnet_saved(float* base, int rows, const cgat_hnet_params* p) {
+  return HnetSaved{base, (size_t)rows * p->W, p->n_fc, p->n_hyper};
+}
+
+static int hnet_check(int rows, const cgat_hnet_params* p) {
+  CGAT_CHECK_ARG(p, "hnet: null params");
+  CGAT_CHECK_ARG(rows >= 0 && p->W > 0, "hnet: bad rows/W");
+  CGAT_CHECK_ARG(p->n_fc >= 1 && p->n_fc <= CGAT_MAX_FC && p->n_hyper >= 1 && p->n_hyper <= CGAT_MAX_HYPER,
+                 "hnet: n_fc=%d n_hyper=%d out of range", p->n_fc, p->n_hyper);
+  return CGAT_OK;
+}
+
+static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const float* h0, const float* v, float* y,
+                             float* saved) {
+  const int W = p->W;
+  const size_t WW = (size_t)W * W;
+  float* Tp = c.take<float>(WW * W);
+  c.seal();
+  HnetSaved sv = hnet_saved(saved, rows, p);
+  const float* hin = h0;
+  if (p->damping) {
+    RUN(mix_launch(h0, v, p->damping, sv.hin(), (long)rows * W, c.s));
+    hin = sv.hin();
+  }
+  const float* vin = v;
+  for (int l = 0; l < p->n_hyper; ++l) {
+    const cgat_hyperlinear_params& L = p->layer[l];
+    const float* t = hin;
+    for (int s = 0; s < p->n_fc; ++s) {  // trunk: Linear + Tanh
+      GemmParams g = gemm_params(rows, W, W, t, W, L.fc_w[s], W, c.dry ? nullptr : sv.act(l, s), W);
+      g.bias = L.fc_b[s];
+      g.act = CGAT_ACT_TANH;
+      CGAT_TRY(c.gemm(g));
+      t = c.dry ? nullptr : sv.act(l, s);
+    }
+    const float* z = t;
+    float* u = c.dry ? nullptr : ((l == p->n_hyper - 1) ? y : sv.u(l));
+    // bias-row terms of the head:  u = vin @ Bm^T + z @ U^T + b0,  Bm = head_b[:W*W] as [o,i], U = head_w[W*W:]
+    {
+      GemmParams g = gemm_params(rows, W, W, vin, W, L.head_b, W, u, W);
+      CGAT_TRY(c.gemm(g));
+      g = gemm_params(rows, W, W, z, W, L.head_w + WW * W, W, u, W);
+      g.bias = L.head_b + WW;
+      g.beta = 1.f;
+      CGAT_TRY(c.gemm(g));
+    }
+    // trilinear term with T[o,i,k] = head_w[(o*W+i)*W + k] re-laid as Tp[i,k,o]
+    RUN(permute3_launch(L.head_w, Tp, W, W, W, 1, 2, 0, c.s));
+    RUN(bilinear_rows_launch(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W, c.s));
+    if (l < p->n_hyper - 1) {
+      RUN(layernorm_tanh_fwd_launch(u, sv.vin(l + 1), rows, W, 1e-5f, c.s));
+      vin = c.dry ? nullptr : sv.vin(l + 1);
+    }
+  }
+  return check_ws(c, "hnet_forward");
+}
+
+static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const float* h0, const float* v,
+                              const float* saved, const float* g_y, float* g_h0, float* g_v,
+                              const cgat_hnet_grads* gr) {
+  const int W = p->W;
+  const size_t WW = (size_t)W * W;
+  const size_t rw = (size_t)rows * W;
+  float* Tp = c.take<float>(WW * W);
+  float* g_hin = c.take<float>(rw);
+  float* g_u = c.take<float>(rw);
+  float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
+  float* g_t = c.take<float>(rw);
+  float* g_pre = c.take<float>(rw);
+  c.seal();
+  HnetSaved sv = hnet_saved(const_cast<float*>(saved), rows, p);
+  const float* hin = p->damping ? sv.hin() : h0;
+  RUN(fill_launch(g_hin, 0.f, (long)rw, c.s));
+  const float* gout = g_y;  // gradient wrt the output of predicted layer l (post norm for l < last)
+  for (int l = p->n_hyper - 1; l >= 0; --l) {
+    const cgat_hyperlinear_params& L = p->layer[l];
+    const cgat_hyperlinear_grads& G = gr->layer[l];
+    const float* gu = gout;  // gradient wrt the pre-norm output u_l
+    if (l < p->n_hyper - 1) {
+      RUN(layernorm_tanh_bwd_launch(sv.u(l), sv.vin(l + 1), gout, g_u, rows, W, 1e-5f, c.s));
+      gu = g_u;
+    }
+    float* g_vin = (l == 0) ? g_v : gvin_buf[l & 1];  // gradient wrt this layer's input
+    const float* vin = (l == 0) ? v : sv.vin(l);
+    const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
+    // ---- head parameter gradients ----
+    CGAT_TRY(c.wgrad(gu, W, vin, W, z, W, G.head_w, rows, W, W, W));  // [o][i][k]
+    {
+      GemmParams g = gemm_params(W, W, rows, gu, W, vin, W, G.head_b, W);  // Bm grad [o][i]
+      g.a_kmajor = 1; g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g, true));
+      g = gemm_params(W, W, rows, gu, W, z, W, G.head_w + WW * W, W);  // U grad [o][k]
+      g.a_kmajor = 1; g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g, true));
+    }
+    CGAT_TRY(c.colsum(gu, W, rows, W, G.head_b + WW, 1.f));
+    // ---- g_z = gu @ U + sum_{o,i} gu[o] vin[i] T[o,i,k]  (T in its stored layout) ----
+    {
+      GemmParams g = gemm_params(rows, W, W, gu, W, L.head_w + WW * W, W, g_t, W);
+      g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g));
+    }
+    RUN(bilinear_rows_launch(gu, W, vin, W, L.head_w, g_t, W, g_t, W, rows, W, W, W, c.s));
+    // ---- g_vin = gu @ Bm + sum_{o,k} gu[o] z[k] T[o,i,k]   (T re-laid as [o,k,i]) ----
+    {
+      GemmParams g = gemm_params(rows, W, W, gu, W, L.head_b, W, g_vin, W);
+      g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g));
+    }
+    RUN(permute3_launch(L.head_w, Tp, W, W, W, 0, 2, 1, c.s));
+    RUN(bilinear_rows_launch(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W, c.s));
+    // ---- trunk backward (g_t holds the gradient wrt the trunk output z) ----
+    for (int s = p->n_fc - 1; s >= 0; --s) {
+      const float* tout = c.dry ? nullptr : sv.act(l, s);
+      const float* tin = (s == 0) ? hin : (c.dry ? nullptr : sv.act(l, s - 1));
+      RUN(act_bwd_launch(tout, g_t, g_pre, (long)rw, CGAT_ACT_TANH, c.s));
+      GemmParams g = gemm_params(W, W, rows, g_pre, W, tin, W, G.fc_w[s], W);
+      g.a_kmajor = 1; g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g, true));
+      CGAT_TRY(c.colsum(g_pre, W, rows, W, G.fc_b[s], 1.f));
+      g = gemm_params(rows, W, W, g_pre, W, L.fc_w[s], W, s == 0 ? g_hin : g_t, W);
+      g.b_kmajor = 1;
+      g.beta = (s == 0) ? 1.f : 0.f;  // every predicted layer's trunk reads the same hyper input
+      CGAT_TRY(c.gemm(g));
+    }
+    gout = g_vin;
+  }
+  if (p->damping) {
+    CGAT_TRY(c.mix_bwd(g_hin, h0, v, p->damping, g_h0, g_v, gr->damping, (long)rw));
+  } else {
+    RUN(copy2d_launch(g_hin, W, g_h0, W, rows, W, c.s));
+  }
+  return check_ws(c, "hnet_backward");
+}
+
+extern "C" size_t cgat_hnet_forward_workspace_bytes(int32_t rows, const cgat_hnet_params* p) {
+  Ctx c(nullptr, 0, true, nullptr);
+  hnet_forward_impl(c, rows, p, nullptr, nullptr, nullptr, nullptr);
+  return c.total();
+}
+extern "C" size_t cgat_hnet_backward_workspace_bytes(int32_t rows, const cgat_hnet_params* p) {
+  Ctx c(nullptr, 0, true, nullptr);
+  cgat_hnet_grads g = {};
+  hnet_backward_impl(c, rows, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &g);
+  return c.total();
+}
+extern "C" int cgat_hnet_forward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v, float* y,
+                                 float* saved, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_TRY(hnet_check(rows, p));
+  Ctx dry(nullptr, 0, true, nullptr);
+  hnet_forward_impl(dry, rows, p, nullptr, nullptr, nullptr, nullptr);
+  if (ws_bytes < dry.total()) {
+    cgat_set_error("hnet_forward: workspace too small (%zu < %zu)", ws_bytes, dry.total());
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  c.scratch_need = dry.scratch_need;
+  return hnet_forward_impl(c, rows, p, h0, v, y, saved);
+}
+extern "C" int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,
+                                  const float* saved, const float* g_y, float* g_h0, float* g_v,
+                                  const cgat_hnet_grads* g, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_TRY(hnet_check(rows, p));
+  CGAT_CHECK_ARG(g, "hnet_backward: null grads");
+  Ctx dry(nullptr, 0, true, nullptr);
+  hnet_backward_impl(dry, rows, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g);
+  if (ws_bytes < dry.total()) {
+    cgat_set_error("hnet_backward: workspace too small (%zu < %zu)", ws_bytes, dry.total());
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  c.scratch_need = dry.scratch_need;
+  return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g);
+}

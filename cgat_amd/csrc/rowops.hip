@@ -1,0 +1,247 @@
+// Row-wise / elementwise kernels around the matrix-core products: LayerNorm(no affine)+tanh
+// of the predicted layers (reference Hypernetworksmp.py:103-107), activation derivatives,
+// column sums for bias gradients, the H_Net damping mix (Hypernetworksmp.py:310-312).
+// All HBM-bound, one wave per row or grid-stride; accurate tanhf/rsqrtf (no fast-math).
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// y = tanh((u - mean) * rsqrt(var + eps)), biased variance; one wave per row
+__global__ void layernorm_tanh_fwd_kernel(const float* __restrict__ u, float* __restrict__ y, int rows, int W,
+                                          float eps) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = u + (long)row * W;
+  float s = 0.f;
+  for (int c = lane; c < W; c += 64) s += x[c];
+  float mean = wave_sum(s) / W;
+  float v = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    float d = x[c] - mean;
+    v += d * d;
+  }
+  float rstd = rsqrtf(wave_sum(v) / W + eps);
+  for (int c = lane; c < W; c += 64) y[(long)row * W + c] = tanhf((x[c] - mean) * rstd);
+}
+
+// gu = rstd * (gx - mean(gx) - xhat * mean(gx * xhat)),  gx = gy * (1 - y^2)
+__global__ void layernorm_tanh_bwd_kernel(const float* __restrict__ u, const float* __restrict__ y,
+                                          const float* __restrict__ gy, float* __restrict__ gu, int rows, int W,
+                                          float eps) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = u + (long)row * W;
+  const float* yy = y + (long)row * W;
+  const float* g = gy + (long)row * W;
+  float s = 0.f;
+  for (int c = lane; c < W; c += 64) s += x[c];
+  float mean = wave_sum(s) / W;
+  float v = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    float d = x[c] - mean;
+    v += d * d;
+  }
+  float rstd = rsqrtf(wave_sum(v) / W + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    float gx = g[c] * (1.f - yy[c] * yy[c]);
+    s1 += gx;
+    s2 += gx * (x[c] - mean) * rstd;
+  }
+  s1 = wave_sum(s1) / W;
+  s2 = wave_sum(s2) / W;
+  for (int c = lane; c < W; c += 64) {
+    float gx = g[c] * (1.f - yy[c] * yy[c]);
+    float xh = (x[c] - mean) * rstd;
+    gu[(long)row * W + c] = rstd * (gx - s1 - xh * s2);
+  }
+}
+
+int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float eps, hipStream_t s) {
+  if (rows <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(layernorm_tanh_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, u, y, rows, W, eps);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+int layernorm_tanh_bwd_launch(const float* u, const float* y, const float* gy, float* gu, int rows, int W, float eps,
+                              hipStream_t s) {
+  if (rows <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(layernorm_tanh_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, u, y, gy, gu, rows, W, eps);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// derivative through an activation, expressed with the post-activation value y
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gpre,
+                               long n, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float yv = y[i], g = gy[i];
+    float d;
+    switch (act) {
+      case CGAT_ACT_TANH: d = 1.f - yv * yv; break;
+      case CGAT_ACT_LEAKY: d = yv > 0.f ? 1.f : 0.01f; break;
+      case CGAT_ACT_RELU: d = yv > 0.f ? 1.f : 0.f; break;
+      default: d = 1.f;
+    }
+    gpre[i] = g * d;
+  }
+}
+
+static inline int grid_for(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act, hipStream_t s) {
+  if (n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, gy, gpre, n, act);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ---- column sums: partial[chunk][c] over row chunks, then a fixed-order final sum (deterministic) ----
+#define COLSUM_ROWS 512
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long ldx, int rows, int cols,
+                                      float* __restrict__ partial) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int chunk = blockIdx.y;
+  if (c >= cols) return;
+  int r0 = chunk * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(long)r * ldx + c];
+  partial[(long)chunk * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out,
+                                    float alpha) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[(long)k * cols + c];
+  out[c] = alpha * s;
+}
+size_t colsum_ws_bytes(int rows, int cols) { return ws_round((size_t)cdiv(rows > 0 ? rows : 1, COLSUM_ROWS) * cols, 4); }
+int colsum_launch(const float* x, long ldx, int rows, int cols, float* out, float alpha, void* ws, size_t ws_bytes,
+                  hipStream_t s) {
+  if (cols <= 0) return CGAT_OK;
+  int chunks = cdiv(rows > 0 ? rows : 1, COLSUM_ROWS);
+  if (!ws || ws_bytes < colsum_ws_bytes(rows, cols)) {
+    cgat_set_error("colsum: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 128), chunks), dim3(128), 0, s, x, ldx, rows, cols,
+                     partial);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 128)), dim3(128), 0, s, partial, chunks, cols, out, alpha);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ---- H_Net hyper input: out = d*a + (1-d)*b, d a device scalar ----
+__global__ void mix_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
+                           float* __restrict__ out, long n) {
+  float dv = d[0];
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = dv * a[i] + (1.f - dv) * b[i];
+}
+int mix_launch(const float* a, const float* b, const float* d, float* out, long n, hipStream_t s) {
+  if (n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(mix_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, d, out, n);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ga = d*g ; gb += (1-d)*g ; gd = sum g*(a-b)   (block partials -> fixed-order final sum)
+__global__ void mix_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
+                               const float* __restrict__ d, float* __restrict__ ga, float* __restrict__ gb, long n,
+                               float* __restrict__ partial) {
+  __shared__ float red[4];
+  float dv = d[0];
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (; i < n; i += stride) {
+    float gv = g[i];
+    if (ga) ga[i] = dv * gv;
+    if (gb) gb[i] += (1.f - dv) * gv;
+    s += gv * (a[i] - b[i]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    out[0] = s;
+  }
+}
+int mix_bwd_launch(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb_accum,
+                   float* gd, long n, void* ws, size_t ws_bytes, hipStream_t s) {
+  int blocks = grid_for(n);
+  if (blocks > 1024) blocks = 1024;
+  if (!ws || ws_bytes < (size_t)blocks * 4) {
+    cgat_set_error("mix_bwd: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(mix_bwd_kernel, dim3(blocks), dim3(256), 0, s, g, a, b, d, ga, gb_accum, n, (float*)ws);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, blocks, gd);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] += alpha * x[i];
+}
+int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s) {
+  if (n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, alpha, n);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows,
+                              int cols) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)rows * cols;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    long r = i / cols, c = i % cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t s) {
+  long total = (long)rows * cols;
+  if (total <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+int fill_launch(float* p, float v, long n, hipStream_t s) {
+  if (n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}

@@ -1,0 +1,152 @@
+// Segment kernels over rows that are already grouped by segment (CSR rowptr): the
+// softmax-over-incoming-edges of the attention (third-party torch_geometric.utils.softmax at
+// reference CGAT.py:323,59: exp(a - segmax) / (segsum + 1e-16)), Roost's weighted variant
+// (roost_message.py:307-311: (w**pow) * exp(a - segmax) / (segsum + 1e-13)), weighted segment
+// sums (scatter_add, CGAT.py:60 / PyG aggregate) and per-row per-head dot products.
+// No atomics anywhere: every output element has exactly one writer and a fixed summation
+// order, so results are bitwise reproducible.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  switch (act) {
+    case CGAT_ACT_TANH: return tanhf(v);
+    case CGAT_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+    case CGAT_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+
+// one thread per (segment, feature)
+__global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mult,
+                                       const int* __restrict__ rowptr, int S, int F, float eps,
+                                       float* __restrict__ alpha, float* __restrict__ ssum) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)S * F) return;
+  int s = (int)(i / F), f = (int)(i % F);
+  int r0 = rowptr[s], r1 = rowptr[s + 1];
+  float mx = -INFINITY;
+  for (int r = r0; r < r1; ++r) mx = fmaxf(mx, a[(long)r * F + f]);
+  float z = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float e = expf(a[(long)r * F + f] - mx);
+    if (mult) e *= mult[r];
+    z += e;
+  }
+  float inv = 1.f / (z + eps);
+  float tot = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float e = expf(a[(long)r * F + f] - mx);
+    if (mult) e *= mult[r];
+    float al = e * inv;
+    alpha[(long)r * F + f] = al;
+    tot += al;
+  }
+  if (ssum) ssum[i] = tot;
+}
+
+// ga = alpha * (g - sum_seg alpha*g),  g = galpha + gssum[seg];   gmult = ga / mult  (F == 1 only)
+__global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
+                                       const float* __restrict__ gssum, const float* __restrict__ mult,
+                                       const int* __restrict__ rowptr, int S, int F, float* __restrict__ ga,
+                                       float* __restrict__ gmult) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)S * F) return;
+  int s = (int)(i / F), f = (int)(i % F);
+  int r0 = rowptr[s], r1 = rowptr[s + 1];
+  float gs = gssum ? gssum[i] : 0.f;
+  float dot = 0.f;
+  for (int r = r0; r < r1; ++r) dot += alpha[(long)r * F + f] * (galpha[(long)r * F + f] + gs);
+  for (int r = r0; r < r1; ++r) {
+    float al = alpha[(long)r * F + f];
+    float g = al * (galpha[(long)r * F + f] + gs - dot);
+    ga[(long)r * F + f] = g;
+    if (gmult) gmult[r] = (mult[r] != 0.f) ? g / mult[r] : 0.f;
+  }
+}
+
+int seg_softmax_fwd_launch(const float* a, const float* mult, const int* rowptr, int S, int F, float eps, float* alpha,
+                           float* ssum, hipStream_t s) {
+  long n = (long)S * F;
+  if (n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
+                     ssum);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float* gssum, const float* mult,
+                           const int* rowptr, int S, int F, float* ga, float* gmult, hipStream_t s) {
+  long n = (long)S * F;
+  if (n <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG(!gmult || F == 1, "seg_softmax_bwd: gradient of the multiplier needs F == 1");
+  hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult, rowptr, S,
+                     F, ga, gmult);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// one workgroup per segment, threads stride the feature dimension, rows in CSR order
+__global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int* __restrict__ ridx,
+                                const float* __restrict__ w, int wF, int fw, const int* __restrict__ rowptr, int F,
+                                int act, float* __restrict__ out, long ldo) {
+  int s = blockIdx.x;
+  int r0 = rowptr[s], r1 = rowptr[s + 1];
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float acc = 0.f;
+    int wf = w ? f / fw : 0;
+    for (int r = r0; r < r1; ++r) {
+      long row = ridx ? (long)ridx[r] : (long)r;
+      float v = act_f(x[row * ldx + f], act);
+      if (w) v *= w[(long)r * wF + wf];
+      acc += v;
+    }
+    out[(long)s * ldo + f] = acc;
+  }
+}
+
+int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
+                    int F, int act, float* out, long ldo, hipStream_t s) {
+  if (S <= 0 || F <= 0) return CGAT_OK;
+  int threads = F >= 256 ? 256 : (F >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(seg_wsum_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out, ldo);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// one wave per row: out[r,h] = sum_j act(x[r,h*Hd+j]) * v[vrow(r)*ldv + h*Hd + j] + bias[h] + addv[vrow(r)*H + h]
+__global__ void rowdot_kernel(const float* __restrict__ x, long ldx, int act, const float* __restrict__ v, long ldv,
+                              const int* __restrict__ vrow, const float* __restrict__ bias,
+                              const float* __restrict__ addv, int rows, int H, int Hd, float* __restrict__ out) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  long vr = vrow ? (long)vrow[row] : 0;
+  const float* xr = x + (long)row * ldx;
+  const float* vv = v + vr * ldv;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int j = lane; j < Hd; j += 64) s += act_f(xr[h * Hd + j], act) * vv[h * Hd + j];
+    s = wave_sum64(s);
+    if (lane == 0) {
+      if (bias) s += bias[h];
+      if (addv) s += addv[vr * H + h];
+      out[(long)row * H + h] = s;
+    }
+  }
+}
+
+int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, const int* vrow, const float* bias,
+                  const float* addv, int rows, int H, int Hd, float* out, hipStream_t s) {
+  if (rows <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, act, v, ldv, vrow, bias, addv, rows, H,
+                     Hd, out);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}

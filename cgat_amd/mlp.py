@@ -1,0 +1,68 @@
+"""SimpleNetwork / Rezero / ResidualNetwork with the reference's parameter layout
+(reference CGAT/message_changed.py:31-138, CGAT/roost_message.py:324-355); every Linear runs in
+the fp32 MFMA GEMM kernel with its activation fused into the epilogue."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import linear
+
+
+class SimpleNetwork(nn.Module):
+    """Linear -> LeakyReLU(0.01) per hidden layer, then Linear (message_changed.py:36-63)."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dims):
+        super().__init__()
+        dims = [input_dim] + list(hidden_layer_dims)
+        self.fcs = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.acts = nn.ModuleList([nn.LeakyReLU() for _ in range(len(dims) - 1)])
+        self.fc_out = nn.Linear(dims[-1], output_dim)
+
+    def forward(self, fea):
+        for fc in self.fcs:
+            fea = linear(fea, fc.weight, fc.bias, _lib.ACT_LEAKY)
+        return linear(fea, self.fc_out.weight, self.fc_out.bias)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class Rezero(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return self.alpha * x
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class ResidualNetwork(nn.Module):
+    """fea = [rezero](relu(fc(fea))) + res_fc(fea) per layer; `last_layer=False` returns the last
+    hidden representation (message_changed.py:86-135)."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dims, if_rezero=False):
+        super().__init__()
+        dims = [input_dim] + list(hidden_layer_dims)
+        self.fcs = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.res_fcs = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) if dims[i] != dims[i + 1]
+                                      else nn.Identity() for i in range(len(dims) - 1)])
+        self.acts = nn.ModuleList([nn.ReLU() for _ in range(len(dims) - 1)])
+        self.fc_out = nn.Linear(dims[-1], output_dim)
+        self.if_rezero = if_rezero
+        if self.if_rezero:
+            self.rezeros = nn.ModuleList([Rezero() for _ in range(len(dims) - 1)])
+
+    def forward(self, fea, *, last_layer=True):
+        for k, (fc, res) in enumerate(zip(self.fcs, self.res_fcs)):
+            h = linear(fea, fc.weight, fc.bias, _lib.ACT_RELU)
+            if self.if_rezero:
+                h = self.rezeros[k](h)
+            skip = fea if isinstance(res, nn.Identity) else linear(fea, res.weight, None)
+            fea = h + skip
+        return linear(fea, self.fc_out.weight, self.fc_out.bias) if last_layer else fea
+
+    def __repr__(self):
+        return self.__class__.__name__

@@ -1,0 +1,287 @@
+"""CGAtNet and its attention layers behind the reference's constructor / forward API and
+state_dict layout (reference CGAT/CGAT.py:14-613), executing on libcgat_hip.
+
+Drop-in: `importlib.import_module("cgat_amd").CGAtNet(200, elem_fea_len=..., ...)` is what
+lightning_module.py:165-176 does with `--version cgat_amd`.
+
+torch_geometric is not required: `GATConvNodes` keeps the MessagePassing-style surface
+(`forward(x, edge_index, edge_attr, x_0, size=None)`, `message`, `update`), and PyG's gather
+convention is applied through the batch's CSR plan: x_j = x[edge_index[0]], x_i =
+x[edge_index[1]], softmax and aggregation keyed by edge_index[1].
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hypernet import H_Net, H_Net_0
+from .mlp import ResidualNetwork, SimpleNetwork
+from .ops import (NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+                  segment_softmax, segment_sum)
+from .roost import Roost
+
+
+class MultiHeadNetwork(nn.Module):
+    """nb_heads independent input_dim -> hidden -> output_dim MLPs with LeakyReLU(0.01), stored as
+    the reference's grouped 1x1 Conv1d parameters (CGAT.py:65-112).  The head replication
+    (`repeat`) of the reference never happens: all heads' first layers are one GEMM, each
+    head's second layer one GEMM on its slice."""
+
+    def __init__(self, input_dim, output_dim, hidden_layer_dim, nb_heads, view=True):
+        super().__init__()
+        self.input_dim = input_dim
+        self.nb_heads = nb_heads
+        self.output_dim = output_dim
+        self.hidden_layer_dim = hidden_layer_dim
+        self.fc_in = nn.Conv1d(in_channels=input_dim * nb_heads, out_channels=hidden_layer_dim * nb_heads,
+                               kernel_size=1, groups=nb_heads)
+        self.acts = nn.LeakyReLU()
+        self.fc_out = nn.Conv1d(in_channels=hidden_layer_dim * nb_heads, out_channels=output_dim * nb_heads,
+                                kernel_size=1, groups=nb_heads)
+        self.view = view
+
+    def forward(self, fea):
+        fea = fea.reshape(-1, self.input_dim)
+        H, Hd, O = self.nb_heads, self.hidden_layer_dim, self.output_dim
+        hid = linear(fea, self.fc_in.weight, self.fc_in.bias, _lib.ACT_LEAKY)            # [M, H*Hd]
+        outs = [linear(hid[:, h * Hd:(h + 1) * Hd], self.fc_out.weight[h * O:(h + 1) * O],
+                       self.fc_out.bias[h * O:(h + 1) * O]) for h in range(H)]
+        return torch.stack(outs, dim=1)                                                   # [M, H, O]
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+class MHAttention(nn.Module):
+    """Per-crystal multi-head attention pooling of node features with the composition
+    embedding as context (CGAT.py:14-62)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, vector_attention=False):
+        super().__init__()
+        self.heads = heads
+        self.out_channels = out_channels
+        self.MH_A = MultiHeadNetwork(2 * in_channels, out_channels if vector_attention else 1, in_channels, heads,
+                                     view=False)
+        self.MH_M = MultiHeadNetwork(in_channels, out_channels, in_channels, heads)
+
+    def forward(self, fea, cry_fea, index, size=None):
+        size = int(index[-1]) + 1 if size is None else size
+        plan = SegmentPlan(index, size)
+        m = self.MH_M(fea)                                                         # [N,H,C]
+        pair = torch.cat([fea, gather_rows(cry_fea, index, plan)], dim=1)          # == stack+transpose+reshape, 55-58
+        alpha = self.MH_A(pair)                                                    # [N,H,1|C]
+        n = alpha.shape[0]
+        alpha = segment_softmax(alpha.reshape(n, -1), plan, eps=1e-16).reshape(alpha.shape)
+        return segment_sum((alpha * m).reshape(n, self.heads * self.out_channels), plan, index)
+
+
+def _edge_hidden(in_channels, nbr_channels):
+    return int((2 * in_channels + nbr_channels) / 1.5)
+
+
+class GATConvEdges(nn.Module):
+    """Edge update (CGAT.py:115-230).  With the shipped no_hyper=True the reference computes the
+    attention and then discards it (224-225): the result is Pooling_NN(edge_attr) alone, and
+    MH_A / MH_M never receive a gradient.  That dead compute is skipped here -- outputs and
+    gradients are identical."""
+
+    def __init__(self, in_channels, out_channels, nbr_channels, heads=1, concat=True, negative_slope=0.2, dropout=0,
+                 bias=True, vector_attention=False, first=False, no_hyper=True, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.nbr_channels = nbr_channels
+        self.heads = heads
+        self.concat = concat
+        self.negative_slope = negative_slope
+        self.dropout = dropout
+        self.vector_attention = vector_attention
+        D, Hd = 2 * in_channels + nbr_channels, _edge_hidden(in_channels, nbr_channels)
+        self.MH_A = MultiHeadNetwork(D, out_channels if vector_attention else 1, Hd, heads)
+        self.MH_M = MultiHeadNetwork(D, out_channels, Hd, heads)
+        if no_hyper:
+            self.Pooling_NN = SimpleNetwork(out_channels, out_channels, [out_channels])
+        elif first:
+            self.Pooling_NN = H_Net_0(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+        else:
+            self.Pooling_NN = H_Net(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+        self.first = first
+        self.no_hyper = no_hyper
+
+    def forward(self, x, edge_index, edge_attr, x_0, size=None):
+        if self.dropout:
+            raise NotImplementedError("attention dropout is always 0 in the reference stack")
+        if self.no_hyper:
+            return self.Pooling_NN(edge_attr)
+        plan = get_plan(edge_index, x.shape[0])
+        splan0, splan1 = _endpoint_plans(plan, edge_index)
+        x_i = gather_rows(x, edge_index[0], splan0)           # note: opposite naming to GATConvNodes (209-210)
+        x_j = gather_rows(x, edge_index[1], splan1)
+        m = torch.cat([x_i, edge_attr, x_j], dim=-1)
+        alpha = self.MH_A(m).exp()
+        m = self.MH_M(m)
+        alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction
+        aggr_out = (m * alpha).mean(dim=1)
+        if self.first:
+            return self.Pooling_NN(edge_attr, aggr_out)
+        return self.Pooling_NN(x_0, edge_attr, aggr_out)
+
+
+class _RowPlan:
+    """Adapter: the rows-grouped-by-endpoint view GatherRowsFn needs, taken from an EdgePlan."""
+
+    def __init__(self, rowptr, perm, S):
+        self.rowptr, self.perm, self.S = rowptr, perm, S
+
+
+def _endpoint_plans(plan, edge_index):
+    """(plan over edge_index[0], plan over edge_index[1]) in ORIGINAL edge order."""
+    if not hasattr(plan, "_orig_plans"):
+        plan._orig_plans = (SegmentPlan(edge_index[0], plan.N), _RowPlan(plan.dst_rowptr, plan.dst_perm, plan.N))
+    return plan._orig_plans
+
+
+class GATConvNodes(nn.Module):
+    """Node update: per-edge multi-head MLPs -> softmax over each atom's incoming edges ->
+    scatter-add -> head mean -> hypernetwork (CGAT.py:233-340)."""
+
+    def __init__(self, in_channels, out_channels, nbr_channels, heads=1, concat=False, negative_slope=0.2, dropout=0,
+                 bias=True, final=False, vector_attention=False, first=False, **kwargs):
+        super().__init__()
+        self.aggr, self.flow, self.node_dim = 'add', 'source_to_target', 0
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.nbr_channels = nbr_channels
+        self.heads = heads
+        self.concat = concat
+        self.negative_slope = negative_slope       # stored, never used: the MLPs use nn.LeakyReLU() = 0.01
+        self.dropout = dropout
+        self.final = final
+        self.first = first
+        self.vector_attention = vector_attention
+        D, Hd = 2 * in_channels + nbr_channels, _edge_hidden(in_channels, nbr_channels)
+        self.MH_A = MultiHeadNetwork(D, out_channels if vector_attention else 1, Hd, heads)
+        self.MH_M = MultiHeadNetwork(D, out_channels, Hd, heads)
+        if not final and first:
+            self.Pooling_NN = H_Net_0(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+        elif not final:
+            self.Pooling_NN = H_Net(out_channels, 3, out_channels, out_channels, 2, out_channels, out_channels)
+
+    # -- fused scalar-attention path: one call into cgat_nodes_attention_forward ---------
+    def _aggregate_fused(self, x, edge_attr, plan):
+        a, m = self.MH_A, self.MH_M
+        return NodesAttentionFn.apply(x, edge_attr, plan, self.heads, a.fc_in.weight, a.fc_in.bias, a.fc_out.weight,
+                                      a.fc_out.bias, m.fc_in.weight, m.fc_in.bias, m.fc_out.weight, m.fc_out.bias)
+
+    # -- MessagePassing-style surface (vector attention, or subclasses overriding message) --
+    def message(self, x_i, x_j, edge_attr, edge_index_i, plan=None):
+        m = torch.cat([x_i, edge_attr, x_j], dim=-1)
+        alpha = self.MH_A(m)
+        m = self.MH_M(m)
+        E = alpha.shape[0]
+        perm = plan.dst_perm.long()
+        al = SegmentSoftmaxFn.apply(alpha.reshape(E, -1).index_select(0, perm), None, plan.dst_rowptr, 1e-16)
+        alpha = torch.empty_like(al).index_copy(0, perm, al).reshape(alpha.shape)
+        return m * alpha
+
+    def propagate(self, edge_index, x, edge_attr, x_0):
+        plan = get_plan(edge_index, x.shape[0])
+        if not self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
+            aggr = self._aggregate_fused(x, edge_attr, plan)
+        else:
+            if self.dropout:
+                raise NotImplementedError("attention dropout is always 0 in the reference stack")
+            splan0, splan1 = _endpoint_plans(plan, edge_index)
+            x_j = gather_rows(x, edge_index[0], splan0)
+            x_i = gather_rows(x, edge_index[1], splan1)
+            msg = self.message(x_i, x_j, edge_attr, edge_index[1], plan=plan)             # [E,H,C]
+            E = msg.shape[0]
+            perm = plan.dst_perm.long()
+            agg = SegmentSumFn.apply(msg.reshape(E, -1).index_select(0, perm), plan.dst_rowptr,
+                                     edge_index[1].index_select(0, perm))
+            aggr = agg.reshape(plan.N, self.heads, self.out_channels).mean(dim=1)
+        return self.update(aggr, x_0=x_0, x=x, _mean_done=True)
+
+    def update(self, aggr_out, x_0, x, _mean_done=False):
+        if not _mean_done:
+            aggr_out = aggr_out.mean(dim=1)
+        if not self.final and self.first:
+            return self.Pooling_NN(x, aggr_out)
+        elif not self.final:
+            return self.Pooling_NN(x_0, x, aggr_out)
+        return aggr_out
+
+    def forward(self, x, edge_index, edge_attr, x_0, size=None):
+        if not torch.is_tensor(x):
+            raise NotImplementedError("bipartite (tuple) node features are not used by CGAtNet")
+        return self.propagate(edge_index, x=x, edge_attr=edge_attr, x_0=x_0)
+
+    def __repr__(self):
+        return '{}({}, {}, heads={})'.format(self.__class__.__name__, self.in_channels, self.out_channels, self.heads)
+
+
+class CGAtNet(nn.Module):
+    """The stack driver (CGAT.py:343-613).  Only update_edges=True exists: the reference's
+    update_edges=False branch raises at forward (positional-argument bug at CGAT.py:408-421)."""
+
+    def __init__(self, orig_elem_fea_len, elem_fea_len, n_graph, nbr_embedding_size=128, neighbor_number=12,
+                 mean_pooling=True, rezero=False, msg_heads=3, update_edges=False, vector_attention=False,
+                 global_vector_attention=False, n_graph_roost=3, no_hyper=True):
+        super().__init__()
+        if not update_edges:
+            raise NotImplementedError("CGAtNet(update_edges=False) is broken in the reference "
+                                      "(CGAT.py:408-421 raises at forward); use update_edges=True")
+        self.mean_pooling = mean_pooling
+        self.update_edges = update_edges
+        self.embedding = nn.Linear(orig_elem_fea_len, elem_fea_len, bias=False)
+        self.nbr_embedding = nn.Embedding(num_embeddings=neighbor_number + 1, embedding_dim=nbr_embedding_size)
+        self.no_hyper = no_hyper
+        self.graphs = nn.ModuleList([
+            nn.ModuleDict({
+                'Node': GATConvNodes(elem_fea_len, elem_fea_len, nbr_embedding_size, msg_heads, concat=True,
+                                     vector_attention=vector_attention, first=(k == 0)),
+                'Edge': GATConvEdges(elem_fea_len, nbr_embedding_size, nbr_embedding_size, msg_heads, concat=True,
+                                     vector_attention=vector_attention, first=(k == 0), no_hyper=no_hyper)})
+            for k in range(n_graph)])
+        self.roost = Roost(orig_elem_fea_len, elem_fea_len, n_graph_roost)
+        self.cry_pool = MHAttention(in_channels=elem_fea_len, out_channels=elem_fea_len, heads=msg_heads,
+                                    vector_attention=global_vector_attention)
+        self.msg_heads = msg_heads
+        self.elem_fea_len = elem_fea_len
+        out_hidden = [1024, 1024, 512, 512, 256, 256, 128]
+        self.output_nn = ResidualNetwork(elem_fea_len if mean_pooling else elem_fea_len * msg_heads, 2, out_hidden,
+                                         if_rezero=rezero)
+
+    def forward(self, batch, roost, *, last_layer=True, return_graph_embedding=False):
+        edge_index = batch.edge_index
+        crystal_elem_idx = batch.batch
+        G = getattr(batch, "num_graphs", None)
+        if G is None:
+            G = int(crystal_elem_idx[-1]) + 1                                   # one host sync per batch
+        edge_attr = self.nbr_embedding(batch.edge_attr)                         # [E] int64 -> [E,Ce]
+        elem_fea = linear(batch.x, self.embedding.weight, None)                 # [N,200] -> [N,C]
+        elem_fea_0 = elem_fea
+        edge_attr_0 = edge_attr
+        for graph_func in self.graphs:
+            node_update = graph_func['Node'](elem_fea, edge_index, edge_attr, elem_fea_0)
+            edge_attr = edge_attr + graph_func['Edge'](elem_fea, edge_index, edge_attr, edge_attr_0)
+            elem_fea = elem_fea + node_update
+        roost = tuple(roost)                                                    # the harness passes a generator
+        crys_fea = self.roost(*roost, num_crystals=G)
+        crys_fea = self.cry_pool(elem_fea, crys_fea, crystal_elem_idx, size=G)
+        if self.mean_pooling:
+            crys_fea = crys_fea.view(-1, self.msg_heads, self.elem_fea_len).mean(dim=1)
+        if return_graph_embedding:
+            return crys_fea
+        return self.output_nn(crys_fea, last_layer=last_layer)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+    def get_output_parameters(self):
+        return self.output_nn.parameters()
+
+    def get_hidden_parameters(self):
+        return itertools.chain(self.embedding.parameters(), self.nbr_embedding.parameters(),
+                               self.graphs.parameters(), self.roost.parameters(), self.cry_pool.parameters())

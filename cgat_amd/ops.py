@@ -1,0 +1,403 @@
+"""torch.autograd wrappers over the C ABI.  PyTorch supplies device memory, the current
+stream and the autograd tape; all arithmetic of the path runs in libcgat_hip kernels.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+# ----------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cgat_amd: the HIP path needs tensors on an MI355X device (cuda:N); "
+                               "there is no CPU fallback -- use oracle/ only for checking")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"cgat_amd: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer.  All launches are ordered on the current stream, so
+    one buffer serves every call (no allocation in the steady state)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+class EdgePlan:
+    """CSR plan of a batch (C struct cgat_plan): built once per edge_index, shared by all layers,
+    forward and backward."""
+
+    def __init__(self, edge_index, num_nodes):
+        _require_gpu(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise TypeError("edge_index must be int64 [2, E]")
+        ei = edge_index.contiguous()
+        E, N = int(ei.shape[1]), int(num_nodes)
+        dev = ei.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.N, self.E = N, E
+        self.dst_rowptr = torch.empty(N + 1, **i32)
+        self.dst_perm = torch.empty(E, **i32)
+        self.dst_sorted = torch.empty(E, **i32)
+        self.src_sorted = torch.empty(E, **i32)
+        self.src_rowptr = torch.empty(N + 1, **i32)
+        self.src_pos = torch.empty(E, **i32)
+        nbytes = lib.cgat_plan_workspace_bytes(E, N)
+        ws = workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_plan_build(_ptr(ei), E, N, _ptr(self.dst_rowptr), _ptr(self.dst_perm),
+                                      _ptr(self.dst_sorted), _ptr(self.src_sorted), _ptr(self.src_rowptr),
+                                      _ptr(self.src_pos), _ptr(ws), ws.numel(), _stream()), "cgat_plan_build")
+        self.c = _lib.Plan(N, E, self.dst_rowptr.data_ptr(), self.dst_perm.data_ptr(), self.dst_sorted.data_ptr(),
+                           self.src_sorted.data_ptr(), self.src_rowptr.data_ptr(), self.src_pos.data_ptr())
+
+
+_plan_cache = {}
+
+
+def get_plan(edge_index, num_nodes):
+    """Small LRU keyed by the edge_index storage: every layer of a stack (and its backward)
+    reuses the same plan."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), int(num_nodes), edge_index._version, edge_index.device.index)
+    plan = _plan_cache.get(key)
+    if plan is None:
+        if len(_plan_cache) >= 8:
+            _plan_cache.pop(next(iter(_plan_cache)))
+        plan = EdgePlan(edge_index, num_nodes)
+        plan._keepalive = edge_index
+        _plan_cache[key] = plan
+    return plan
+
+
+class SegmentPlan:
+    """rowptr/perm for a generic int64 segment index (crystal index, Roost self index)."""
+
+    def __init__(self, index, num_segments):
+        _require_gpu(index)
+        dev = index.device
+        n, S = int(index.numel()), int(num_segments)
+        keys = index.to(torch.int32).contiguous()
+        self.n, self.S = n, S
+        self.rowptr = torch.empty(S + 1, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = workspace(lib.cgat_csr_workspace_bytes(S), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_csr_from_keys(_ptr(keys), n, S, _ptr(self.rowptr), _ptr(self.perm), _ptr(ws), ws.numel(),
+                                         _stream()), "cgat_csr_from_keys")
+        self.perm64 = self.perm.long()
+
+
+# ----------------------------------------------------------------------------------------
+# GATConvNodes message + softmax + aggregate
+# ----------------------------------------------------------------------------------------
+def _attn_params(x, edge_attr, H, ws_):
+    A_in_w = ws_[0]
+    C_, Ce = x.shape[1], edge_attr.shape[1]
+    D = 2 * C_ + Ce
+    HHd = A_in_w.shape[0]
+    assert A_in_w.numel() == HHd * D and HHd % H == 0
+    Hd = HHd // H
+    p = _lib.AttnParams(C_, Ce, H, Hd, *[t.data_ptr() for t in ws_])
+    return p, Hd
+
+
+class NodesAttentionFn(torch.autograd.Function):
+    """aggr[n] = mean_h sum_{e: dst(e)=n} softmax_dst(MH_A(m_e))[h] * MH_M(m_e)[h]
+    (reference CGAT.py:319-329 + PyG aggregate), scalar attention."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, plan, H, A_in_w, A_in_b, A_out_w, A_out_b, M_in_w, M_in_b, M_out_w, M_out_b):
+        weights = [A_in_w, A_in_b, A_out_w, A_out_b, M_in_w, M_in_b, M_out_w, M_out_b]
+        _require_gpu(x, edge_attr, *weights)
+        x, edge_attr = _f32c(x), _f32c(edge_attr)
+        weights = [_f32c(w.detach()) for w in weights]
+        if A_out_w.numel() != H * (A_in_w.shape[0] // H):
+            raise ValueError("NodesAttentionFn handles scalar attention (MH_A output_dim == 1)")
+        N, E = plan.N, plan.E
+        if x.shape[0] != N or edge_attr.shape[0] != E:
+            raise ValueError(f"plan is for N={N}, E={E}; got x {tuple(x.shape)}, edge_attr {tuple(edge_attr.shape)}")
+        p, Hd = _attn_params(x, edge_attr, H, weights)
+        dev = x.device
+        saved = torch.empty(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), dtype=torch.float32, device=dev)
+        aggr = torch.empty(N, x.shape[1], dtype=torch.float32, device=dev)
+        ws = workspace(lib.cgat_nodes_attention_forward_workspace_bytes(C.byref(plan.c), C.byref(p)), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_nodes_attention_forward(C.byref(plan.c), C.byref(p), _ptr(x), _ptr(edge_attr), _ptr(aggr),
+                                                   _ptr(saved), _ptr(ws), ws.numel(), _stream()),
+                  "cgat_nodes_attention_forward")
+        ctx.plan, ctx.H = plan, H
+        ctx.save_for_backward(x, edge_attr, saved, *weights)
+        return aggr
+
+    @staticmethod
+    def backward(ctx, g_aggr):
+        x, edge_attr, saved, *weights = ctx.saved_tensors
+        plan, H = ctx.plan, ctx.H
+        g_aggr = _f32c(g_aggr)
+        p, Hd = _attn_params(x, edge_attr, H, weights)
+        dev = x.device
+        g_x = torch.empty_like(x)
+        g_e = torch.empty_like(edge_attr)
+        grads = [torch.empty_like(w) for w in weights]
+        g = _lib.AttnGrads(*[t.data_ptr() for t in grads])
+        ws = workspace(lib.cgat_nodes_attention_backward_workspace_bytes(C.byref(plan.c), C.byref(p)), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_nodes_attention_backward(C.byref(plan.c), C.byref(p), _ptr(x), _ptr(edge_attr), _ptr(saved),
+                                                    _ptr(g_aggr), _ptr(g_x), _ptr(g_e), C.byref(g), _ptr(ws),
+                                                    ws.numel(), _stream()), "cgat_nodes_attention_backward")
+        return (g_x, g_e, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------
+# hypernetwork Pooling_NN
+# ----------------------------------------------------------------------------------------
+def _hnet_struct(cls, W, n_fc, n_hyper, flat, damping):
+    s = cls()
+    if cls is _lib.HnetParams:
+        s.W, s.n_fc, s.n_hyper = W, n_fc, n_hyper
+    per = 2 * n_fc + 2
+    for l in range(n_hyper):
+        t = flat[l * per:(l + 1) * per]
+        for k in range(n_fc):
+            s.layer[l].fc_w[k] = t[k].data_ptr()
+            s.layer[l].fc_b[k] = t[n_fc + k].data_ptr()
+        s.layer[l].head_w = t[2 * n_fc].data_ptr()
+        s.layer[l].head_b = t[2 * n_fc + 1].data_ptr()
+    s.damping = None if damping is None else damping.data_ptr()
+    return s
+
+
+class HNetFn(torch.autograd.Function):
+    """y = HyperFC(hyper_input)(v)  with hyper_input = h0 (H_Net_0) or d*h0 + (1-d)*v (H_Net);
+    reference Hypernetworksmp.py:257-313.  `flat` = per predicted layer: n_fc trunk weights,
+    n_fc trunk biases, head weight [W*W+W, W], head bias [W*W+W]."""
+
+    @staticmethod
+    def forward(ctx, h0, v, damping, n_fc, n_hyper, *flat):
+        _require_gpu(h0, v, *flat)
+        h0, v = _f32c(h0), _f32c(v)
+        flat = [_f32c(t.detach()) for t in flat]
+        d = None if damping is None else _f32c(damping.detach())
+        rows, W = v.shape
+        if h0.shape != v.shape:
+            raise ValueError("hypernetwork: h0 and v must both be [rows, W]")
+        for l in range(n_hyper):
+            hw = flat[l * (2 * n_fc + 2) + 2 * n_fc]
+            if tuple(hw.shape) != (W * W + W, W):
+                raise ValueError(f"hypernetwork head weight must be [{W * W + W}, {W}] (all widths equal), got {tuple(hw.shape)}")
+        p = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
+        dev = v.device
+        saved = torch.empty(lib.cgat_hnet_saved_floats(rows, C.byref(p)), dtype=torch.float32, device=dev)
+        y = torch.empty_like(v)
+        ws = workspace(lib.cgat_hnet_forward_workspace_bytes(rows, C.byref(p)), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_hnet_forward(rows, C.byref(p), _ptr(h0), _ptr(v), _ptr(y), _ptr(saved), _ptr(ws), ws.numel(),
+                                        _stream()), "cgat_hnet_forward")
+        ctx.n_fc, ctx.n_hyper, ctx.has_d = n_fc, n_hyper, d is not None
+        ctx.save_for_backward(h0, v, saved, *( [d] if d is not None else []), *flat)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        h0, v, saved, *rest = ctx.saved_tensors
+        d = rest.pop(0) if ctx.has_d else None
+        flat = rest
+        n_fc, n_hyper = ctx.n_fc, ctx.n_hyper
+        rows, W = v.shape
+        g_y = _f32c(g_y)
+        p = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
+        grads = [torch.empty_like(t) for t in flat]
+        g_d = torch.empty_like(d) if d is not None else None
+        g = _hnet_struct(_lib.HnetGrads, W, n_fc, n_hyper, grads, g_d)
+        g_h0, g_v = torch.empty_like(h0), torch.empty_like(v)
+        dev = v.device
+        ws = workspace(lib.cgat_hnet_backward_workspace_bytes(rows, C.byref(p)), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_hnet_backward(rows, C.byref(p), _ptr(h0), _ptr(v), _ptr(saved), _ptr(g_y), _ptr(g_h0),
+                                         _ptr(g_v), C.byref(g), _ptr(ws), ws.numel(), _stream()), "cgat_hnet_backward")
+        return (g_h0, g_v, g_d, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------
+# dense layer, segment ops
+# ----------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b); x [M,K], W [N,K] (any leading stride), act in {none,tanh,leaky,relu}."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        _require_gpu(x, w, b)
+        x = _f32c(x)
+        w2 = w.detach().reshape(w.shape[0], -1)
+        if w2.stride(1) != 1:
+            w2 = w2.contiguous()
+        if w2.dtype != torch.float32:
+            raise TypeError("weights must be float32")
+        bb = None if b is None else _f32c(b.detach())
+        M, K = x.shape
+        N = w2.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.cgat_linear_forward(_ptr(x), K, _ptr(w2), w2.stride(0), _ptr(bb), _ptr(y), N, M, K, N, act,
+                                          _stream()), "cgat_linear_forward")
+        ctx.act, ctx.has_b, ctx.wshape = act, b is not None, w.shape
+        ctx.save_for_backward(x, w2, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, w2, y = ctx.saved_tensors
+        g_y = _f32c(g_y)
+        M, K = x.shape
+        N = w2.shape[0]
+        dev = x.device
+        gpre = torch.empty_like(y) if ctx.act != _lib.ACT_NONE else None
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty(N, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        g_b = torch.empty(N, dtype=torch.float32, device=dev) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        ws = workspace(lib.cgat_linear_backward_workspace_bytes(M, K, N), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_linear_backward(_ptr(x), K, _ptr(w2), w2.stride(0), _ptr(y), N, _ptr(g_y), N, _ptr(gpre),
+                                           _ptr(g_x), K, 0, _ptr(g_w), K, _ptr(g_b), M, K, N, ctx.act, _ptr(ws),
+                                           ws.numel(), _stream()), "cgat_linear_backward")
+        return g_x, (None if g_w is None else g_w.reshape(ctx.wshape)), g_b, None
+
+
+def linear(x, w, b=None, act=_lib.ACT_NONE):
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), w, b, act)
+    return y.reshape(*lead, y.shape[-1])
+
+
+class SegmentSoftmaxFn(torch.autograd.Function):
+    """alpha = mult * exp(a - segmax) / (segsum + eps) over CSR-ordered rows [R, F]."""
+
+    @staticmethod
+    def forward(ctx, a, mult, rowptr, eps):
+        _require_gpu(a, mult, rowptr)
+        a = _f32c(a)
+        m = None if mult is None else _f32c(mult)
+        R, F = a.shape
+        S = rowptr.numel() - 1
+        alpha = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            check(lib.cgat_segment_softmax_forward(_ptr(a), _ptr(m), _ptr(rowptr), S, F, eps, _ptr(alpha), _stream()),
+                  "cgat_segment_softmax_forward")
+        ctx.has_m = m is not None
+        ctx.save_for_backward(alpha, rowptr, *([m] if m is not None else []))
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g_alpha):
+        alpha, rowptr, *rest = ctx.saved_tensors
+        m = rest[0] if ctx.has_m else None
+        g_alpha = _f32c(g_alpha)
+        R, F = alpha.shape
+        S = rowptr.numel() - 1
+        g_a = torch.empty_like(alpha)
+        g_m = torch.empty_like(m) if (m is not None and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device(alpha.device):
+            check(lib.cgat_segment_softmax_backward(_ptr(alpha), _ptr(g_alpha), _ptr(m), _ptr(rowptr), S, F, _ptr(g_a),
+                                                    _ptr(g_m), _stream()), "cgat_segment_softmax_backward")
+        return g_a, g_m, None, None
+
+
+class SegmentSumFn(torch.autograd.Function):
+    """out[s] = sum of the CSR-ordered rows of segment s; backward = broadcast."""
+
+    @staticmethod
+    def forward(ctx, x, rowptr, seg_of_row):
+        _require_gpu(x, rowptr)
+        x = _f32c(x)
+        R, F = x.shape
+        S = rowptr.numel() - 1
+        out = torch.empty(S, F, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.cgat_segment_sum(_ptr(x), F, None, _ptr(rowptr), S, F, _ptr(out), F, _stream()), "cgat_segment_sum")
+        ctx.save_for_backward(seg_of_row)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg_of_row,) = ctx.saved_tensors
+        return g.index_select(0, seg_of_row), None, None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """x[index] whose backward is an atomics-free segment sum over the index's CSR plan
+    (deterministic, unlike index_add)."""
+
+    @staticmethod
+    def forward(ctx, x, index, plan):
+        _require_gpu(x, index)
+        ctx.plan, ctx.rows = plan, x.shape[0]
+        return x.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = _f32c(g)
+        F = g.shape[1]
+        out = torch.empty(ctx.rows, F, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib.cgat_segment_sum(_ptr(g), F, _ptr(plan.perm), _ptr(plan.rowptr), plan.S, F, _ptr(out), F,
+                                       _stream()), "cgat_segment_sum")
+        return out, None, None
+
+
+def gather_rows(x, index, plan):
+    return GatherRowsFn.apply(x, index, plan)
+
+
+def segment_softmax(a, index_plan, mult=None, eps=1e-16):
+    """softmax over the segments of `index_plan` for rows in their ORIGINAL order [R, F]."""
+    perm = index_plan.perm64
+    a_s = a.index_select(0, perm)
+    m_s = None if mult is None else mult.reshape(-1).index_select(0, perm)
+    al_s = SegmentSoftmaxFn.apply(a_s, m_s, index_plan.rowptr, eps)
+    out = torch.empty_like(al_s)
+    return out.index_copy(0, perm, al_s)
+
+
+def segment_sum(x, index_plan, index):
+    """scatter_add(x, index, dim=0, dim_size=S) for rows in their original order."""
+    perm = index_plan.perm64
+    return SegmentSumFn.apply(x.index_select(0, perm), index_plan.rowptr, index.index_select(0, perm))
+
+
+def prof_enable(on=True):
+    lib.cgat_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib.cgat_prof_reset()
+
+
+def prof_get(tag):
+    n, ms = C.c_int(0), C.c_float(0.0)
+    lib.cgat_prof_get(tag.encode(), C.byref(n), C.byref(ms))
+    return n.value, ms.value

@@ -1,0 +1,205 @@
+/* libcgat_hip -- C ABI of the MI355X (gfx950) edge-attention hot path of hyllios/CGAT.
+ *
+ * Every pointer is a DEVICE pointer to contiguous fp32 / int32 / int64 data unless stated
+ * otherwise; `stream` is a hipStream_t passed as void*.  Functions return 0 on success; on
+ * failure cgat_last_error() describes the problem.  No function allocates device memory or
+ * synchronises the host: outputs, saved-for-backward buffers and workspaces are provided by
+ * the caller (size queries below), so every call is hipGraph-capturable.
+ *
+ * The reference (pure Python) has no FFI; each entry point names the reference operator it
+ * replaces (paths relative to the reference repository root).
+ */
+#ifndef CGAT_HIP_H
+#define CGAT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGAT_ABI_VERSION 1
+#define CGAT_MAX_FC 8      /* Linear+Tanh layers per hypernetwork trunk */
+#define CGAT_MAX_HYPER 8   /* predicted layers per hypernetwork */
+
+int cgat_abi_version(void);
+const char* cgat_last_error(void);
+
+/* ---- launch timing (HIP events on the launch stream) --------------------------------- */
+void cgat_prof_enable(int on);
+void cgat_prof_reset(void);
+/* sums all recorded launches of kernels tagged `tag` ("bilinear_rows", "bilinear_wgrad",
+ * "gemm_f32", ...); synchronises the recorded events. */
+int cgat_prof_get(const char* tag, int* count, float* total_ms);
+
+/* ---- CSR plan: PyG propagate's implicit segment structure, built once per batch --------
+ * replaces the index handling of torch_geometric MessagePassing.propagate / utils.softmax /
+ * torch_scatter.scatter_add as used at CGAT/CGAT.py:313-326 (aggregation keyed by
+ * edge_index[1]).  dst_perm: edge ids sorted (stably) by edge_index[1]; dst_rowptr[N+1];
+ * dst_sorted/src_sorted: endpoints in that order; (src_rowptr, src_pos): sorted positions
+ * grouped by edge_index[0]. */
+typedef struct cgat_plan {
+  int32_t N, E;
+  const int32_t* dst_rowptr;
+  const int32_t* dst_perm;
+  const int32_t* dst_sorted;
+  const int32_t* src_sorted;
+  const int32_t* src_rowptr;
+  const int32_t* src_pos;
+} cgat_plan;
+size_t cgat_plan_workspace_bytes(int32_t E, int32_t N);
+int cgat_plan_build(const int64_t* edge_index /* [2,E] */, int32_t E, int32_t N, int32_t* dst_rowptr /* [N+1] */,
+                    int32_t* dst_perm /* [E] */, int32_t* dst_sorted /* [E] */, int32_t* src_sorted /* [E] */,
+                    int32_t* src_rowptr /* [N+1] */, int32_t* src_pos /* [E] */, void* ws, size_t ws_bytes,
+                    void* stream);
+/* generic CSR from int32 keys in [0,S): rowptr[S+1], perm[n] (ids ascending inside a segment) */
+size_t cgat_csr_workspace_bytes(int32_t S);
+int cgat_csr_from_keys(const int32_t* keys, int32_t n, int32_t S, int32_t* rowptr, int32_t* perm, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* ---- GATConvNodes message + softmax + aggregate (scalar attention) ----------------------
+ * replaces CGAT/CGAT.py:319-329: m=cat[x_i,edge_attr,x_j]; alpha=softmax_dst(MH_A(m));
+ * aggr = scatter_add(MH_M(m)*alpha).mean(heads), with MH_* = MultiHeadNetwork (CGAT.py:65-112).
+ * Parameter tensors are exactly the reference state_dict tensors (Conv1d weights
+ * [H*Hd, D, 1] / [H*out, Hd, 1] are passed as the same contiguous memory). */
+typedef struct cgat_attn_params {
+  int32_t C, Ce, H, Hd; /* D = 2C + Ce, columns of *_in_w ordered [x_i | edge_attr | x_j] */
+  const float* A_in_w;  /* [H*Hd, D]  MH_A.fc_in.weight  */
+  const float* A_in_b;  /* [H*Hd]                         */
+  const float* A_out_w; /* [H, Hd]    MH_A.fc_out.weight */
+  const float* A_out_b; /* [H]                            */
+  const float* M_in_w;  /* [H*Hd, D]  MH_M.fc_in.weight  */
+  const float* M_in_b;  /* [H*Hd]                         */
+  const float* M_out_w; /* [H*C, Hd]  MH_M.fc_out.weight */
+  const float* M_out_b; /* [H*C]                          */
+} cgat_attn_params;
+typedef struct cgat_attn_grads {
+  float *A_in_w, *A_in_b, *A_out_w, *A_out_b, *M_in_w, *M_in_b, *M_out_w, *M_out_b;
+} cgat_attn_grads;
+/* saved-for-backward: `saved` holds Z[E,2*H*Hd] | alpha[E,H] | S[N,H*Hd] | ssum[N,H] */
+size_t cgat_nodes_attention_saved_floats(int32_t N, int32_t E, int32_t H, int32_t Hd);
+size_t cgat_nodes_attention_forward_workspace_bytes(const cgat_plan* plan, const cgat_attn_params* p);
+size_t cgat_nodes_attention_backward_workspace_bytes(const cgat_plan* plan, const cgat_attn_params* p);
+int cgat_nodes_attention_forward(const cgat_plan* plan, const cgat_attn_params* p, const float* x /* [N,C] */,
+                                 const float* edge_attr /* [E,Ce], original edge order */,
+                                 float* aggr /* out [N,C] = head-mean of the aggregated messages */, float* saved,
+                                 void* ws, size_t ws_bytes, void* stream);
+int cgat_nodes_attention_backward(const cgat_plan* plan, const cgat_attn_params* p, const float* x,
+                                  const float* edge_attr, const float* saved, const float* g_aggr /* [N,C] */,
+                                  float* g_x /* [N,C] */, float* g_edge_attr /* [E,Ce] */, const cgat_attn_grads* g,
+                                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---- H_Net_0 / H_Net: hypernetwork Pooling_NN -------------------------------------------
+ * replaces CGAT/Hypernetworksmp.py:257-313 (HyperFC of n_hyper predicted layers, each with its
+ * own FCBlock trunk of n_fc Linear+Tanh and a Linear(W -> W*W+W) head; LayerNorm(no affine,
+ * eps 1e-5)+Tanh after every predicted layer but the last).  All widths equal W, as
+ * CGAT.py:301-305 constructs them.  damping == NULL selects H_Net_0 (hyper input = h0);
+ * otherwise hyper input = d*h0 + (1-d)*v with d = *damping (already clamped by the caller,
+ * Hypernetworksmp.py:310-311). */
+typedef struct cgat_hyperlinear_params {
+  const float* fc_w[CGAT_MAX_FC]; /* [W,W]      hypo_params.net.{s}.net.0.weight */
+  const float* fc_b[CGAT_MAX_FC]; /* [W]                                          */
+  const float* head_w;            /* [W*W+W, W] hypo_params.net.{n_fc}.weight    */
+  const float* head_b;            /* [W*W+W]                                      */
+} cgat_hyperlinear_params;
+typedef struct cgat_hnet_params {
+  int32_t W, n_fc, n_hyper;
+  cgat_hyperlinear_params layer[CGAT_MAX_HYPER];
+  const float* damping; /* device scalar or NULL */
+} cgat_hnet_params;
+typedef struct cgat_hyperlinear_grads {
+  float* fc_w[CGAT_MAX_FC];
+  float* fc_b[CGAT_MAX_FC];
+  float* head_w;
+  float* head_b;
+} cgat_hyperlinear_grads;
+typedef struct cgat_hnet_grads {
+  cgat_hyperlinear_grads layer[CGAT_MAX_HYPER];
+  float* damping; /* [1] or NULL */
+} cgat_hnet_grads;
+size_t cgat_hnet_saved_floats(int32_t rows, const cgat_hnet_params* p);
+size_t cgat_hnet_forward_workspace_bytes(int32_t rows, const cgat_hnet_params* p);
+size_t cgat_hnet_backward_workspace_bytes(int32_t rows, const cgat_hnet_params* p);
+int cgat_hnet_forward(int32_t rows, const cgat_hnet_params* p, const float* h0 /* [rows,W] */,
+                      const float* v /* [rows,W] */, float* y /* [rows,W] */, float* saved, void* ws, size_t ws_bytes,
+                      void* stream);
+int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v, const float* saved,
+                       const float* g_y, float* g_h0, float* g_v, const cgat_hnet_grads* g, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* ---- dense layer  y = act(x W^T + b)  (nn.Linear / 1x1 Conv1d group + activation) --------
+ * replaces the Linear/LeakyReLU/ReLU/Tanh pairs of CGAT/message_changed.py:58-63,124-130,
+ * CGAT/roost_message.py:348-352 and one head of MultiHeadNetwork (CGAT/CGAT.py:103-109).
+ * act: 0 none, 1 tanh, 2 LeakyReLU(0.01), 3 ReLU.  ldx/ldw/ldy are row strides in floats. */
+size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N);
+int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                        int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* stream);
+/* gpre = g_y * act'(y) is written to `gpre` [M,N] (caller buffer); g_x += or = per accumulate_gx */
+int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
+                         const float* g_y, int64_t ldgy, float* gpre /* [M,N] dense */, float* g_x, int64_t ldgx,
+                         int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b, int32_t M, int32_t K, int32_t N,
+                         int32_t act, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- segment softmax / segment sums over CSR-ordered rows --------------------------------
+ * replaces torch_geometric.utils.softmax (CGAT.py:59,323; eps 1e-16), the weighted softmax of
+ * roost_message.py:307-311 (mult = w**pow, eps 1e-13) and torch_scatter.scatter_add
+ * (CGAT.py:60, roost_message.py:315).  Rows must be ordered by segment (rowptr[S+1]). */
+int cgat_segment_softmax_forward(const float* a /* [R,F] */, const float* mult /* [R] or NULL */,
+                                 const int32_t* rowptr, int32_t S, int32_t F, float eps, float* alpha /* [R,F] */,
+                                 void* stream);
+int cgat_segment_softmax_backward(const float* alpha, const float* g_alpha, const float* mult, const int32_t* rowptr,
+                                  int32_t S, int32_t F, float* g_a, float* g_mult /* [R] or NULL, F==1 */,
+                                  void* stream);
+/* out[s,f] = sum_{r in seg s} x[ridx ? ridx[r] : r, f] */
+int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx, const int32_t* rowptr, int32_t S, int32_t F,
+                     float* out, int64_t ldo, void* stream);
+
+/* ---- kernel-level primitives (what the layer entry points above are composed of) --------- */
+/* C = act(alpha * A.B + bias + add1[add1_idx[m]] + add2[add2_idx[m]]) + beta * C on the fp32 matrix
+ * cores.  A(m,k) = A[row(m)*lda + k] (a_kmajor=0, row(m)=a_rgather?a_rgather[m]:m) or A[k*lda + m]
+ * (a_kmajor=1); B(k,n) = B[n*ldb + k] (b_kmajor=0, i.e. a torch Linear weight) or
+ * B[krow(k)*ldb + n] (b_kmajor=1, krow(k)=b_kgather?b_kgather[k]:k); output row = c_scatter?c_scatter[m]:m.
+ * splits > 1 splits K over workgroups (deterministic slab reduction; needs workspace). */
+typedef struct cgat_gemm_desc {
+  int32_t M, N, K;
+  const float* A;
+  int64_t lda;
+  int32_t a_kmajor;
+  const int32_t* a_rgather;
+  const float* B;
+  int64_t ldb;
+  int32_t b_kmajor;
+  const int32_t* b_kgather;
+  float* C;
+  int64_t ldc;
+  const int32_t* c_scatter;
+  float alpha, beta;
+  const float* bias;
+  const float* add1;
+  const int32_t* add1_idx;
+  const float* add2;
+  const int32_t* add2_idx;
+  int64_t ld_add;
+  int32_t act;
+  int32_t splits; /* 0 = choose automatically */
+} cgat_gemm_desc;
+size_t cgat_gemm_workspace_bytes(const cgat_gemm_desc* d);
+int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, void* stream);
+/* out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T[(a*NB+b)*NC + c]   (init may be NULL or == out) */
+int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T, const float* init,
+                       int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA, int32_t NB, int32_t NC,
+                       void* stream);
+/* out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c] */
+size_t cgat_bilinear_wgrad_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC);
+int cgat_bilinear_wgrad(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* r, int64_t ldr,
+                        float* out, int32_t rows, int32_t NA, int32_t NB, int32_t NC, void* ws, size_t ws_bytes,
+                        void* stream);
+/* y = tanh(LayerNorm(u)) without affine, biased variance (Hypernetworksmp.py:103-107) and its backward */
+int cgat_layernorm_tanh_forward(const float* u, float* y, int32_t rows, int32_t W, float eps, void* stream);
+int cgat_layernorm_tanh_backward(const float* u, const float* y, const float* g_y, float* g_u, int32_t rows, int32_t W,
+                                 float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGAT_HIP_H */

@@ -142,18 +142,25 @@ def _np(t):
 
 
 def record(case, *, full_param_grads):
+    """fp32 run of the reference (outputs, gradients) + fp64 run of the same.  For every tensor
+    the fp64 run yields the reference's own rounding deviation `nf.<name>` = ||fp32 - fp64||_inf:
+    the noise floor below which a difference from the fp32 reference carries no information."""
     out = {}
     y, grads, _ = recipe.run_case(case, torch.float32)
+    y64, grads64, _ = recipe.run_case(case, torch.float64)
     out["out"] = _np(y)
+    out["out_f64"] = _np(y64)
     for name, g in grads.items():
         if g is None:
             out[name + ".none"] = np.zeros(0, dtype=np.float32)
-        elif name.startswith("gp.") and (g.numel() > recipe.PROBE_ABOVE or not full_param_grads):
+            continue
+        g64 = grads64[name]
+        out["nf." + name] = np.array([(g.double() - g64).abs().max().item(), g64.abs().max().item()])
+        if name.startswith("gp.") and (g.numel() > recipe.PROBE_ABOVE or not full_param_grads):
             out["gpn." + name[3:]] = recipe.grad_probe(g)
+            out["gpn64." + name[3:]] = recipe.grad_probe(g64)
         else:
             out[name] = _np(g)
-    y64, _, _ = recipe.run_case(case, torch.float64, want_grads=False)   # noise floor of the reference itself
-    out["out_f64"] = _np(y64)
     return out
 
 

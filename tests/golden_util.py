@@ -34,35 +34,47 @@ def maxnorm_rel(a, b):
     return float(np.abs(a - b).max() / den)
 
 
-def check_case(fname, cname, case, *, device="cpu", tol=1e-4, grad_tol=None):
+NOISE_MULT = 16.0
+
+
+def check_case(fname, cname, case, *, device="cpu", tol=1e-4, grad_tol=None, report=None):
     """Run `case` (module built from the namespace under test) and compare output, input grads,
-    parameter grads (full or probe) and None-ness of grads with the reference's fixture."""
+    parameter grads (full or probe) and None-ness of grads with the reference's fixture.
+
+    Criterion per tensor:  ||got - ref||_inf <= max(tol * ||ref||_inf, NOISE_MULT * nf)
+    where nf = ||ref_fp32 - ref_fp64||_inf is the reference's own rounding deviation recorded in the
+    fixture.  The second term only matters for tensors the reference itself cannot resolve to
+    `tol` in fp32 (gradients that are zero by symmetry, or dominated by cancellation)."""
     grad_tol = tol if grad_tol is None else grad_tol
     ref = case_arrays(fname, cname)
     y, grads, _ = recipe.run_case(case, torch.float32, device=device)
     errs = {"out": maxnorm_rel(y.detach().cpu().numpy(), ref["out"])}
-    assert errs["out"] <= tol, f"{cname}: out err {errs['out']:.3e}"
+    nf_out = np.abs(ref["out"].astype(np.float64) - ref["out_f64"]).max() / max(np.abs(ref["out_f64"]).max(), 1e-300)
+    assert errs["out"] <= max(tol, NOISE_MULT * nf_out), f"{cname}: out err {errs['out']:.3e}"
+    # gradients below 1e-6 of the largest gradient of the case are zero at fp32 resolution
+    # (fp32 epsilon times the ~sqrt(E) growth of an E-term sum)
+    case_scale = max([float(v[1]) for k, v in ref.items() if k.startswith("nf.")] + [0.0])
     for name, g in grads.items():
         if name + ".none" in ref:
             # reference leaves this gradient unset; we may return None or exact zeros
             assert g is None or float(g.abs().max()) == 0.0, f"{cname}: {name} should have no gradient"
             continue
         assert g is not None, f"{cname}: {name} has no gradient but the reference has one"
+        nf_abs, ref_max = ref["nf." + name]
         if name in ref:
             want = ref[name]
-            e = maxnorm_rel(g.detach().cpu().numpy(), want)
-            scale = np.abs(want).max()
+            abs_err = np.abs(g.detach().cpu().numpy().astype(np.float64) - want).max()
         else:
             want = ref["gpn." + name[3:]]
             got = recipe.grad_probe(g)
-            # compare sum / ramp-dot relative to the L2 norm (they can cancel to ~0), norm and max relatively
-            nrm = max(want[1], 1e-30)
-            e = max(abs(got[0] - want[0]) / (nrm * np.sqrt(g.numel())) * 10, abs(got[1] - want[1]) / nrm,
-                    abs(got[2] - want[2]) / max(want[2], 1e-30), abs(got[3] - want[3]) / (nrm * np.sqrt(g.numel())) * 10,
-                    np.abs(got[4:] - want[4:]).max() / max(want[2], 1e-30))
-            scale = want[2]
-        errs[name] = e
-        if scale < 1e-12:   # gradient that is zero up to rounding in the reference (softmax shift invariance)
-            continue
-        assert e <= grad_tol, f"{cname}: {name} err {e:.3e}"
+            n = g.numel()
+            # probe entries: sum, L2, max, ramp-dot, first 8 values -> convert each to a per-element-scale error
+            abs_err = max(abs(got[0] - want[0]) / np.sqrt(n), abs(got[1] - want[1]) / np.sqrt(n), abs(got[2] - want[2]),
+                          abs(got[3] - want[3]) / np.sqrt(n), np.abs(got[4:] - want[4:]).max())
+        allowed = max(grad_tol * ref_max, NOISE_MULT * nf_abs, 1e-6 * case_scale)
+        errs[name] = abs_err / max(ref_max, 1e-300)
+        if report is not None:
+            report.append((cname, name, abs_err, ref_max, nf_abs))
+        assert abs_err <= allowed, (f"{cname}: {name} abs err {abs_err:.3e} > allowed {allowed:.3e} "
+                                    f"(|ref| {ref_max:.3e}, reference fp32 noise {nf_abs:.3e})")
     return errs

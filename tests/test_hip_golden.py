@@ -1,0 +1,204 @@
+"""Parity of the HIP product (cgat_amd, through its reference-shaped module API and the C
+ABI underneath) with
+  (1) the golden vectors recorded from the unmodified reference (tests/golden/*.npz), and
+  (2) the oracle on seeded inputs at sizes the oracle finishes in seconds,
+  (3) size-independent properties at the BASELINE size (1M edges).
+
+Tolerance (north_star): max-norm relative <= 1e-4, fp32, per tensor -- outputs, input
+gradients and parameter gradients.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from golden_util import check_case, maxnorm_rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def product_ns():
+    import cgat_amd as P
+    return types.SimpleNamespace(
+        MultiHeadNetwork=P.MultiHeadNetwork, GATConvNodes=P.GATConvNodes, GATConvEdges=P.GATConvEdges,
+        MHAttention=P.MHAttention, CGAtNet=P.CGAtNet, H_Net_0=P.H_Net_0, H_Net=P.H_Net,
+        SimpleNetwork=P.SimpleNetwork, ResidualNetwork=P.ResidualNetwork, WeightedAttention=P.WeightedAttention,
+        MessageLayer=P.MessageLayer, Roost=P.Roost, RoostSimpleNetwork=P.SimpleNetwork)
+
+
+def oracle_ns():
+    from oracle import cgat_oracle as O
+    return types.SimpleNamespace(
+        MultiHeadNetwork=O.MultiHeadNetwork, GATConvNodes=O.GATConvNodes, GATConvEdges=O.GATConvEdges,
+        MHAttention=O.MHAttention, CGAtNet=O.CGAtNet, H_Net_0=O.H_Net_0, H_Net=O.H_Net,
+        SimpleNetwork=O.SimpleNetwork, ResidualNetwork=O.ResidualNetwork, WeightedAttention=O.WeightedAttention,
+        MessageLayer=O.MessageLayer, Roost=O.Roost, RoostSimpleNetwork=O.SimpleNetwork)
+
+
+_TINY_NAMES = sorted(recipe.tiny_cases(oracle_ns()))
+_BASE_NAMES = sorted(recipe.base_cases(oracle_ns()))
+
+
+@pytest.mark.parametrize("cname", _TINY_NAMES)
+def test_golden_tiny(cname):
+    case = recipe.tiny_cases(product_ns())[cname]
+    check_case("tiny.npz", cname, case, device="cuda:0", tol=TOL)
+
+
+@pytest.mark.parametrize("cname", _BASE_NAMES)
+def test_golden_base(cname):
+    case = recipe.base_cases(product_ns())[cname]
+    check_case("base.npz", cname, case, device="cuda:0", tol=TOL)
+
+
+NOISE_MULT = 16.0
+
+
+def _compare_with_oracle(mk_prod, mk_orac, inputs, call, tol=TOL):
+    """Same seeded parameters (copied through the shared state_dict layout) and inputs.  The
+    oracle runs in fp32 and fp64; criterion per tensor, as for the golden fixtures:
+        ||hip - oracle32||_inf <= max(tol * ||oracle||_inf, NOISE_MULT * ||oracle32 - oracle64||_inf)"""
+    torch.manual_seed(1)
+    om = mk_orac()
+    pm = mk_prod()
+    pm.load_state_dict(om.state_dict())           # identical layout is part of the contract
+    pm = pm.to("cuda:0")
+    import copy
+    om64 = copy.deepcopy(om).double()
+
+    def prep(v, dev=None, dt=None):
+        if not torch.is_tensor(v):
+            return v
+        if v.is_floating_point():
+            v = v.to(dt) if dt is not None else v.clone()
+            return (v.to(dev) if dev else v).requires_grad_(True)
+        return v.to(dev) if dev else v
+    oin = {k: prep(v) for k, v in inputs.items()}
+    oin64 = {k: prep(v, dt=torch.float64) for k, v in inputs.items()}
+    pin = {k: prep(v, dev="cuda:0") for k, v in inputs.items()}
+    yo, yo64, yp = call(om, oin), call(om64, oin64), call(pm, pin)
+    cot = torch.randn(yo.shape, generator=torch.Generator().manual_seed(9))
+
+    def grads(m, ins, y, c):
+        leaves = [v for v in ins.values() if torch.is_tensor(v) and v.requires_grad]
+        params = dict(m.named_parameters())
+        g = torch.autograd.grad((y * c).sum(), leaves + list(params.values()), allow_unused=True)
+        return [f"in{i}" for i in range(len(leaves))] + list(params), g
+    names, go = grads(om, oin, yo, cot)
+    _, go64 = grads(om64, oin64, yo64, cot.double())
+    _, gp = grads(pm, pin, yp, cot.to("cuda:0"))
+    failures, worst = [], 0.0
+    case_scale = max(float(b.detach().abs().max()) for b in go64 if b is not None)
+    items = [("out", yp, yo, yo64)] + list(zip(names, gp, go, go64))
+    for name, a, b, b64 in items:
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+            continue
+        assert a is not None, name
+        a = a.detach().cpu().double()
+        ref_max = float(b64.detach().abs().max())
+        nf = float((b.detach().double() - b64.detach()).abs().max())
+        err = float((a - b.detach().double()).abs().max())
+        allowed = max(tol * ref_max, NOISE_MULT * nf, 0.0 if name == 'out' else 1e-6 * case_scale)
+        worst = max(worst, err / max(ref_max, 1e-300))
+        if err > allowed:
+            failures.append(f"{name}: err {err:.3e} allowed {allowed:.3e} |ref| {ref_max:.3e} oracle fp32 noise {nf:.3e}")
+    assert not failures, "\n".join(failures)
+    return worst
+
+
+@pytest.mark.parametrize("first", [True, False])
+def test_nodes_layer_vs_oracle_random_init(first):
+    """Config 1 -> 2 of BASELINE.json at a size the oracle finishes in seconds: 60 crystals
+    (N=1200, E=14400), C=Ce=128, H=3, default (random) initialisation, one GATConvNodes layer."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = P.synthetic_batch(60, 20, 12, seed=3)
+    g = torch.Generator().manual_seed(4)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True, first=first),
+                         lambda: O.GATConvNodes(128, 128, 128, 3, concat=True, first=first), inputs, call)
+
+
+def test_ragged_graphs_vs_oracle():
+    """Ragged crystals (2..40 atoms), K=24 neighbours, H=5: the DCGAT-like shape of config 4."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    rs = np.random.RandomState(11)
+    sizes = rs.randint(2, 41, size=30).tolist()
+    b, _ = recipe.build_graphs(sizes, K=24, species_per_graph=rs.randint(1, 5, size=30).tolist(), seed=12)
+    g = torch.Generator().manual_seed(5)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 64, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 32, generator=g), "x_0": torch.randn(N, 64, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(64, 64, 32, 5, concat=True),
+                         lambda: O.GATConvNodes(64, 64, 32, 5, concat=True), inputs, call)
+
+
+def test_full_stack_vs_oracle_random_init():
+    """Config 3 shape (msg_heads=3, 4 layers, 200-d embeddings) on 40 crystals, random init."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, roost = P.synthetic_batch(40, 20, 12, seed=8)
+    inputs = {"x": b.x, "edge_index": b.edge_index, "edge_attr": b.edge_attr, "batch": b.batch,
+              "r0": roost[0], "r1": roost[1], "r2": roost[2], "r3": roost[3], "r4": roost[4]}
+
+    def call(m, i):
+        bb = recipe.GraphBatch(i["x"], i["edge_index"], i["edge_attr"], i["batch"])
+        return m(bb, (t for t in (i["r0"], i["r1"], i["r2"], i["r3"], i["r4"])))
+    mk = lambda ns: (lambda: ns.CGAtNet(200, 128, 4, msg_heads=3, neighbor_number=12, update_edges=True))
+    _compare_with_oracle(mk(P), mk(O), inputs, call)
+
+
+def test_determinism_bitwise():
+    """No atomics on the data path: two runs give bit-identical outputs and gradients."""
+    import cgat_amd as P
+    b, _ = P.synthetic_batch(200, 20, 12, seed=2)
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    m = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    g = torch.Generator().manual_seed(6)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0 = (torch.randn(s, 128, generator=g).to(dev) for s in (N, E, N))
+    ei = b.edge_index.to(dev)
+    outs = []
+    for _ in range(2):
+        xx, ee = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+        y = m(xx, ei, ee, x0)
+        gr = torch.autograd.grad(y.square().sum(), [xx, ee] + list(m.parameters()))
+        outs.append([y.detach()] + [t.detach() for t in gr])
+    for a, bb in zip(*outs):
+        assert torch.equal(a, bb)
+
+
+def test_million_edge_properties():
+    """BASELINE size (G=4167 -> N=83 340, E=1 000 080): properties that need no oracle run.
+    (a) permutation equivariance: relabelling the edges (same multiset) leaves the node output
+        unchanged up to summation order; (b) graph locality: crystals are independent, so the
+        first 50 crystals evaluated alone give the same rows as inside the big batch."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    b, _ = P.synthetic_batch(4167, 20, 12, seed=0)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    assert E == 1000080
+    torch.manual_seed(1)
+    m = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    g = torch.Generator().manual_seed(7)
+    x, e, x0 = (torch.randn(s, 128, generator=g).to(dev) for s in (N, E, N))
+    ei = b.edge_index.to(dev)
+    with torch.no_grad():
+        y = m(x, ei, e, x0)
+        perm = torch.randperm(E, generator=g).to(dev)
+        y_perm = m(x, ei[:, perm].contiguous(), e[perm].contiguous(), x0)
+        n_sub, e_sub = 50 * 20, 50 * 20 * 12
+        y_sub = m(x[:n_sub].contiguous(), ei[:, :e_sub].contiguous(), e[:e_sub].contiguous(), x0[:n_sub].contiguous())
+    assert torch.isfinite(y).all()
+    assert maxnorm_rel(y_perm.cpu().numpy(), y.cpu().numpy()) <= 1e-5
+    assert maxnorm_rel(y_sub.cpu().numpy(), y[:n_sub].cpu().numpy()) <= 1e-5

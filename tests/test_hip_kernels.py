@@ -1,0 +1,222 @@
+"""Kernel-level parity on the GPU: every primitive of libcgat_hip against a plain torch fp32
+(or fp64) reference of the same op.  Tolerance: max-norm relative 2e-5 for fp32 contractions
+(exact-fp32 MFMA, only the summation order differs), bit-exact for the integer CSR plan."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    d = b.abs().max().item()
+    return (a - b).abs().max().item() / (d if d > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import cgat_amd
+    from cgat_amd import _lib, ops
+    return cgat_amd, _lib, ops, torch.device("cuda:0")
+
+
+def _gemm(env, M, N, K, *, a_km=False, b_km=False, rg=False, kg=False, scatter=False, adds=False, bias=False, act=0,
+          alpha=1.0, beta=0.0, splits=1, lda_pad=0, seed=0):
+    _, _lib, ops, dev = env
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    R = M + 7 if rg else M                       # gather source has extra rows
+    A = rnd(K, R + lda_pad) if a_km else rnd(R, K + lda_pad)
+    KB = K + 5 if kg else K
+    B = rnd(KB, N + lda_pad) if b_km else rnd(N, K + lda_pad)
+    Cm = rnd(M + (3 if scatter else 0), N)
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_kmajor = A.data_ptr(), A.stride(0), int(a_km)
+    d.B, d.ldb, d.b_kmajor = B.data_ptr(), B.stride(0), int(b_km)
+    d.C, d.ldc = Cm.data_ptr(), Cm.stride(0)
+    d.alpha, d.beta, d.act, d.splits = alpha, beta, act, splits
+    Aeff = (A[:K, :R].t() if a_km else A[:R, :K])
+    Beff = (B[:KB, :N] if b_km else B[:N, :K].t())
+    keep = []
+    if rg:
+        idx = torch.randperm(R, generator=g)[:M].to(torch.int32).to(dev)
+        d.a_rgather = idx.data_ptr(); keep.append(idx)
+        Aeff = Aeff[idx.long()]
+    if kg:
+        kidx = torch.randperm(KB, generator=g)[:K].to(torch.int32).to(dev)
+        d.b_kgather = kidx.data_ptr(); keep.append(kidx)
+        Beff = Beff[kidx.long()]
+    ref = alpha * (Aeff.double() @ Beff.double())
+    if bias:
+        bv = rnd(N); d.bias = bv.data_ptr(); keep.append(bv)
+        ref = ref + bv.double()
+    if adds:
+        P1, P2 = rnd(11, N + 8), rnd(13, N + 8)
+        i1 = torch.randint(0, 11, (M,), generator=g).to(torch.int32).to(dev)
+        i2 = torch.randint(0, 13, (M,), generator=g).to(torch.int32).to(dev)
+        d.add1, d.add1_idx, d.add2, d.add2_idx, d.ld_add = P1.data_ptr(), i1.data_ptr(), P2.data_ptr(), i2.data_ptr(), N + 8
+        keep += [P1, P2, i1, i2]
+        ref = ref + P1[i1.long(), :N].double() + P2[i2.long(), :N].double()
+    if act == 1:
+        ref = torch.tanh(ref)
+    elif act == 2:
+        ref = torch.where(ref > 0, ref, 0.01 * ref)
+    elif act == 3:
+        ref = ref.clamp(min=0)
+    rows = torch.arange(M, device=dev)
+    if scatter:
+        sidx = torch.randperm(M + 3, generator=g)[:M].to(torch.int32).to(dev)
+        d.c_scatter = sidx.data_ptr(); keep.append(sidx)
+        rows = sidx.long()
+    C0 = Cm.clone()
+    ref = ref + beta * C0[rows].double()
+    nb = _lib.lib.cgat_gemm_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.cgat_gemm(C.byref(d), ws.data_ptr(), ws.numel(), None), "cgat_gemm")
+    torch.cuda.synchronize()
+    err = rel(Cm[rows], ref)
+    untouched = torch.ones(Cm.shape[0], dtype=torch.bool, device=dev)
+    untouched[rows] = False
+    assert torch.equal(Cm[untouched], C0[untouched]), "rows outside the output were written"
+    return err
+
+
+GEMM_CASES = [
+    dict(M=128, N=128, K=32), dict(M=256, N=384, K=128), dict(M=1, N=1, K=1), dict(M=130, N=70, K=37),
+    dict(M=300, N=129, K=200, bias=True, act=1), dict(M=97, N=1536, K=16, rg=True, adds=True),
+    dict(M=513, N=48, K=48, a_km=True), dict(M=513, N=48, K=50, b_km=True), dict(M=64, N=200, K=777, a_km=True, b_km=True),
+    dict(M=128, N=128, K=5000, a_km=True, b_km=True, splits=7, alpha=0.5), dict(M=96, N=16, K=3000, a_km=True, b_km=True, kg=True, splits=0),
+    dict(M=333, N=16, K=96, b_km=True, scatter=True), dict(M=200, N=3, K=128), dict(M=3, N=128, K=999, a_km=True, b_km=True, splits=4),
+    dict(M=150, N=64, K=3, b_km=True, alpha=1 / 3, beta=1.0), dict(M=257, N=255, K=129, lda_pad=3, bias=True, act=2),
+    dict(M=140, N=90, K=64, act=3, beta=1.0), dict(M=1000, N=128, K=128, rg=True),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_gemm(env, case):
+    assert _gemm(env, **case) <= TOL
+
+
+@pytest.mark.parametrize("W,rows", [(128, 128), (128, 300), (128, 1), (16, 45), (128, 1000)])
+@pytest.mark.parametrize("with_init", [False, True])
+def test_bilinear_rows(env, W, rows, with_init):
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(W + rows)
+    p, q = torch.randn(rows, W, generator=g).to(dev), torch.randn(rows, W, generator=g).to(dev)
+    T = (torch.randn(W, W, W, generator=g) / W).to(dev)
+    init = torch.randn(rows, W, generator=g).to(dev) if with_init else None
+    out = torch.full((rows, W), float("nan"), device=dev)
+    ref = torch.einsum("na,nb,abc->nc", p.double(), q.double(), T.double())
+    if with_init:
+        ref = ref + init.double()
+    _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, q.data_ptr(), W, T.data_ptr(),
+                                           None if init is None else init.data_ptr(), W, out.data_ptr(), W, rows, W, W,
+                                           W, None), "bilinear_rows")
+    torch.cuda.synchronize()
+    assert rel(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45)])
+def test_bilinear_wgrad(env, W, rows):
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(W + rows)
+    p, q, r = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))
+    out = torch.full((W, W, W), float("nan"), device=dev)
+    ref = torch.einsum("na,nb,nc->abc", p.double(), q.double(), r.double())
+    nb = _lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W)
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.cgat_bilinear_wgrad(p.data_ptr(), W, q.data_ptr(), W, r.data_ptr(), W, out.data_ptr(), rows, W,
+                                            W, W, ws.data_ptr(), ws.numel(), None), "bilinear_wgrad")
+    torch.cuda.synchronize()
+    assert rel(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("W,rows", [(128, 257), (16, 33), (100, 5)])
+def test_layernorm_tanh(env, W, rows):
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(3)
+    u = torch.randn(rows, W, generator=g).to(dev)
+    gy = torch.randn(rows, W, generator=g).to(dev)
+    y, gu = torch.empty_like(u), torch.empty_like(u)
+    _lib.check(_lib.lib.cgat_layernorm_tanh_forward(u.data_ptr(), y.data_ptr(), rows, W, 1e-5, None), "ln fwd")
+    _lib.check(_lib.lib.cgat_layernorm_tanh_backward(u.data_ptr(), y.data_ptr(), gy.data_ptr(), gu.data_ptr(), rows, W,
+                                                     1e-5, None), "ln bwd")
+    ud = u.double().cpu().requires_grad_(True)
+    yr = torch.tanh(torch.nn.functional.layer_norm(ud, [W], eps=1e-5))
+    (gur,) = torch.autograd.grad(yr, ud, gy.double().cpu())
+    assert rel(y, yr.detach()) <= TOL and rel(gu, gur) <= 5e-5
+
+
+def test_plan_matches_stable_sort(env):
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(5)
+    N, E = 1000, 12345
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N - 50, (E,), generator=g)])  # last 50 nodes: in-degree 0
+    plan = ops.EdgePlan(ei.to(dev), N)
+    torch.cuda.synchronize()
+    perm_ref = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(plan.dst_perm.cpu().long(), perm_ref)
+    assert torch.equal(plan.dst_sorted.cpu().long(), ei[1][perm_ref])
+    assert torch.equal(plan.src_sorted.cpu().long(), ei[0][perm_ref])
+    rp = torch.zeros(N + 1, dtype=torch.long)
+    rp[1:] = torch.bincount(ei[1], minlength=N).cumsum(0)
+    assert torch.equal(plan.dst_rowptr.cpu().long(), rp)
+    src_sorted = ei[0][perm_ref]
+    pos_ref = torch.sort(src_sorted, stable=True).indices
+    assert torch.equal(plan.src_pos.cpu().long(), pos_ref)
+    rp2 = torch.zeros(N + 1, dtype=torch.long)
+    rp2[1:] = torch.bincount(ei[0], minlength=N).cumsum(0)
+    assert torch.equal(plan.src_rowptr.cpu().long(), rp2)
+
+
+def test_plan_large_scan(env):
+    """N beyond one 1024-wide scan tile, and E = 0."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(6)
+    N, E = 70000, 200000
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)])
+    plan = ops.EdgePlan(ei.to(dev), N)
+    rp = torch.zeros(N + 1, dtype=torch.long)
+    rp[1:] = torch.bincount(ei[1], minlength=N).cumsum(0)
+    assert torch.equal(plan.dst_rowptr.cpu().long(), rp)
+    assert torch.equal(plan.dst_perm.cpu().long(), torch.sort(ei[1], stable=True).indices)
+    empty = ops.EdgePlan(torch.zeros(2, 0, dtype=torch.long, device=dev), 5)
+    assert empty.dst_rowptr.cpu().tolist() == [0] * 6
+
+
+@pytest.mark.parametrize("F,with_mult", [(3, False), (1, True), (48, False)])
+def test_segment_softmax(env, F, with_mult):
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(7)
+    S = 40
+    counts = torch.randint(0, 9, (S,), generator=g)
+    counts[3] = 0
+    rowptr = torch.zeros(S + 1, dtype=torch.int32)
+    rowptr[1:] = counts.cumsum(0).int()
+    R = int(rowptr[-1])
+    seg = torch.repeat_interleave(torch.arange(S), counts)
+    a = (3 * torch.randn(R, F, generator=g)).to(dev).requires_grad_(True)
+    mult = (torch.rand(R, generator=g) + 0.1).to(dev).requires_grad_(True) if with_mult else None
+    eps = 1e-13 if with_mult else 1e-16
+    al = ops.SegmentSoftmaxFn.apply(a, mult, rowptr.to(dev), eps)
+    cot = torch.randn(R, F, generator=g).to(dev)
+    grads = torch.autograd.grad((al * cot).sum(), [a] + ([mult] if with_mult else []))
+    # fp64 reference
+    ad = a.detach().double().cpu().requires_grad_(True)
+    md = mult.detach().double().cpu().requires_grad_(True) if with_mult else None
+    mx = torch.full((S, F), -float("inf"), dtype=torch.float64).scatter_reduce(0, seg.view(-1, 1).expand(R, F), ad.detach(), "amax")
+    ex = (ad - mx[seg]).exp()
+    if with_mult:
+        ex = ex * md.view(-1, 1)
+    den = torch.zeros(S, F, dtype=torch.float64).index_add(0, seg, ex)
+    ref = ex / (den[seg] + eps)
+    rg = torch.autograd.grad((ref * cot.double().cpu()).sum(), [ad] + ([md] if with_mult else []))
+    assert rel(al.detach(), ref.detach()) <= TOL
+    for got, want in zip(grads, rg):
+        assert rel(got, want) <= 5e-5
