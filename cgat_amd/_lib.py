@@ -55,7 +55,7 @@ class GemmDesc(C.Structure):
                 ("a_kmajor", C.c_int32), ("a_rgather", vp), ("B", vp), ("ldb", C.c_int64), ("b_kmajor", C.c_int32),
                 ("b_kgather", vp), ("C", vp), ("ldc", C.c_int64), ("c_scatter", vp), ("alpha", C.c_float),
                 ("beta", C.c_float), ("bias", vp), ("add1", vp), ("add1_idx", vp), ("add2", vp), ("add2_idx", vp),
-                ("ld_add", C.c_int64), ("act", C.c_int32), ("splits", C.c_int32)]
+                ("ld_add", C.c_int64), ("act", C.c_int32), ("splits", C.c_int32), ("a_block", C.c_int64)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -93,8 +93,9 @@ PROTOTYPES = {
     "cgat_segment_sum": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, C.c_int64, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
+    "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32,
-                                     C.c_int32, C.c_int32, C.c_int32, vp]),
+                                     C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
     "cgat_bilinear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, vp, C.c_size_t, vp]),

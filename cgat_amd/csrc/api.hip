@@ -156,7 +156,7 @@ extern "C" int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx
 // ---- kernel-level primitives ----
 static GemmParams from_desc(const cgat_gemm_desc* d) {
   GemmParams g = gemm_params(d->M, d->N, d->K, d->A, d->lda, d->B, d->ldb, d->C, d->ldc);
-  g.a_kmajor = d->a_kmajor; g.a_rgather = d->a_rgather;
+  g.a_kmajor = d->a_kmajor; g.a_rgather = d->a_rgather; g.a_block = d->a_block;
   g.b_kmajor = d->b_kmajor; g.b_kgather = d->b_kgather;
   g.c_scatter = d->c_scatter;
   g.alpha = d->alpha; g.beta = d->beta; g.bias = d->bias;
@@ -176,10 +176,21 @@ extern "C" int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, voi
   CGAT_CHECK_ARG(!(!d->b_kmajor && d->b_kgather), "gemm: b_kgather needs b_kmajor == 1");
   return gemm_launch(from_desc(d), ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
+  return ws_round((size_t)NA * NB * NC, 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
+}
 extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T,
                                   const float* init, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA,
-                                  int32_t NB, int32_t NC, void* stream) {
-  return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, (hipStream_t)stream);
+                                  int32_t NB, int32_t NC, void* ws, size_t ws_bytes, void* stream) {
+  if (ws_bytes < cgat_bilinear_rows_workspace_bytes(rows, NA, NB, NC)) {
+    cgat_set_error("bilinear_rows: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  float* Tq = (float*)ws;
+  size_t off = ws_round((size_t)NA * NB * NC, 4);
+  CGAT_TRY(bilinear_prepare_T(T, Tq, NA, NB, NC, 0, 1, 2, (hipStream_t)stream));
+  return bilinear_rows_launch(p, ldp, q, ldq, Tq, init, ldi, out, ldo, rows, NA, NB, NC, (char*)ws + off,
+                              ws_bytes - off, (hipStream_t)stream);
 }
 extern "C" size_t cgat_bilinear_wgrad_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
   return bilinear_wgrad_ws_bytes(rows, NA, NB, NC) + 256;

@@ -21,18 +21,29 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// T is expected in the "interleaved" layout made by bilinear_prepare_T: row (a,b) holds its 128
+// output columns as [r = c % 32][cb = c / 32], so that lane r fetches the B operands of its four
+// accumulator blocks with ONE ds_read_b128.
+// grid = asplit * tiles: workgroup (s, tile) covers a in [s*NA/asplit, (s+1)*NA/asplit) and writes
+// a partial slab when asplit > 1 (summed in fixed order by slab_sum_rows_kernel).
 __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* __restrict__ p, long ldp,
                                                                   const float* __restrict__ q, long ldq,
                                                                   const float* __restrict__ T,
                                                                   const float* __restrict__ init, long ldi,
                                                                   float* __restrict__ out, long ldo, int nrows,
-                                                                  int NA) {
+                                                                  int NA, int tiles, int asplit, long slab_stride) {
   __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hi = lane >> 5;
-  const int row0 = blockIdx.x * 128 + wave * 32;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
+  const int row0 = tile * 128 + wave * 32;
   const int myrow = row0 + r;
   const long rowc = myrow < nrows ? myrow : nrows - 1;
+  if (asplit > 1) {
+    out += (long)split * slab_stride;
+    if (split > 0) init = nullptr;
+  }
 
   // q[row, 64*hi .. 64*hi+63] stays in registers
   float qreg[64];
@@ -58,17 +69,16 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
     }
 
   // chunk (a, jc): T rows  a*128 + 64*kk + 16*jc + jj,  kk in {0,1}, jj < 16   -> LDS row kk*16 + jj
-  // per-thread constant part of the four 16-byte pieces it moves per chunk
   const int f_row = tid >> 5, f_cq = tid & 31;            // piece i covers LDS row f_row + 8*i
-  const long t_off = (long)(64 * (f_row >> 4) + (f_row & 15)) * 128 + 4 * f_cq;   // i adds 8 rows (same kk for i<2 / i>=2)
+  const long t_off = (long)f_row * 128 + 4 * f_cq;
   float4 pre0, pre1, pre2, pre3;
 #define BIL_GLOAD(a_, jc_)                                                              \
   {                                                                                     \
     const float* tb = T + ((long)(a_) * 128 + 16 * (jc_)) * 128 + t_off;                \
     pre0 = *reinterpret_cast<const float4*>(tb);                                        \
     pre1 = *reinterpret_cast<const float4*>(tb + 8 * 128);                              \
-    pre2 = *reinterpret_cast<const float4*>(tb + 64 * 128);                            \
-    pre3 = *reinterpret_cast<const float4*>(tb + (64 + 8) * 128);                       \
+    pre2 = *reinterpret_cast<const float4*>(tb + 64 * 128);                             \
+    pre3 = *reinterpret_cast<const float4*>(tb + 72 * 128);                             \
   }
 #define BIL_LSTORE(buf_)                                                                \
   {                                                                                     \
@@ -78,12 +88,12 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
     *reinterpret_cast<float4*>(lb + 16 * 128) = pre2;                                   \
     *reinterpret_cast<float4*>(lb + 24 * 128) = pre3;                                   \
   }
-  BIL_GLOAD(0, 0);
+  BIL_GLOAD(a_beg, 0);
   BIL_LSTORE(0);
-  float pa = p[rowc * ldp];
+  float pa = p[rowc * ldp + a_beg];
   __syncthreads();
-  for (int a = 0; a < NA; ++a) {
-    const int an = (a + 1 < NA) ? a + 1 : a;  // the prefetch after the last chunk re-reads a valid chunk, unused
+  for (int a = a_beg; a < a_end; ++a) {
+    const int an = (a + 1 < a_end) ? a + 1 : a;  // the prefetch after the last chunk re-reads a valid chunk, unused
     float pa_next = p[rowc * ldp + an];
     // two-level summation: the 128 products of one `a` go into fresh accumulators, which are then
     // added to the totals -- the error growth of the reference's (W_n = T z ; y = W_n v) order,
@@ -97,13 +107,20 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
     for (int jc = 0; jc < 4; ++jc) {
       const int cur = jc & 1;
       if (jc < 3) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0);
-      const float* bs = &Bs[cur][(hi * 16) * 128 + r];
+      // B operands of step jj for this lane's four blocks: one 16-byte LDS read, fetched one step ahead
+      const float4* bs = reinterpret_cast<const float4*>(&Bs[cur][(hi * 16) * 128 + 4 * r]);
+      float4 bv = bs[0];
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
-        float av = pa * qreg[16 * jc + jj];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          part[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bs[jj * 128 + cb * 32], part[cb], 0, 0, 0);
+        float4 bn = bv;
+        if (jj < 15) bn = bs[(jj + 1) * 32];
+        __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS read ahead of this step's MFMAs
+        const float av = pa * qreg[16 * jc + jj];
+        part[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, part[0], 0, 0, 0);
+        part[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, part[1], 0, 0, 0);
+        part[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, part[2], 0, 0, 0);
+        part[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, part[3], 0, 0, 0);
+        bv = bn;
       }
       BIL_LSTORE(cur ^ 1);
       __syncthreads();
@@ -121,6 +138,16 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
       int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
       if (orow < nrows) out[(long)orow * ldo + cb * 32 + r] = acc[cb][t];
     }
+}
+
+// out[n, c] = sum_s slab[s][n][c]   (fixed order)
+__global__ void slab_sum_rows_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
+                                     float* __restrict__ out, long ldo) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nrows * 128) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slab[(long)z * slab_stride + i];
+  out[(i >> 7) * ldo + (i & 127)] = s;
 }
 
 // any NA, NB, NC: one thread per output element (used for widths other than 128 and as a
@@ -151,21 +178,75 @@ static bool force_generic() {
   return v == 1;
 }
 
+static bool rows_fast(const float* q, long ldq, int NB, int NC) {
+  return NB == 128 && NC == 128 && (ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && !force_generic();
+}
+
+// how many ways to split the `a` range so that tiles*split fills 256 CUs without a ragged last wave
+static int rows_asplit(int nrows) {
+  const int tiles = cdiv(nrows, 128);
+  int best = 1;
+  double best_eff = 0.0;
+  for (int sp = 1; sp <= 4; ++sp) {
+    double w = (double)tiles * sp / 256.0;
+    double eff = w / (double)((long)(w + 0.999999));
+    if (eff > best_eff + 0.02) {
+      best_eff = eff;
+      best = sp;
+    }
+  }
+  return best;
+}
+
+bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
+
+size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
+  if (!bilinear_T_interleaved(NB, NC)) return 0;
+  int sp = rows_asplit(nrows);
+  return sp > 1 ? ws_round((size_t)sp * nrows * 128, 4) : 0;
+}
+
+// T must come from bilinear_prepare_T (interleaved columns iff bilinear_T_interleaved(NB, NC))
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
-                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, hipStream_t stream) {
+                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
   if (nrows <= 0) return CGAT_OK;
-  bool fast = NB == 128 && NC == 128 && (ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)T) & 15) == 0 &&
-              !force_generic();
-  if (fast) {
-    CGAT_PROF("bilinear_rows", stream);
-    hipLaunchKernelGGL(bilinear_rows128_kernel, dim3(cdiv(nrows, 128)), dim3(256), 0, stream, p, ldp, q, ldq, T, init,
-                       ldi, out, ldo, nrows, NA);
+  if (bilinear_T_interleaved(NB, NC)) {
+    if (!rows_fast(q, ldq, NB, NC) || (((uintptr_t)T) & 15) != 0) {
+      cgat_set_error("bilinear_rows: q and T must be 16-byte aligned with ldq %% 4 == 0 at width 128");
+      return CGAT_ERR_ARG;
+    }
+    const int tiles = cdiv(nrows, 128);
+    const int sp = rows_asplit(nrows);
+    float* dst = out;
+    long dld = ldo, stride = 0;
+    if (sp > 1) {
+      size_t need = ws_round((size_t)sp * nrows * 128, 4);
+      if (!ws || ws_bytes < need) {
+        cgat_set_error("bilinear_rows: workspace too small (%zu < %zu)", ws_bytes, need);
+        return CGAT_ERR_WORKSPACE;
+      }
+      dst = (float*)ws;
+      dld = 128;
+      stride = (long)nrows * 128;
+    }
+    {
+      CGAT_PROF("bilinear_rows", stream);
+      hipLaunchKernelGGL(bilinear_rows128_kernel, dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, T, init, ldi,
+                         dst, dld, nrows, NA, tiles, sp, stride);
+    }
+    CGAT_LAUNCH_CHECK();
+    if (sp > 1) {
+      hipLaunchKernelGGL(slab_sum_rows_kernel, dim3(cdiv((long)nrows * 128, 256)), dim3(256), 0, stream,
+                         (const float*)ws, sp, stride, nrows, out, ldo);
+      CGAT_LAUNCH_CHECK();
+    }
   } else {
     CGAT_PROF("bilinear_rows_generic", stream);
     hipLaunchKernelGGL(bilinear_rows_generic_kernel, dim3(cdiv((long)nrows * NC, 256)), dim3(256), 0, stream, p, ldp,
                        q, ldq, T, init, ldi, out, ldo, nrows, NA, NB, NC);
+    CGAT_LAUNCH_CHECK();
   }
-  CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
 
@@ -260,18 +341,29 @@ __global__ __launch_bounds__(256, 2) void bilinear_wgrad128_kernel(const float* 
           for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
         }
     }
+    {  // operands of step i+1 are fetched from LDS before the MFMAs of step i issue
+      const float* qb = &qs[cur][hi * 128 + wb + r];
+      const float* rb = &rs[cur][hi * 128 + wc + r];
+      const float* pb = &ps[cur][hi];
+      float pv = pb[0], q0 = qb[0], q1 = qb[32], b0 = rb[0], b1 = rb[32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int n = 2 * i + hi;
-      float pv = ps[cur][n];
-      float a0 = pv * qs[cur][n * 128 + wb + r];
-      float a1 = pv * qs[cur][n * 128 + wb + 32 + r];
-      float b0 = rs[cur][n * 128 + wc + r];
-      float b1 = rs[cur][n * 128 + wc + 32 + r];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        float pvn = pv, q0n = q0, q1n = q1, b0n = b0, b1n = b1;
+        if (i < 15) {
+          pvn = pb[2 * (i + 1)];
+          q0n = qb[(2 * (i + 1)) * 128];
+          q1n = qb[(2 * (i + 1)) * 128 + 32];
+          b0n = rb[(2 * (i + 1)) * 128];
+          b1n = rb[(2 * (i + 1)) * 128 + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads ahead of this step's MFMAs
+        const float a0 = pv * q0, a1 = pv * q1;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        pv = pvn; q0 = q0n; q1 = q1n; b0 = b0n; b1 = b1n;
+      }
     }
     if (c + 1 < nchunks) WG_LSTORE(cur ^ 1);
     __syncthreads();
@@ -365,16 +457,17 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
   return CGAT_OK;
 }
 
-// dst = src with its three indices permuted: dst dims are (n[perm0], n[perm1], n[perm2])
+// dst = src with its three indices permuted: dst dims are (n[perm0], n[perm1], n[perm2]).
+// interleave != 0 (last dst dim == 128): column c of every dst row is stored at (c % 32) * 4 + c / 32.
 __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2,
-                                int perm0, int perm1, int perm2) {
+                                int perm0, int perm1, int perm2, int interleave) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)n0 * n1 * n2;
   if (i >= total) return;
   int dims[3] = {n0, n1, n2};
-  int d0 = dims[perm0], d1 = dims[perm1], d2 = dims[perm2];
-  (void)d0;
-  int z = (int)(i % d2);
+  int d1 = dims[perm1], d2 = dims[perm2];
+  int zs = (int)(i % d2);              // stored position inside the dst row
+  int z = interleave ? ((zs & 3) * 32 + (zs >> 2)) : zs;
   int y = (int)((i / d2) % d1);
   int x = (int)(i / ((long)d2 * d1));
   int idx[3];
@@ -383,11 +476,19 @@ __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict
 }
 
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
-                    hipStream_t stream) {
+                    int interleave, hipStream_t stream) {
   long total = (long)n0 * n1 * n2;
   if (total <= 0) return CGAT_OK;
   hipLaunchKernelGGL(permute3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, dst, n0, n1, n2, perm0, perm1,
-                     perm2);
+                     perm2, interleave);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
+}
+
+// The B operand of bilinear_rows for a [n0,n1,n2] tensor viewed with permuted indices.
+int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
+                       hipStream_t stream) {
+  int dims[3] = {n0, n1, n2};
+  return permute3_launch(src, dst, n0, n1, n2, perm0, perm1, perm2,
+                         bilinear_T_interleaved(dims[perm1], dims[perm2]) ? 1 : 0, stream);
 }

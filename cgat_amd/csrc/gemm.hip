@@ -42,6 +42,7 @@ struct TileLoader {
   const int* rgather;  // !KM: optional row index
   const int* kgather;  // KM: optional k index
   bool vec;          // 16-byte loads legal
+  long blk;          // 128-wide column-block stride (0 = plain layout)
   long roff[4];      // !KM: precomputed row offsets (elements), -1 = out of range
 
   __device__ void init(int tid) {
@@ -68,7 +69,7 @@ struct TileLoader {
       if (!KM) {
         int k = k0 + 4 * (f & 7);
         if (roff[i] >= 0 && k < kend) {
-          const float* p = base + roff[i] + k;
+          const float* p = base + roff[i] + (blk ? (long)(k >> 7) * blk + (k & 127) : (long)k);
           if (vec && k + 3 < kend) {
             t = *reinterpret_cast<const float4*>(p);
           } else {
@@ -83,7 +84,7 @@ struct TileLoader {
         int r = r0 + 4 * (f & 31);
         if (k < kend && r < R) {
           long krow = kgather ? (long)kgather[k] : (long)k;
-          const float* p = base + krow * ld + r;
+          const float* p = base + krow * ld + (blk ? (long)(r >> 7) * blk + (r & 127) : (long)r);
           if (vec && r + 3 < R) {
             t = *reinterpret_cast<const float4*>(p);
           } else {
@@ -123,24 +124,49 @@ template <bool AKM, bool BKM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int PA = AKM ? 132 : 129;
   constexpr int PB = BKM ? 132 : 129;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
+  // one LDS block: [As0 | As1 | Bs0 | Bs1]; reused as the 128 x 132 C tile by the vector epilogue
+  __shared__ __attribute__((aligned(16))) float lds_all[(2 * BK * PA + 2 * BK * PB) > BM * 132 ? (2 * BK * PA + 2 * BK * PB) : BM * 132];
+  float(*As)[BK * PA] = reinterpret_cast<float(*)[BK * PA]>(lds_all);
+  float(*Bs)[BK * PB] = reinterpret_cast<float(*)[BK * PB]>(lds_all + 2 * BK * PA);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hi = lane >> 5;
+  // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
+  // L2), so linear ids L and L+8 share an L2.  The "outer" index (K-split for split-K products,
+  // row tile otherwise) is striped over the XCDs and the tiles that share its operands ("inner")
+  // run back to back on ONE XCD: the shared operand tile is fetched into one L2 once instead
+  // of into up to eight.  Pure placement: any mapping gives the same results.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int tile_m, tile_n, z;
+  {
+    const int inner = p.splits > 1 ? tiles_m * tiles_n : tiles_n;
+    const int outer = p.splits > 1 ? p.splits : tiles_m;
+    const int L = blockIdx.x;
+    const int j = L >> 3;
+    const int o = (L & 7) + 8 * (j / inner);
+    const int i = j % inner;
+    if (o >= outer) return;
+    if (p.splits > 1) {
+      z = o;
+      tile_m = i / tiles_n;
+      tile_n = i % tiles_n;
+    } else {
+      z = 0;
+      tile_m = o;
+      tile_n = i;
+    }
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   // K range of this split
-  const int z = blockIdx.y;
   const int kbeg = z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
-  TileLoader<AKM> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, {0, 0, 0, 0}};
-  TileLoader<BKM> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, {0, 0, 0, 0}};
+  TileLoader<AKM> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, p.a_block, {0, 0, 0, 0}};
+  TileLoader<BKM> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, 0, {0, 0, 0, 0}};
   la.init(tid);
   lb.init(tid);
 
@@ -162,9 +188,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
       for (int t = 0; t < 16; ++t) tot[i][j][t] = 0.f;
   float4 ra[4], rb[4];
   const int nchunks = (kend - kbeg + BK - 1) / BK;
+  // Split-K streams start at offsets that are multiples of large powers of two and advance in
+  // lockstep, i.e. they all sit on the same HBM channels at the same time.  Each workgroup
+  // therefore walks its K range from a different (fixed, id-derived) starting chunk, wrapping
+  // around: same products, deterministic order, streams spread over the channels.
+  const int rot = (p.splits > 1 && nchunks > 1) ? (int)(((unsigned)z * 37u + (unsigned)tile_m * 11u + (unsigned)tile_n * 5u) % (unsigned)nchunks) : 0;
+#define CHUNK_K(c_) (kbeg + (((c_) + rot) >= nchunks ? ((c_) + rot - nchunks) : ((c_) + rot)) * BK)
   if (nchunks > 0) {
-    la.load(tid, kbeg, kend, ra);
-    lb.load(tid, kbeg, kend, rb);
+    la.load(tid, CHUNK_K(0), kend, ra);
+    lb.load(tid, CHUNK_K(0), kend, rb);
     la.template store<PA>(tid, As[0], ra);
     lb.template store<PB>(tid, Bs[0], rb);
   }
@@ -182,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         }
     }
     if (c + 1 < nchunks) {
-      la.load(tid, kbeg + (c + 1) * BK, kend, ra);
-      lb.load(tid, kbeg + (c + 1) * BK, kend, rb);
+      la.load(tid, CHUNK_K(c + 1), kend, ra);
+      lb.load(tid, CHUNK_K(c + 1), kend, rb);
     }
     const float* as = As[cur] + hi * PA + wm + r;
     const float* bs = Bs[cur] + hi * PB + wn + r;
@@ -203,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     __syncthreads();
   }
 
+#undef CHUNK_K
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -212,6 +245,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   const bool slab = p.splits > 1;
   if (slab) Cbase = p.slab + (long)z * p.M * p.N;
   const long ldc = slab ? (long)p.N : p.ldc;
+
+  if (p.c_vec) {
+    // Vector epilogue: the 128 x 128 accumulator tile goes through LDS (the operand buffers are
+    // free now) so that every global access of the epilogue -- the store, the gathered addends,
+    // the previous C -- is a 16-byte piece of a 512-byte row segment instead of one dword per
+    // lane (the dword form is store-issue-bound: 62 -> 29 TFLOP/s on the per-edge product).
+    constexpr int PC = 132;
+    float* Cs = lds_all;
+    __syncthreads();
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          Cs[(wm + bi * 32 + (t & 3) + 8 * (t >> 2) + 4 * hi) * PC + wn + bj * 32 + r] = acc[bi][bj][t];
+    __syncthreads();
+    const int c4 = tid & 31;            // 16-byte column piece
+    const int n = n0 + 4 * c4;
+    const bool ncol = n < p.N;          // N % 4 == 0 on this path
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!slab && p.bias && ncol) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int row = (tid >> 5) + 8 * i;
+      const int m = m0 + row;
+      if (m >= p.M || !ncol) continue;
+      float4 v = *reinterpret_cast<const float4*>(&Cs[row * PC + 4 * c4]);
+      long crow = m;
+      if (!slab) {
+        v.x = v.x * p.alpha + bias4.x; v.y = v.y * p.alpha + bias4.y;
+        v.z = v.z * p.alpha + bias4.z; v.w = v.w * p.alpha + bias4.w;
+        if (p.c_scatter) crow = p.c_scatter[m];
+        if (p.add1) {
+          const float4 g = *reinterpret_cast<const float4*>(p.add1 + (long)p.add1_idx[m] * p.ld_add + n);
+          v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+        }
+        if (p.add2) {
+          const float4 g = *reinterpret_cast<const float4*>(p.add2 + (long)p.add2_idx[m] * p.ld_add + n);
+          v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+        }
+        v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act);
+        v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+        if (p.beta != 0.f) {
+          const float4 c0 = *reinterpret_cast<const float4*>(Cbase + crow * ldc + n);
+          v.x += p.beta * c0.x; v.y += p.beta * c0.y; v.z += p.beta * c0.z; v.w += p.beta * c0.w;
+        }
+      }
+      *reinterpret_cast<float4*>(Cbase + crow * ldc + n) = v;
+    }
+    return;
+  }
+
+  // Scalar epilogue (N % 4 != 0 or unaligned C / addends): one dword per lane.
+  const int nA = n0 + wn + r, nB = nA + 32;
+  const bool okA = nA < p.N, okB = nB < p.N;
+  const float biasA = (!slab && p.bias && okA) ? p.bias[nA] : 0.f;
+  const float biasB = (!slab && p.bias && okB) ? p.bias[nB] : 0.f;
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi) {
 #pragma unroll
@@ -227,12 +318,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj) {
-        const int n = n0 + wn + bj * 32 + r;
-        if (n >= p.N) continue;
+        const int n = bj ? nB : nA;
+        if (!(bj ? okB : okA)) continue;
         float v = acc[bi][bj][t];
         if (!slab) {
-          v *= p.alpha;
-          if (p.bias) v += p.bias[n];
+          v = v * p.alpha + (bj ? biasB : biasA);
           if (g1) v += g1[n];
           if (g2) v += g2[n];
           v = act_apply(v, p.act);
@@ -263,16 +353,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 
 size_t gemm_ws_bytes(const GemmParams& p) { return p.splits > 1 ? ws_round((size_t)p.splits * p.M * p.N, 4) : 0; }
 
-// Chooses a split count for reductions with a long K and few output tiles.
+// Chooses a split count for reductions with a long K and few output tiles.  Workgroups are
+// striped over the 8 XCDs (see the kernel) and an XCD holds 32 CUs x 2 resident workgroups = 64
+// slots, so the choice is the q (splits = 8q) whose q * tiles workgroups per XCD fill whole
+// rounds of 64 best: 43 splits x 12 tiles left 8 workgroups per XCD for a second round and ran
+// 1.7x slower than 128 splits (3 exact rounds).
 int gemm_pick_splits(int M, int N, int K) {
-  long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
+  const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
   if (tiles >= 256 || K < 4 * BK * 8) return 1;
-  long want = (512 + tiles - 1) / tiles;
-  long maxs = K / (BK * 8);  // at least 8 chunks per split
-  long s = want < maxs ? want : maxs;
-  if (s < 1) s = 1;
-  if (s > 256) s = 256;
-  return (int)s;
+  const long qmax = K / (8L * BK * 8);  // at least 8 chunks per split
+  if (qmax < 1) return K >= 2 * BK * 8 ? (int)(K / (BK * 8)) : 1;
+  int best_q = 1;
+  double best = -1.0;
+  for (long q = 1; q <= qmax && q <= 64; ++q) {
+    const long per_xcd = q * tiles;
+    const long rounds = (per_xcd + 63) / 64;
+    double eff = (double)per_xcd / (64.0 * rounds);
+    if (rounds > 4) eff -= 0.02 * (rounds - 4);  // slab traffic grows with the split count
+    if (eff > best + 1e-9) {
+      best = eff;
+      best_q = (int)q;
+    }
+  }
+  return 8 * best_q;
 }
 
 int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -298,9 +401,27 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   }
   // 16-byte vector loads are legal when the contiguous dimension starts 16B-aligned in every row
   auto aligned = [](const float* ptr, long ld) { return (((uintptr_t)ptr) & 15) == 0 && (ld % 4) == 0; };
+  if (p.a_block) {
+    CGAT_CHECK_ARG(p.lda == 128 && (p.a_block % 4) == 0, "gemm: blocked A needs lda == 128");
+  }
   p.a_vec = aligned(p.A, p.lda) ? 1 : 0;
   p.b_vec = aligned(p.B, p.ldb) ? 1 : 0;
-  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.splits);
+  {
+    bool cv = (p.N % 4) == 0;
+    if (p.splits > 1) cv = cv && ((((uintptr_t)p.slab) & 15) == 0);
+    else {
+      cv = cv && aligned(p.C, p.ldc);
+      if (p.bias) cv = cv && ((((uintptr_t)p.bias) & 15) == 0);
+      if (p.add1) cv = cv && aligned(p.add1, p.ld_add);
+      if (p.add2) cv = cv && aligned(p.add2, p.ld_add);
+    }
+    p.c_vec = cv ? 1 : 0;
+  }
+  // 1-D grid in XCD-striped order (see the kernel): 8 * inner * ceil(outer / 8) workgroups
+  const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
+  const int inner = p.splits > 1 ? tiles_m * tiles_n : tiles_n;
+  const int outer = p.splits > 1 ? p.splits : tiles_m;
+  dim3 grid(8 * inner * cdiv(outer, 8));
   {
     CGAT_PROF("gemm_f32", stream);
     if (!p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, p);

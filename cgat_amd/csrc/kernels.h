@@ -13,6 +13,8 @@ struct GemmParams {
   long lda;
   int a_kmajor;          // 0: A(m,k)=A[row(m)*lda+k]   1: A(m,k)=A[k*lda+m]
   const int* a_rgather;  // a_kmajor==0 only: row(m)=a_rgather[m]
+  long a_block;          // != 0: A is stored in 128-wide column blocks [cols/128][rows][128] with this block
+                         // stride (elements); the blocked dimension is k (a_kmajor==0) or m (a_kmajor==1); lda=128
   const float* B;
   long ldb;
   int b_kmajor;          // 0: B(k,n)=B[n*ldb+k] (torch Linear weight)   1: B(k,n)=B[krow(k)*ldb+n]
@@ -30,7 +32,7 @@ struct GemmParams {
   int act;
   int splits;            // >1: split the K range, partial slabs in workspace, then reduce
   // filled by gemm_launch
-  int k_per_split, a_vec, b_vec;
+  int k_per_split, a_vec, b_vec, c_vec;
   float* slab;
 };
 
@@ -48,16 +50,22 @@ int gemm_pick_splits(int M, int N, int K);
 size_t gemm_ws_bytes(const GemmParams& p);
 
 // ---- bilinear (hypernetwork) contractions, bilinear.hip ----
-// out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T[(a*NB+b)*NC + c]
+// out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T3[a,b,c], with T = bilinear_prepare_T(T3 source):
+// a permuted copy whose columns are interleaved for the MFMA kernel when NB == NC == 128.
+bool bilinear_T_interleaved(int NB, int NC);
+int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
+                       hipStream_t stream);
+size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
-                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, hipStream_t stream);
+                         long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
 // out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c]      (workspace: slabs)
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
-                    hipStream_t stream);
+                    int interleave, hipStream_t stream);
 
 // ---- elementwise / row kernels, rowops.hip ----
 int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float eps, hipStream_t s);
@@ -81,7 +89,7 @@ int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float*
                            const int* rowptr, int S, int F, float* ga, float* gmult, hipStream_t s);
 // out[s, f] = sum_{r in seg s} w[r, f / fw] * act(x[r or ridx[r], f])      (w nullable, fw = features per weight)
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
-                    int F, int act, float* out, long ldo, hipStream_t s);
+                    int F, int act, float* out, long ldo, hipStream_t s, long xblock = 0);
 // per-row, per-head dot:  out[r,h] = sum_j act(x[r, h*Hd+j]) * v[(vrow(r)) * ldv + h*Hd + j] + bias[h] (+ addv[vrow(r)*H + h])
 int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, const int* vrow, const float* bias,
                   const float* addv, int rows, int H, int Hd, float* out, hipStream_t s);

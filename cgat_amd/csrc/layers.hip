@@ -49,6 +49,12 @@ struct Ctx {
     if (dry) return CGAT_OK;
     return bilinear_wgrad_launch(p, ldp, q, ldq, r, ldr, out, rows, NA, NB, NC, scratch, scratch_bytes, s);
   }
+  int bilinear(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init, long ldi,
+               float* out, long ldo, int rows, int NA, int NB, int NC) {
+    need(bilinear_rows_ws_bytes(rows, NA, NB, NC));
+    if (dry) return CGAT_OK;
+    return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, scratch, scratch_bytes, s);
+  }
   int mix_bwd(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb, float* gd, long n) {
     need(4096);
     if (dry) return CGAT_OK;
@@ -76,7 +82,7 @@ static int check_ws(const Ctx& c, const char* who) {
 __global__ void edge_gz_kernel(const float* __restrict__ Z, float* __restrict__ gZ, const float* __restrict__ ga,
                                const float* __restrict__ alpha, const float* __restrict__ gS,
                                const int* __restrict__ dst, const float* __restrict__ wA_out, int E, int H, int Hd,
-                               float* __restrict__ partial) {
+                               float* __restrict__ partial, long gz_block) {
   const int HHd = H * Hd, W2 = 2 * HHd;
   const int chunk = blockIdx.x;
   const int t0 = chunk * GZ_ROWS, t1 = min(E, t0 + GZ_ROWS);
@@ -97,7 +103,8 @@ __global__ void edge_gz_kernel(const float* __restrict__ Z, float* __restrict__ 
       } else {
         g = alpha[(long)t * H + h] * gS[(long)dst[t] * HHd + cc] * d;
       }
-      gZ[(long)t * W2 + col] = g;
+      if (gz_block) gZ[(long)(col >> 7) * gz_block + (long)t * 128 + (col & 127)] = g;  // column-block-major
+      else gZ[(long)t * W2 + col] = g;
     }
     if (isA) partial[(long)chunk * HHd + cc] = psum;
   }
@@ -210,6 +217,10 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(const_cast<float*>(saved), d);
   const float invH = 1.f / d.H;
+  // gZ is stored in 128-column blocks [W2/128][E][128] when the width allows: the weight-gradient
+  // product gZ^T @ e then streams each block contiguously instead of 512-byte pieces at a 6 KB stride
+  const long gzb = (d.W2 % 128 == 0) ? (long)d.E * 128 : 0;
+  const long gz_ld = gzb ? 128 : d.W2;
 
   CGAT_TRY(stack_in_weights(c, p, d, Wcat, nullptr));
   for (int h = 0; h < d.H; ++h) {
@@ -245,25 +256,28 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   if (!c.dry && d.E > 0) {
     hipLaunchKernelGGL(edge_gz_kernel, dim3(chunks), dim3(256), 0, c.s, sv.Z, gZ, ga, sv.alpha, gS, plan->dst_sorted,
-                       p->A_out_w, d.E, d.H, d.Hd, partial);
+                       p->A_out_w, d.E, d.H, d.Hd, partial, gzb);
     CGAT_LAUNCH_CHECK();
   }
   CGAT_TRY(c.colsum(partial, d.HHd, d.E > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   {  // grad edge_attr[perm[t]] = gZ[t] @ W_e
-    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, d.W2, Wcat + d.C, d.D, g_e, d.Ce);
+    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
+    g.a_block = gzb;
     g.b_kmajor = 1;
     g.c_scatter = plan->dst_perm;
     CGAT_TRY(c.gemm(g));
     // grad W_e = gZ^T @ e[perm]
-    g = gemm_params(d.W2, d.Ce, d.E, gZ, d.W2, e, d.Ce, gWcat + d.C, d.D);
+    g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
+    g.a_block = gzb;
     g.a_kmajor = 1; g.b_kmajor = 1;
     g.b_kgather = plan->dst_perm;
     CGAT_TRY(c.gemm(g, true));
   }
   // segment sums of gZ by destination (x_i side) and by source (x_j side)
-  RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s));
+  RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s,
+                      gzb));
   RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
-                      c.s));
+                      c.s, gzb));
   {
     GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
     g.b_kmajor = 1;
@@ -401,8 +415,8 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
       CGAT_TRY(c.gemm(g));
     }
     // trilinear term with T[o,i,k] = head_w[(o*W+i)*W + k] re-laid as Tp[i,k,o]
-    RUN(permute3_launch(L.head_w, Tp, W, W, W, 1, 2, 0, c.s));
-    RUN(bilinear_rows_launch(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W, c.s));
+    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 1, 2, 0, c.s));
+    CGAT_TRY(c.bilinear(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W));
     if (l < p->n_hyper - 1) {
       RUN(layernorm_tanh_fwd_launch(u, sv.vin(l + 1), rows, W, 1e-5f, c.s));
       vin = c.dry ? nullptr : sv.vin(l + 1);
@@ -450,21 +464,22 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       CGAT_TRY(c.gemm(g, true));
     }
     CGAT_TRY(c.colsum(gu, W, rows, W, G.head_b + WW, 1.f));
-    // ---- g_z = gu @ U + sum_{o,i} gu[o] vin[i] T[o,i,k]  (T in its stored layout) ----
+    // ---- g_z = gu @ U + sum_{o,i} gu[o] vin[i] T[o,i,k]  ----
     {
       GemmParams g = gemm_params(rows, W, W, gu, W, L.head_w + WW * W, W, g_t, W);
       g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g));
     }
-    RUN(bilinear_rows_launch(gu, W, vin, W, L.head_w, g_t, W, g_t, W, rows, W, W, W, c.s));
+    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 1, 2, c.s));
+    CGAT_TRY(c.bilinear(gu, W, vin, W, Tp, g_t, W, g_t, W, rows, W, W, W));
     // ---- g_vin = gu @ Bm + sum_{o,k} gu[o] z[k] T[o,i,k]   (T re-laid as [o,k,i]) ----
     {
       GemmParams g = gemm_params(rows, W, W, gu, W, L.head_b, W, g_vin, W);
       g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g));
     }
-    RUN(permute3_launch(L.head_w, Tp, W, W, W, 0, 2, 1, c.s));
-    RUN(bilinear_rows_launch(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W, c.s));
+    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 2, 1, c.s));
+    CGAT_TRY(c.bilinear(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W));
     // ---- trunk backward (g_t holds the gradient wrt the trunk output z) ----
     for (int s = p->n_fc - 1; s >= 0; --s) {
       const float* tout = c.dry ? nullptr : sv.act(l, s);

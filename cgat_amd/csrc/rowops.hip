@@ -109,41 +109,51 @@ int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act
   return CGAT_OK;
 }
 
-// ---- column sums: partial[chunk][c] over row chunks, then a fixed-order final sum (deterministic) ----
-#define COLSUM_ROWS 512
+// ---- column sums: partial[chunk][c] over 128-row chunks (256 threads = 64 columns x 4 row lanes,
+// LDS-combined), then a second pass of the same shape over the partials; fixed summation order,
+// hence deterministic ----
+#define COLSUM_ROWS 128
 __global__ void colsum_partial_kernel(const float* __restrict__ x, long ldx, int rows, int cols,
-                                      float* __restrict__ partial) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  int chunk = blockIdx.y;
-  if (c >= cols) return;
-  int r0 = chunk * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+                                      float* __restrict__ partial, float alpha) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += x[(long)r * ldx + c];
-  partial[(long)chunk * cols + c] = s;
+  if (c < cols)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(long)r * ldx + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = alpha * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out,
-                                    float alpha) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[(long)k * cols + c];
-  out[c] = alpha * s;
+static inline int colsum_chunks(int rows) { return cdiv(rows > 0 ? rows : 1, COLSUM_ROWS); }
+size_t colsum_ws_bytes(int rows, int cols) {
+  size_t c1 = colsum_chunks(rows), c2 = colsum_chunks((int)c1);
+  return ws_round(c1 * cols, 4) + ws_round(c2 * cols, 4);
 }
-size_t colsum_ws_bytes(int rows, int cols) { return ws_round((size_t)cdiv(rows > 0 ? rows : 1, COLSUM_ROWS) * cols, 4); }
 int colsum_launch(const float* x, long ldx, int rows, int cols, float* out, float alpha, void* ws, size_t ws_bytes,
                   hipStream_t s) {
   if (cols <= 0) return CGAT_OK;
-  int chunks = cdiv(rows > 0 ? rows : 1, COLSUM_ROWS);
   if (!ws || ws_bytes < colsum_ws_bytes(rows, cols)) {
     cgat_set_error("colsum: workspace too small");
     return CGAT_ERR_WORKSPACE;
   }
-  float* partial = (float*)ws;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 128), chunks), dim3(128), 0, s, x, ldx, rows, cols,
-                     partial);
-  CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 128)), dim3(128), 0, s, partial, chunks, cols, out, alpha);
-  CGAT_LAUNCH_CHECK();
+  float* bufs[2] = {(float*)ws, (float*)((char*)ws + ws_round((size_t)colsum_chunks(rows) * cols, 4))};
+  const float* src = x;
+  long ld = ldx;
+  int n = rows > 0 ? rows : 0, level = 0;
+  while (true) {
+    int chunks = colsum_chunks(n);
+    float* dst = chunks == 1 ? out : bufs[level & 1];
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, s, src, ld, n, cols, dst,
+                       level == 0 ? alpha : 1.f);
+    CGAT_LAUNCH_CHECK();
+    if (chunks == 1) break;
+    src = dst;
+    ld = cols;
+    n = chunks;
+    ++level;
+  }
   return CGAT_OK;
 }
 

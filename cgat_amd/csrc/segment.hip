@@ -95,7 +95,7 @@ int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float*
 // one workgroup per segment, threads stride the feature dimension, rows in CSR order
 __global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int* __restrict__ ridx,
                                 const float* __restrict__ w, int wF, int fw, const int* __restrict__ rowptr, int F,
-                                int act, float* __restrict__ out, long ldo) {
+                                int act, float* __restrict__ out, long ldo, long xblock) {
   int s = blockIdx.x;
   int r0 = rowptr[s], r1 = rowptr[s + 1];
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
@@ -103,7 +103,7 @@ __global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int
     int wf = w ? f / fw : 0;
     for (int r = r0; r < r1; ++r) {
       long row = ridx ? (long)ridx[r] : (long)r;
-      float v = act_f(x[row * ldx + f], act);
+      float v = act_f(xblock ? x[(long)(f >> 7) * xblock + row * 128 + (f & 127)] : x[row * ldx + f], act);
       if (w) v *= w[(long)r * wF + wf];
       acc += v;
     }
@@ -112,10 +112,11 @@ __global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int
 }
 
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
-                    int F, int act, float* out, long ldo, hipStream_t s) {
+                    int F, int act, float* out, long ldo, hipStream_t s, long xblock) {
   if (S <= 0 || F <= 0) return CGAT_OK;
   int threads = F >= 256 ? 256 : (F >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(seg_wsum_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out, ldo);
+  hipLaunchKernelGGL(seg_wsum_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out, ldo,
+                     xblock);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

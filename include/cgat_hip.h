@@ -182,13 +182,17 @@ typedef struct cgat_gemm_desc {
   int64_t ld_add;
   int32_t act;
   int32_t splits; /* 0 = choose automatically */
+  int64_t a_block; /* != 0: A stored as 128-wide column blocks [cols/128][rows][128], block stride in floats;
+                      the blocked dimension is k (a_kmajor=0) or m (a_kmajor=1); lda must be 128 */
 } cgat_gemm_desc;
 size_t cgat_gemm_workspace_bytes(const cgat_gemm_desc* d);
 int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, void* stream);
-/* out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T[(a*NB+b)*NC + c]   (init may be NULL or == out) */
+/* out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T[(a*NB+b)*NC + c]   (init may be NULL or == out).
+ * The workspace holds the kernel-side re-layout of T and the partial slabs of the a-split. */
+size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC);
 int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T, const float* init,
                        int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA, int32_t NB, int32_t NC,
-                       void* stream);
+                       void* ws, size_t ws_bytes, void* stream);
 /* out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c] */
 size_t cgat_bilinear_wgrad_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC);
 int cgat_bilinear_wgrad(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* r, int64_t ldr,
