@@ -26,13 +26,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // accumulator blocks with ONE ds_read_b128.
 // grid = asplit * tiles: workgroup (s, tile) covers a in [s*NA/asplit, (s+1)*NA/asplit) and writes
 // a partial slab when asplit > 1 (summed in fixed order by slab_sum_rows_kernel).
+// JS = j-steps per LDS chunk (a chunk is 2*JS rows of T = JS KB), FLUSH = number of consecutive
+// `a` whose products share one partial accumulator (two-level summation, see below).
+template <int JS, int FLUSH>
 __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* __restrict__ p, long ldp,
                                                                   const float* __restrict__ q, long ldq,
                                                                   const float* __restrict__ T,
                                                                   const float* __restrict__ init, long ldi,
                                                                   float* __restrict__ out, long ldo, int nrows,
                                                                   int NA, int tiles, int asplit, long slab_stride) {
-  __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
+  constexpr int NCH = 64 / JS;          // chunks per `a`
+  constexpr int NP = JS / 4;            // 16-byte pieces per thread per chunk (2*JS rows * 32 pieces / 256 threads)
+  __shared__ __attribute__((aligned(16))) float Bs[2][2 * JS * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hi = lane >> 5;
   const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -68,68 +73,77 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
       acc[cb][t] = v;
     }
 
-  // chunk (a, jc): T rows  a*128 + 64*kk + 16*jc + jj,  kk in {0,1}, jj < 16   -> LDS row kk*16 + jj
-  const int f_row = tid >> 5, f_cq = tid & 31;            // piece i covers LDS row f_row + 8*i
-  const long t_off = (long)f_row * 128 + 4 * f_cq;
-  float4 pre0, pre1, pre2, pre3;
-#define BIL_GLOAD(a_, jc_)                                                              \
-  {                                                                                     \
-    const float* tb = T + ((long)(a_) * 128 + 16 * (jc_)) * 128 + t_off;                \
-    pre0 = *reinterpret_cast<const float4*>(tb);                                        \
-    pre1 = *reinterpret_cast<const float4*>(tb + 8 * 128);                              \
-    pre2 = *reinterpret_cast<const float4*>(tb + 64 * 128);                             \
-    pre3 = *reinterpret_cast<const float4*>(tb + 72 * 128);                             \
+  // chunk (a, jc): T rows  a*128 + 64*kk + JS*jc + jj,  kk in {0,1}, jj < JS  -> LDS row kk*JS + jj.
+  // Thread piece i (< NP) covers LDS row f_row + 8*i: kk = (f_row + 8 i) / JS, jj = (f_row + 8 i) % JS.
+  const int f_row = tid >> 5, f_cq = tid & 31;
+  // named staging registers (an array captured by a lambda is demoted to scratch by hipcc)
+  float4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;
+#define BIL_G1(i_, reg_)                                                                                   \
+  if constexpr ((i_) < NP) {                                                                               \
+    constexpr int kk = (8 * (i_)) / JS;                                                                    \
+    reg_ = *reinterpret_cast<const float4*>(tb + ((long)(64 * kk + 8 * (i_) - kk * JS)) * 128);            \
   }
-#define BIL_LSTORE(buf_)                                                                \
-  {                                                                                     \
-    float* lb = &Bs[buf_][f_row * 128 + 4 * f_cq];                                      \
-    *reinterpret_cast<float4*>(lb) = pre0;                                              \
-    *reinterpret_cast<float4*>(lb + 8 * 128) = pre1;                                    \
-    *reinterpret_cast<float4*>(lb + 16 * 128) = pre2;                                   \
-    *reinterpret_cast<float4*>(lb + 24 * 128) = pre3;                                   \
+#define BIL_GLOAD(a_, jc_)                                                                                 \
+  {                                                                                                        \
+    const float* tb = T + ((long)(a_) * 128 + JS * (jc_) + f_row) * 128 + 4 * f_cq;                        \
+    BIL_G1(0, pre0) BIL_G1(1, pre1) BIL_G1(2, pre2) BIL_G1(3, pre3)                                        \
+    BIL_G1(4, pre4) BIL_G1(5, pre5) BIL_G1(6, pre6) BIL_G1(7, pre7)                                        \
+  }
+#define BIL_S1(i_, reg_) \
+  if constexpr ((i_) < NP) *reinterpret_cast<float4*>(lb + 8 * (i_) * 128) = reg_;
+#define BIL_LSTORE(buf_)                                                                                   \
+  {                                                                                                        \
+    float* lb = &Bs[buf_][f_row * 128 + 4 * f_cq];                                                         \
+    BIL_S1(0, pre0) BIL_S1(1, pre1) BIL_S1(2, pre2) BIL_S1(3, pre3)                                        \
+    BIL_S1(4, pre4) BIL_S1(5, pre5) BIL_S1(6, pre6) BIL_S1(7, pre7)                                        \
   }
   BIL_GLOAD(a_beg, 0);
   BIL_LSTORE(0);
   float pa = p[rowc * ldp + a_beg];
   __syncthreads();
-  for (int a = a_beg; a < a_end; ++a) {
-    const int an = (a + 1 < a_end) ? a + 1 : a;  // the prefetch after the last chunk re-reads a valid chunk, unused
-    float pa_next = p[rowc * ldp + an];
-    // two-level summation: the 128 products of one `a` go into fresh accumulators, which are then
-    // added to the totals -- the error growth of the reference's (W_n = T z ; y = W_n v) order,
-    // instead of one 16 384-term fp32 chain
+  // Two-level summation: the 128*FLUSH products of FLUSH consecutive `a` go into fresh accumulators
+  // that are then added to the totals -- the error growth of the reference's blocked order
+  // (W_n = T z ; y = W_n v), instead of one 16 384-term fp32 chain.
+  int buf = 0;
+  for (int a2 = a_beg; a2 < a_end; a2 += FLUSH) {
     f32x16 part[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
       for (int t = 0; t < 16; ++t) part[cb][t] = 0.f;
+    for (int a = a2; a < a2 + FLUSH && a < a_end; ++a) {
+      const int an = (a + 1 < a_end) ? a + 1 : a;  // the prefetch after the last chunk re-reads a valid chunk, unused
+      float pa_next = p[rowc * ldp + an];
 #pragma unroll
-    for (int jc = 0; jc < 4; ++jc) {
-      const int cur = jc & 1;
-      if (jc < 3) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0);
-      // B operands of step jj for this lane's four blocks: one 16-byte LDS read, fetched one step ahead
-      const float4* bs = reinterpret_cast<const float4*>(&Bs[cur][(hi * 16) * 128 + 4 * r]);
-      float4 bv = bs[0];
+      for (int jc = 0; jc < NCH; ++jc) {
+        if (jc + 1 < NCH) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0);
+        // B operands of step jj for this lane's four blocks: one 16-byte LDS read, fetched ahead
+        const float4* bs = reinterpret_cast<const float4*>(&Bs[buf][(hi * JS) * 128 + 4 * r]);
+        float4 bv = bs[0];
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        float4 bn = bv;
-        if (jj < 15) bn = bs[(jj + 1) * 32];
-        __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS read ahead of this step's MFMAs
-        const float av = pa * qreg[16 * jc + jj];
-        part[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, part[0], 0, 0, 0);
-        part[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, part[1], 0, 0, 0);
-        part[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, part[2], 0, 0, 0);
-        part[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, part[3], 0, 0, 0);
-        bv = bn;
+        for (int jj = 0; jj < JS; ++jj) {
+          float4 bn = bv;
+          if (jj + 1 < JS) bn = bs[(jj + 1) * 32];
+          __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS read ahead of this step's MFMAs
+          const float av = pa * qreg[JS * jc + jj];
+          part[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, part[0], 0, 0, 0);
+          part[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, part[1], 0, 0, 0);
+          part[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, part[2], 0, 0, 0);
+          part[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, part[3], 0, 0, 0);
+          bv = bn;
+        }
+        BIL_LSTORE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
       }
-      BIL_LSTORE(cur ^ 1);
-      __syncthreads();
+      pa = pa_next;
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb];
-    pa = pa_next;
   }
+#undef BIL_G1
 #undef BIL_GLOAD
+#undef BIL_S1
 #undef BIL_LSTORE
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
@@ -232,8 +246,25 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
     }
     {
       CGAT_PROF("bilinear_rows", stream);
-      hipLaunchKernelGGL(bilinear_rows128_kernel, dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, T, init, ldi,
-                         dst, dld, nrows, NA, tiles, sp, stride);
+      static int variant = -1;  // dev knob: CGAT_BIL_VARIANT = <JS><FLUSH>, e.g. 161, 162, 322, 324
+      if (variant < 0) {
+        const char* ev = getenv("CGAT_BIL_VARIANT");
+        variant = ev ? atoi(ev) : 162;
+      }
+      const char* ev2 = getenv("CGAT_BIL_VARIANT_LIVE");  // re-read on every call (A/B in one process)
+      const int v = ev2 ? atoi(ev2) : variant;
+#define BIL_LAUNCH(JS_, FL_)                                                                                     \
+  hipLaunchKernelGGL((bilinear_rows128_kernel<JS_, FL_>), dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, \
+                     T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride)
+      switch (v) {
+        case 161: BIL_LAUNCH(16, 1); break;
+        case 164: BIL_LAUNCH(16, 4); break;
+        case 321: BIL_LAUNCH(32, 1); break;
+        case 322: BIL_LAUNCH(32, 2); break;
+        case 324: BIL_LAUNCH(32, 4); break;
+        default: BIL_LAUNCH(16, 2); break;
+      }
+#undef BIL_LAUNCH
     }
     CGAT_LAUNCH_CHECK();
     if (sp > 1) {

@@ -110,6 +110,137 @@ __global__ void edge_gz_kernel(const float* __restrict__ Z, float* __restrict__ 
   }
 }
 
+// Node-aligned fused edge backward.  One workgroup owns SEGB_NODES consecutive destination
+// segments (whole segments, CSR order), so everything that PyG's softmax/scatter backward needs
+// per destination is local: per node n
+//   1. g_alpha[t,h] = leaky(zM[t,h,:]) . gS[n,h,:] + gs[n,h]            (block reductions)
+//   2. g_a[t,h]     = alpha[t,h] * (g_alpha[t,h] - sum_seg alpha * g_alpha)   (softmax backward)
+//   3. gZ[t,:]      = [ g_a * wA_out * leaky'(zA) | alpha * gS[n] * leaky'(zM) ],
+//      Gi[n,:]      = sum_seg gZ[t,:]   (the x_i-side segment sum),  partial sums of g_a*leaky(zA)
+//      for the gradient of MH_A.fc_out.weight.
+// gS[n] is read once per node instead of gathered per edge; Z is read twice but the second
+// read of a 70 KB segment hits L2.  No atomics; fixed summation order.
+#define SEGB_NODES 8
+__device__ __forceinline__ float wave_sum_l(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restrict__ Z, float* __restrict__ gZ,
+                                                           long gz_block, const float* __restrict__ alpha,
+                                                           const float* __restrict__ gS, const float* __restrict__ gs,
+                                                           const int* __restrict__ rowptr,
+                                                           const float* __restrict__ wA_out, int N, int H, int Hd,
+                                                           float* __restrict__ tt, float* __restrict__ ga,
+                                                           float* __restrict__ Gi, float* __restrict__ partialW) {
+  extern __shared__ float pw[];  // [HHd] per-column partial sums of g_a * leaky(zA)
+  const int HHd = H * Hd, W2 = 2 * HHd;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < HHd; c += 256) pw[c] = 0.f;
+  const int n0 = blockIdx.x * SEGB_NODES, n1 = min(N, n0 + SEGB_NODES);
+  for (int n = n0; n < n1; ++n) {
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    if (r1 == r0) {  // no incoming edge: zero row of the segment sum
+      for (int c = tid; c < W2; c += 256) Gi[(long)n * W2 + c] = 0.f;
+      continue;
+    }
+    const float* gSn = gS + (long)n * HHd;
+    // ---- 1. g_alpha: one wave per row, wave-level reductions only ----
+    for (int t = r0 + wave; t < r1; t += 4) {
+      const float* zM = Z + (long)t * W2 + HHd;
+      for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+        if (VEC) {
+          const float4* z4 = reinterpret_cast<const float4*>(zM + h * Hd);
+          const float4* g4 = reinterpret_cast<const float4*>(gSn + h * Hd);
+          for (int j = lane; j < Hd / 4; j += 64) {
+            float4 z = z4[j], g = g4[j];
+            part += (z.x > 0.f ? z.x : 0.01f * z.x) * g.x + (z.y > 0.f ? z.y : 0.01f * z.y) * g.y +
+                    (z.z > 0.f ? z.z : 0.01f * z.z) * g.z + (z.w > 0.f ? z.w : 0.01f * z.w) * g.w;
+          }
+        } else {
+          for (int j = lane; j < Hd; j += 64) {
+            float z = zM[h * Hd + j];
+            part += (z > 0.f ? z : 0.01f * z) * gSn[h * Hd + j];
+          }
+        }
+        part = wave_sum_l(part);
+        if (lane == 0) tt[(long)t * H + h] = part + gs[(long)n * H + h];
+      }
+    }
+    __syncthreads();
+    // ---- 2. softmax backward over the segment ----
+    if (tid < H) {
+      float dot = 0.f;
+      for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + tid] * tt[(long)t * H + tid];
+      for (int t = r0; t < r1; ++t) ga[(long)t * H + tid] = alpha[(long)t * H + tid] * (tt[(long)t * H + tid] - dot);
+    }
+    __syncthreads();
+    // ---- 3. gZ rows, their segment sum, partial sums for grad wA_out ----
+    if (VEC) {  // four consecutive columns per thread (a head boundary is a multiple of 4)
+      for (int c4 = tid; c4 < W2 / 4; c4 += 256) {
+        const int col = 4 * c4;
+        const bool isA = col < HHd;
+        const int cc = isA ? col : col - HHd;
+        const int h = cc / Hd;
+        const float4 wv = isA ? *reinterpret_cast<const float4*>(wA_out + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gsv = isA ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gSn + cc);
+        float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), ps = gi;
+        for (int t = r0; t < r1; ++t) {
+          const float4 z = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+          const float4 d = make_float4(z.x > 0.f ? 1.f : 0.01f, z.y > 0.f ? 1.f : 0.01f, z.z > 0.f ? 1.f : 0.01f,
+                                       z.w > 0.f ? 1.f : 0.01f);
+          float4 g;
+          if (isA) {
+            const float gav = ga[(long)t * H + h];
+            g = make_float4(gav * wv.x * d.x, gav * wv.y * d.y, gav * wv.z * d.z, gav * wv.w * d.w);
+            ps.x += gav * z.x * d.x; ps.y += gav * z.y * d.y; ps.z += gav * z.z * d.z; ps.w += gav * z.w * d.w;
+          } else {
+            const float al = alpha[(long)t * H + h];
+            g = make_float4(al * gsv.x * d.x, al * gsv.y * d.y, al * gsv.z * d.z, al * gsv.w * d.w);
+          }
+          float* dst = gz_block ? gZ + (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : gZ + (long)t * W2 + col;
+          *reinterpret_cast<float4*>(dst) = g;
+          gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
+        }
+        *reinterpret_cast<float4*>(Gi + (long)n * W2 + col) = gi;
+        if (isA) {
+          pw[cc] += ps.x; pw[cc + 1] += ps.y; pw[cc + 2] += ps.z; pw[cc + 3] += ps.w;
+        }
+      }
+    } else {
+      for (int col = tid; col < W2; col += 256) {
+        const bool isA = col < HHd;
+        const int cc = isA ? col : col - HHd;
+        const int h = cc / Hd;
+        const float wv = isA ? wA_out[cc] : 0.f;
+        const float gsv = isA ? 0.f : gSn[cc];
+        float gi = 0.f, ps = 0.f;
+        for (int t = r0; t < r1; ++t) {
+          const float z = Z[(long)t * W2 + col];
+          const float d = z > 0.f ? 1.f : 0.01f;
+          float g;
+          if (isA) {
+            const float gav = ga[(long)t * H + h];
+            g = gav * wv * d;
+            ps += gav * z * d;
+          } else {
+            g = alpha[(long)t * H + h] * gsv * d;
+          }
+          if (gz_block) gZ[(long)(col >> 7) * gz_block + (long)t * 128 + (col & 127)] = g;
+          else gZ[(long)t * W2 + col] = g;
+          gi += g;
+        }
+        Gi[(long)n * W2 + col] = gi;
+        if (isA) pw[cc] += ps;
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < HHd; c += 256) partialW[(long)blockIdx.x * HHd + c] = pw[c];
+}
+
 struct AttnDims {
   int N, E, C, Ce, H, Hd, D, HHd, W2;
 };
@@ -202,7 +333,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
                               const float* saved, const float* g_aggr, float* g_x, float* g_e,
                               const cgat_attn_grads* gr) {
   const AttnDims d = attn_dims(plan, p);
-  const int chunks = cdiv(d.E > 0 ? d.E : 1, GZ_ROWS);
+  const int chunks = cdiv(d.N > 0 ? d.N : 1, SEGB_NODES);  // workgroups of the fused segment kernel
   float* Wcat = c.take<float>((size_t)d.W2 * d.D);
   float* gWcat = c.take<float>((size_t)d.W2 * d.D);
   float* gbcat = c.take<float>((size_t)d.W2);
@@ -249,17 +380,24 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     g.alpha = invH;
     CGAT_TRY(c.gemm(g, true));
   }
-  // g_alpha[t,h] = leaky(zM[t,h,:]) . gS[dst,h,:] + gs[dst,h]
-  RUN(rowdot_launch(sv.Z + d.HHd, d.W2, CGAT_ACT_LEAKY, gS, d.HHd, plan->dst_sorted, nullptr, gs, d.E, d.H, d.Hd, tt,
-                    c.s));
-  RUN(seg_softmax_bwd_launch(sv.alpha, tt, nullptr, nullptr, plan->dst_rowptr, d.N, d.H, ga, nullptr, c.s));
-  CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
-  if (!c.dry && d.E > 0) {
-    hipLaunchKernelGGL(edge_gz_kernel, dim3(chunks), dim3(256), 0, c.s, sv.Z, gZ, ga, sv.alpha, gS, plan->dst_sorted,
-                       p->A_out_w, d.E, d.H, d.Hd, partial, gzb);
+  // g_alpha, softmax backward, gZ, the destination-side segment sum Gi and the partial sums for
+  // grad fc_out_A, all per whole destination segment in one pass (edge_seg_bwd_kernel)
+  if (!c.dry && d.N > 0) {
+    CGAT_CHECK_ARG(d.H <= 16, "nodes_attention_backward: more than 16 heads");
+    CGAT_PROF("edge_seg_bwd", c.s);
+    size_t shm = (size_t)d.HHd * sizeof(float);
+    const bool vec = (d.Hd % 4 == 0) && ((((uintptr_t)sv.Z) | ((uintptr_t)gZ) | ((uintptr_t)gS) | ((uintptr_t)Gi) |
+                                          ((uintptr_t)p->A_out_w)) & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial);
+    else
+      hipLaunchKernelGGL(edge_seg_bwd_kernel<false>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial);
     CGAT_LAUNCH_CHECK();
   }
-  CGAT_TRY(c.colsum(partial, d.HHd, d.E > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
+  CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
+  CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   {  // grad edge_attr[perm[t]] = gZ[t] @ W_e
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = gzb;
@@ -273,9 +411,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     g.b_kgather = plan->dst_perm;
     CGAT_TRY(c.gemm(g, true));
   }
-  // segment sums of gZ by destination (x_i side) and by source (x_j side)
-  RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s,
-                      gzb));
+  // segment sum of gZ by source (x_j side); the destination side came out of the fused kernel
   RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
                       c.s, gzb));
   {

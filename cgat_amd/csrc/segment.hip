@@ -122,6 +122,8 @@ int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, i
 }
 
 // one wave per row: out[r,h] = sum_j act(x[r,h*Hd+j]) * v[vrow(r)*ldv + h*Hd + j] + bias[h] + addv[vrow(r)*H + h]
+// VEC: 16-byte loads (Hd % 4 == 0, 16-byte aligned rows)
+template <bool VEC>
 __global__ void rowdot_kernel(const float* __restrict__ x, long ldx, int act, const float* __restrict__ v, long ldv,
                               const int* __restrict__ vrow, const float* __restrict__ bias,
                               const float* __restrict__ addv, int rows, int H, int Hd, float* __restrict__ out) {
@@ -133,7 +135,16 @@ __global__ void rowdot_kernel(const float* __restrict__ x, long ldx, int act, co
   const float* vv = v + vr * ldv;
   for (int h = 0; h < H; ++h) {
     float s = 0.f;
-    for (int j = lane; j < Hd; j += 64) s += act_f(xr[h * Hd + j], act) * vv[h * Hd + j];
+    if (VEC) {
+      const float4* x4 = reinterpret_cast<const float4*>(xr + h * Hd);
+      const float4* v4 = reinterpret_cast<const float4*>(vv + h * Hd);
+      for (int j = lane; j < Hd / 4; j += 64) {
+        float4 a = x4[j], b = v4[j];
+        s += act_f(a.x, act) * b.x + act_f(a.y, act) * b.y + act_f(a.z, act) * b.z + act_f(a.w, act) * b.w;
+      }
+    } else {
+      for (int j = lane; j < Hd; j += 64) s += act_f(xr[h * Hd + j], act) * vv[h * Hd + j];
+    }
     s = wave_sum64(s);
     if (lane == 0) {
       if (bias) s += bias[h];
@@ -146,8 +157,13 @@ __global__ void rowdot_kernel(const float* __restrict__ x, long ldx, int act, co
 int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, const int* vrow, const float* bias,
                   const float* addv, int rows, int H, int Hd, float* out, hipStream_t s) {
   if (rows <= 0) return CGAT_OK;
-  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, act, v, ldv, vrow, bias, addv, rows, H,
-                     Hd, out);
+  const bool vec = (Hd % 4 == 0) && (ldx % 4 == 0) && (ldv % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)v)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(rowdot_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, act, v, ldv, vrow, bias, addv,
+                       rows, H, Hd, out);
+  else
+    hipLaunchKernelGGL(rowdot_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, act, v, ldv, vrow, bias, addv,
+                       rows, H, Hd, out);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
