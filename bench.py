@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=GRAPHS, help="crystals per rank (default: the 1M-edge batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["layer", "stack"], default="layer",
+                    help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
+                         "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -93,21 +96,39 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     torch.manual_seed(1)                                   # identical parameters on every rank
-    layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
-    params = list(layer.parameters())
-    ei, x, e, x0, cot = make_inputs(args.graphs, rank, device)     # each rank: its own crystals
-    N, E = x.shape[0], ei.shape[1]
-    x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
-    averager = GradientAverager(params) if world > 1 else None
+    if args.workload == "layer":
+        layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
+        params = list(layer.parameters())
+        ei, x, e, x0, cot = make_inputs(args.graphs, rank, device)     # each rank: its own crystals
+        N, E = x.shape[0], ei.shape[1]
+        x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
+        averager = GradientAverager(params) if world > 1 else None
 
-    def step():
-        for p in params:
-            p.grad = None
-        x.grad = e.grad = x0.grad = None
-        y = layer(x, ei, e, x0)
-        y.backward(cot)
-        if averager is not None:
-            averager.finish()
+        def step():
+            for p in params:
+                p.grad = None
+            x.grad = e.grad = x0.grad = None
+            y = layer(x, ei, e, x0)
+            y.backward(cot)
+            if averager is not None:
+                averager.finish()
+    else:
+        net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
+        params = list(net.parameters())
+        b, roost = P.synthetic_batch(args.graphs, ATOMS, K_NBR, seed=rank)
+        b = b.to(device)
+        roost = tuple(t.to(device) for t in roost)
+        N, E = b.num_nodes, b.edge_index.shape[1]
+        averager = GradientAverager(params) if world > 1 else None
+
+        def step():
+            for p in params:
+                p.grad = None
+            out = net(b, roost)
+            loss = (out[:, 0] - b.y).abs().mean()          # L1 on the prediction column, as the harness' default
+            loss.backward()
+            if averager is not None:
+                averager.finish()
 
     def fence():
         if world > 1:
@@ -146,17 +167,27 @@ def main():
         for tag in ("bilinear_rows", "bilinear_wgrad", "gemm_f32"):
             n_t, ms_t = ops.prof_get(tag)
             shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_bilinear_rows.json")
+        if roof is not None and os.path.exists(traffic_file):
+            # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
+            roof["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        metric = ("edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch" if args.workload == "layer"
+                  else "batch-edges/sec through the full CGAT stack (4 layers, fwd+bwd), 1M-edge batch [informational]")
         out = {
-            "metric": "edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch",
+            "metric": metric,
             "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
-                                   f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention",
+            "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
+                                    f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention")
+                       if args.workload == "layer" else
+                       (f"CGAtNet(200,128,4,msg_heads=3,update_edges=True) fwd+bwd of L1 loss, {args.graphs} crystals: "
+                        f"N={N}, E={E}"),
                        "edges_per_rank": E, "parallelism": f"dp{world} (graphs sharded, gradient all-reduce)"},
             "roofline": roof, "kernel_ms_per_step": shares,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -6,6 +6,10 @@ import raises, and every compute entry point refuses non-GPU tensors.
 import ctypes as C
 import os
 
+# torch must initialise its (bundled) HIP runtime before libcgat_hip.so is mapped: loading our
+# library first would bind a second copy of libamdhip64 and leave one of the two without devices.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgat_hip.so")
 
