@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // a partial slab when asplit > 1 (summed in fixed order by slab_sum_rows_kernel).
 // JS = j-steps per LDS chunk (a chunk is 2*JS rows of T = JS KB), FLUSH = number of consecutive
 // `a` whose products share one partial accumulator (two-level summation, see below).
-template <int JS, int FLUSH>
+template <int JS, int FLUSH, int ABL = 0>  // ABL: timing-only ablations (1 no barrier, 2 no global loads, 3 both): wrong results
 __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* __restrict__ p, long ldp,
                                                                   const float* __restrict__ q, long ldq,
                                                                   const float* __restrict__ T,
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
       float pa_next = p[rowc * ldp + an];
 #pragma unroll
       for (int jc = 0; jc < NCH; ++jc) {
-        if (jc + 1 < NCH) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0);
+        if constexpr (!(ABL & 2)) { if (jc + 1 < NCH) BIL_GLOAD(a, jc + 1) else BIL_GLOAD(an, 0); }
         // B operands of step jj for this lane's four blocks: one 16-byte LDS read, fetched ahead
         const float4* bs = reinterpret_cast<const float4*>(&Bs[buf][(hi * JS) * 128 + 4 * r]);
         float4 bv = bs[0];
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
           part[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, part[3], 0, 0, 0);
           bv = bn;
         }
-        BIL_LSTORE(buf ^ 1);
-        __syncthreads();
+        if constexpr (!(ABL & 2)) BIL_LSTORE(buf ^ 1);
+        if constexpr (!(ABL & 1)) __syncthreads();
         buf ^= 1;
       }
       pa = pa_next;
@@ -258,6 +258,9 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
                      T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride)
       switch (v) {
         case 161: BIL_LAUNCH(16, 1); break;
+        case 901: hipLaunchKernelGGL((bilinear_rows128_kernel<16, 2, 1>), dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride); break;
+        case 902: hipLaunchKernelGGL((bilinear_rows128_kernel<16, 2, 2>), dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride); break;
+        case 903: hipLaunchKernelGGL((bilinear_rows128_kernel<16, 2, 3>), dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride); break;
         case 164: BIL_LAUNCH(16, 4); break;
         case 321: BIL_LAUNCH(32, 1); break;
         case 322: BIL_LAUNCH(32, 2); break;

@@ -18,6 +18,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    backend = backend or os.environ.get("CGAT_DIST_BACKEND")          # test hook: "gloo" on a 1-GPU box
+    if use_gpu and os.environ.get("CGAT_DIST_SHARE_GPU") == "1":      # test hook: all ranks on cuda:0
+        local = 0
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
