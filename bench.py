@@ -29,7 +29,8 @@ if ROOT not in sys.path:
 
 C_FEA, HEADS, K_NBR, ATOMS = 128, 3, 12, 20
 GRAPHS = 4167                       # -> E = 1 000 080
-MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32 matrix peak (= vector peak)
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input matrix peak (= vector peak)
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
 def make_inputs(graphs, seed, device):
@@ -159,10 +160,21 @@ def main():
         if n_l:
             avg_ms = ms_l / n_l
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "bilinear_rows128_kernel", "achieved": round(ach, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            mode = P.get_bilinear_mode()
+            if mode == "f32":
+                peak, kname = MFMA_F32_PEAK_TFLOPS, "bilinear_rows128_kernel"
+                note = "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32"
+            else:
+                passes = 6 if mode == "bf16x6" else 3
+                peak, kname = MFMA_BF16_PEAK_TFLOPS / passes, "bilinear_rows128_bf16_kernel"
+                note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_32x32x16_bf16 passes per product, fp32 "
+                        f"accumulate (measured fp32-equivalent accuracy): executed MFMA flop = {passes} x algorithmic, so the "
+                        f"roof for ALGORITHMIC flop is the dense bf16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {passes}; the "
+                        f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": None, "launches_per_step": n_l / args.steps, "avg_launch_ms": round(avg_ms, 4),
-                    "flops_per_launch": flops_per_launch}
+                    "flops_per_launch": flops_per_launch, "arithmetic": note}
         shares = {}
         for tag in ("bilinear_rows", "bilinear_wgrad", "gemm_f32"):
             n_t, ms_t = ops.prof_get(tag)
@@ -178,7 +190,7 @@ def main():
             "metric": metric,
             "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
                                     f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention")
                        if args.workload == "layer" else

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "cgat_segment_sum": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, C.c_int64, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
+    "cgat_set_bilinear_mode": (None, [C.c_int32]),
+    "cgat_get_bilinear_mode": (C.c_int32, []),
     "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),

@@ -176,8 +176,10 @@ extern "C" int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, voi
   CGAT_CHECK_ARG(!(!d->b_kmajor && d->b_kgather), "gemm: b_kgather needs b_kmajor == 1");
   return gemm_launch(from_desc(d), ws, ws_bytes, (hipStream_t)stream);
 }
+extern "C" void cgat_set_bilinear_mode(int32_t mode) { bilinear_set_mode(mode); }
+extern "C" int32_t cgat_get_bilinear_mode(void) { return bilinear_mode(); }
 extern "C" size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
-  return ws_round((size_t)NA * NB * NC, 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
+  return ws_round((size_t)NA * NB * NC * 3 / 2 + 4, 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
 }
 extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T,
                                   const float* init, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA,
@@ -187,7 +189,7 @@ extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, i
     return CGAT_ERR_WORKSPACE;
   }
   float* Tq = (float*)ws;
-  size_t off = ws_round((size_t)NA * NB * NC, 4);
+  size_t off = ws_round((size_t)NA * NB * NC * 3 / 2 + 4, 4);
   CGAT_TRY(bilinear_prepare_T(T, Tq, NA, NB, NC, 0, 1, 2, (hipStream_t)stream));
   return bilinear_rows_launch(p, ldp, q, ldq, Tq, init, ldi, out, ldo, rows, NA, NB, NC, (char*)ws + off,
                               ws_bytes - off, (hipStream_t)stream);

@@ -16,6 +16,8 @@
 // is fetched one scalar per 256 MFMAs, T streams through LDS in 16 KB chunks (contiguous
 // 512-byte rows, double-buffered).  MFMA-bound by construction: 32 768 v_mfma_f32_32x32x2_f32
 // per wave per 128 rows, 2*C^3 flop per row.
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -154,6 +156,184 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-bf16 form of the same contraction.  Every fp32 operand x is written x = x1 + x2 + x3 with
+// bf16 pieces (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 significant bits in
+// all) and the product a*b is accumulated in fp32 as a3b1 + a1b3 + a2b2 + a2b1 + a1b2 + a1b1
+// with v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in fp32; the dropped terms are
+// <= 2^-24 relative).  Measured on MI355X (tools/bf16x3_probe.hip): max-norm relative error vs fp64
+// 4.0e-7 / 9.4e-7 / 3.2e-6 at K = 128 / 2048 / 16384, against 4.5e-7 / 1.2e-6 / 4.2e-6 for the
+// f32-input MFMA chain -- the same accuracy, at a matrix-core ceiling of 2500/6 = 417 TFLOP/s of
+// fp32-equivalent work instead of 157.  PASSES = 3 keeps only a2b1 + a1b2 + a1b1 (~4e-6).
+//
+// T arrives pre-split and pre-arranged by bilinear_prepare_T_bf16 in MFMA B-fragment order
+//   Tq[a][s = b/16][piece][cb = c/32][h = (b/8)%2][r = c%32][j = b%8]   (bf16)
+// so a chunk of four k-steps is one contiguous 48 KB block and a B fragment is one ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(float a, __bf16& x1, __bf16& x2, __bf16& x3) {
+  x1 = (__bf16)a;
+  const float r1 = a - (float)x1;
+  x2 = (__bf16)r1;
+  x3 = (__bf16)(r1 - (float)x2);
+}
+
+// WAVES waves per workgroup (32 rows each) share every T chunk of KS k-steps; WAVES = 8 runs two waves
+// per SIMD so that one wave's operand-split VALU work overlaps the other's MFMAs.
+template <int PASSES, int FLUSH, int WAVES, int KS, int ABL = 0>  // ABL (timing only, wrong results): 2 no T loads, 4 no split
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_kernel(
+    const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const uint4* __restrict__ Tq,
+    const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo, int nrows, int NA, int tiles, int asplit,
+    long slab_stride) {
+  constexpr int NT = 64 * WAVES;
+  constexpr int CH16 = KS * 3 * 4 * 2 * 32;   // 16-byte pieces per chunk
+  constexpr int NPC = CH16 / NT;              // pieces per thread per chunk
+  constexpr int NCH = 8 / KS;                 // chunks per `a`
+  static_assert(CH16 % NT == 0 && NPC <= 12 && 8 % KS == 0, "unsupported chunking");
+  __shared__ uint4 Bs[2][CH16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
+  const int row0 = tile * (32 * WAVES) + wave * 32;
+  const int myrow = row0 + r;
+  const long rowc = myrow < nrows ? myrow : nrows - 1;
+  if (asplit > 1) {
+    out += (long)split * slab_stride;
+    if (split > 0) init = nullptr;
+  }
+  // q[row, 16 s + 8 hi + j], s < 8, j < 8 stays in registers: qreg[8 s + j]
+  float qreg[64];
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const float4* qp = reinterpret_cast<const float4*>(q + rowc * ldq + 16 * s8 + 8 * hi);
+    float4 t0 = qp[0], t1 = qp[1];
+    qreg[8 * s8 + 0] = t0.x; qreg[8 * s8 + 1] = t0.y; qreg[8 * s8 + 2] = t0.z; qreg[8 * s8 + 3] = t0.w;
+    qreg[8 * s8 + 4] = t1.x; qreg[8 * s8 + 5] = t1.y; qreg[8 * s8 + 6] = t1.z; qreg[8 * s8 + 7] = t1.w;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float v = 0.f;
+      if (init) {
+        int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+        if (orow < nrows) v = init[(long)orow * ldi + cb * 32 + r];
+      }
+      acc[cb][t] = v;
+    }
+  uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7, pre8, pre9, pre10, pre11;
+#define BF_G1(i_, reg_) if constexpr ((i_) < NPC) reg_ = tb[(i_) * NT];
+#define BF_S1(i_, reg_) if constexpr ((i_) < NPC) lb[(i_) * NT] = reg_;
+#define BF_GLOAD(a_, ch_)                                                                        \
+  {                                                                                              \
+    const uint4* tb = Tq + ((long)(a_) * NCH + (ch_)) * CH16 + tid;                              \
+    BF_G1(0, pre0) BF_G1(1, pre1) BF_G1(2, pre2) BF_G1(3, pre3) BF_G1(4, pre4) BF_G1(5, pre5)    \
+    BF_G1(6, pre6) BF_G1(7, pre7) BF_G1(8, pre8) BF_G1(9, pre9) BF_G1(10, pre10) BF_G1(11, pre11) \
+  }
+#define BF_LSTORE(buf_)                                                                          \
+  {                                                                                              \
+    uint4* lb = &Bs[buf_][tid];                                                                  \
+    BF_S1(0, pre0) BF_S1(1, pre1) BF_S1(2, pre2) BF_S1(3, pre3) BF_S1(4, pre4) BF_S1(5, pre5)    \
+    BF_S1(6, pre6) BF_S1(7, pre7) BF_S1(8, pre8) BF_S1(9, pre9) BF_S1(10, pre10) BF_S1(11, pre11) \
+  }
+  BF_GLOAD(a_beg, 0);
+  BF_LSTORE(0);
+  float pa = p[rowc * ldp + a_beg];
+  __syncthreads();
+  int buf = 0;
+  for (int a2 = a_beg; a2 < a_end; a2 += FLUSH) {
+    f32x16 part[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) part[cb][t] = 0.f;
+    for (int a = a2; a < a2 + FLUSH && a < a_end; ++a) {
+      const int an = (a + 1 < a_end) ? a + 1 : a;
+      const float pa_next = p[rowc * ldp + an];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if constexpr (!(ABL & 2)) { if (ch + 1 < NCH) BF_GLOAD(a, ch + 1) else BF_GLOAD(an, 0); }
+        const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Bs[buf][hi * 32 + r]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          // A fragments: the lane's 8 products p[n,a] * q[n,b], split into three bf16 planes
+          bf16x8 a1, a2v, a3;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if constexpr (ABL & 4) {  // no split arithmetic: reuse one conversion for all three pieces
+              const __bf16 x = (__bf16)(pa + qreg[8 * (KS * ch + ks) + j]);
+              a1[j] = x; a2v[j] = x; a3[j] = x;
+            } else {
+              __bf16 x1, x2, x3;
+              split3_bf16(pa * qreg[8 * (KS * ch + ks) + j], x1, x2, x3);
+              a1[j] = x1; a2v[j] = x2; a3[j] = x3;
+            }
+          }
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            // piece index (ks*3 + piece)*4 + cb, 64 sixteen-byte slots each
+            const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];
+            const bf16x8 b2 = bs[((ks * 3 + 1) * 4 + cb) * 64];
+            if (PASSES >= 6) {
+              const bf16x8 b3 = bs[((ks * 3 + 2) * 4 + cb) * 64];
+              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, part[cb], 0, 0, 0);
+              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, part[cb], 0, 0, 0);
+              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b2, part[cb], 0, 0, 0);
+            }
+            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b1, part[cb], 0, 0, 0);
+            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, part[cb], 0, 0, 0);
+            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, part[cb], 0, 0, 0);
+          }
+        }
+        if constexpr (!(ABL & 2)) BF_LSTORE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+      pa = pa_next;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb];
+  }
+#undef BF_G1
+#undef BF_S1
+#undef BF_GLOAD
+#undef BF_LSTORE
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+      if (orow < nrows) out[(long)orow * ldo + cb * 32 + r] = acc[cb][t];
+    }
+}
+
+// Tq[a][s][piece][cb][h][r][j] (bf16) from a [n0,n1,n2] fp32 tensor viewed with permuted indices
+// (dst dims (n[perm0], n[perm1], n[perm2]) = (NA, 128, 128)).
+__global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int n0, int n1, int n2,
+                                      int perm0, int perm1, int perm2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)n0 * n1 * n2;
+  if (i >= total) return;
+  int dims[3] = {n0, n1, n2};
+  const int d1 = dims[perm1], d2 = dims[perm2];   // 128, 128
+  const int c = (int)(i % d2);
+  const int b = (int)((i / d2) % d1);
+  const int a = (int)(i / ((long)d2 * d1));
+  int idx[3];
+  idx[perm0] = a; idx[perm1] = b; idx[perm2] = c;
+  const float v = src[((long)idx[0] * n1 + idx[1]) * n2 + idx[2]];
+  __bf16 x1, x2, x3;
+  split3_bf16(v, x1, x2, x3);
+  const int s = b >> 4, h = (b >> 3) & 1, j = b & 7, cb = c >> 5, r = c & 31;
+  const long base = (((long)a * 8 + s) * 3) * 4;   // in units of [cb][h][r][j] blocks of 2*32*8
+  const long o1 = ((((base + 0 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
+  const long o2 = ((((base + 1 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
+  const long o3 = ((((base + 2 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
+  dst[o1] = x1; dst[o2] = x2; dst[o3] = x3;
+}
+
 // out[n, c] = sum_s slab[s][n][c]   (fixed order)
 __global__ void slab_sum_rows_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
                                      float* __restrict__ out, long ldo) {
@@ -197,8 +377,8 @@ static bool rows_fast(const float* q, long ldq, int NB, int NC) {
 }
 
 // how many ways to split the `a` range so that tiles*split fills 256 CUs without a ragged last wave
-static int rows_asplit(int nrows) {
-  const int tiles = cdiv(nrows, 128);
+static int rows_asplit(int nrows, int rows_wg) {
+  const int tiles = cdiv(nrows, rows_wg);
   int best = 1;
   double best_eff = 0.0;
   for (int sp = 1; sp <= 4; ++sp) {
@@ -212,11 +392,38 @@ static int rows_asplit(int nrows) {
   return best;
 }
 
+int bilinear_mode();
+// rows per workgroup of the kernel variant that will run (the split-bf16 kernel uses 8 waves = 256 rows)
+static int rows_per_wg() {
+  if (bilinear_mode() == 0) return 128;
+  const char* ab = getenv("CGAT_BF16_VARIANT");
+  const int var = ab ? atoi(ab) : 82;
+  return (var / 10 == 8) ? 256 : 128;
+}
+
 bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
+
+// 0 = f32-input MFMA (exact fp32), 6 = 3-way bf16 split with 6 MFMA passes (fp32-equivalent), 3 = 3 passes
+static int g_bilinear_mode = -1;
+int bilinear_mode() {
+  if (g_bilinear_mode < 0) {
+    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 (default) | bf16x3
+    g_bilinear_mode = 6;
+    if (e && !strcmp(e, "f32")) g_bilinear_mode = 0;
+    if (e && !strcmp(e, "bf16x3")) g_bilinear_mode = 3;
+  }
+  return g_bilinear_mode;
+}
+void bilinear_set_mode(int m) { g_bilinear_mode = (m == 6 || m == 3) ? m : 0; }
+// floats of workspace the prepared T occupies (the bf16 form stores three 2-byte planes)
+size_t bilinear_T_floats(int NA, int NB, int NC) {
+  size_t n = (size_t)NA * NB * NC;
+  return (bilinear_T_interleaved(NB, NC) && bilinear_mode() != 0) ? (n * 3 + 1) / 2 : n;
+}
 
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
   if (!bilinear_T_interleaved(NB, NC)) return 0;
-  int sp = rows_asplit(nrows);
+  int sp = rows_asplit(nrows, rows_per_wg());
   return sp > 1 ? ws_round((size_t)sp * nrows * 128, 4) : 0;
 }
 
@@ -231,7 +438,7 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
       return CGAT_ERR_ARG;
     }
     const int tiles = cdiv(nrows, 128);
-    const int sp = rows_asplit(nrows);
+    const int sp = rows_asplit(nrows, rows_per_wg());
     float* dst = out;
     long dld = ldo, stride = 0;
     if (sp > 1) {
@@ -244,7 +451,23 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
       dld = 128;
       stride = (long)nrows * 128;
     }
-    {
+    if (bilinear_mode() != 0) {
+      CGAT_PROF("bilinear_rows", stream);
+      const char* ab = getenv("CGAT_BF16_VARIANT");   // dev knob: <waves><ks>, e.g. 44, 82, 84
+      const int var = ab ? atoi(ab) : 82;
+      const int rows_wg = (var / 10 == 8) ? 256 : 128;
+      const int tiles2 = cdiv(nrows, rows_wg);
+#define BF_LAUNCH(P_, W_, K_)                                                                                       \
+  hipLaunchKernelGGL((bilinear_rows128_bf16_kernel<P_, 1, W_, K_>), dim3(tiles2 * sp), dim3(64 * W_), 0, stream, p, \
+                     ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride)
+      const bool six = bilinear_mode() == 6;
+      switch (var) {
+        case 44: if (six) BF_LAUNCH(6, 4, 4); else BF_LAUNCH(3, 4, 4); break;
+        case 84: if (six) BF_LAUNCH(6, 8, 4); else BF_LAUNCH(3, 8, 4); break;
+        default: if (six) BF_LAUNCH(6, 8, 2); else BF_LAUNCH(3, 8, 2); break;
+      }
+#undef BF_LAUNCH
+    } else {
       CGAT_PROF("bilinear_rows", stream);
       static int variant = -1;  // dev knob: CGAT_BIL_VARIANT = <JS><FLUSH>, e.g. 161, 162, 322, 324
       if (variant < 0) {
@@ -441,6 +664,160 @@ __global__ void bilinear_wgrad_generic_kernel(const float* __restrict__ p, long 
   out[i] = s;
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-bf16 weight gradient:  out[a,b,c] = sum_n p[n,a] q[n,b] r[n,c]  with the contraction
+// index n on the MFMA k axis.  Pre-passes (once per call, ~0.1 ms at N = 83k):
+//   pT, qT [128][Np]   transposes (Np = N rounded up to 32, zero padded): an A fragment needs 8
+//                      consecutive n for one b
+//   Rq [Np/16][piece][cb][h][r][j]   r split into three bf16 planes in B-fragment order
+// Workgroup = 8 waves = two `a` values (waves 0-3 / 4-7) x 128 b x 128 c; wave = 32 b x 128 c.
+// The A fragment (p*q, 8 values per lane) is split on the fly; six MFMA passes, smallest first.
+// ---------------------------------------------------------------------------------------
+__global__ void transpose_pad_kernel(const float* __restrict__ in, long ld, int rows, int cols, int rows_pad,
+                                     float* __restrict__ out) {  // out[c][n] = in[n][c], n < rows_pad (zeros beyond rows)
+  __shared__ float t[32][33];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8) {
+    int n = n0 + i, c = c0 + tx;
+    t[i][tx] = (n < rows && c < cols) ? in[(long)n * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, n = n0 + tx;
+    if (c < cols && n < rows_pad) out[(long)c * rows_pad + n] = t[tx][i];
+  }
+}
+
+__global__ void split_rows_bf16_kernel(const float* __restrict__ r, long ldr, int rows, int rows_pad,
+                                       __bf16* __restrict__ dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows_pad * 128) return;
+  const int n = (int)(i >> 7), c = (int)(i & 127);
+  const float v = n < rows ? r[(long)n * ldr + c] : 0.f;
+  __bf16 x1, x2, x3;
+  split3_bf16(v, x1, x2, x3);
+  const int s = n >> 4, h = (n >> 3) & 1, j = n & 7, cb = c >> 5, rr = c & 31;
+  const long base = (long)s * 3 * 4;
+  dst[((((base + 0 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x1;
+  dst[((((base + 1 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x2;
+  dst[((((base + 2 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x3;
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const float* __restrict__ pT,
+                                                                        const float* __restrict__ qT,
+                                                                        const uint4* __restrict__ Rq,
+                                                                        float* __restrict__ slab, int rows_pad,
+                                                                        int rows_per_split, int NA) {
+  constexpr int KS = 2;                    // k-steps (16 rows each) per chunk
+  constexpr int RCH = KS * 768;            // 16-byte pieces of Rq per chunk
+  constexpr int QP = 36;                   // pitch (floats) of the q^T tile: conflict-free 16-byte reads
+  __shared__ uint4 Rs[2][RCH];
+  __shared__ __attribute__((aligned(16))) float Qs[2][128 * QP];
+  __shared__ __attribute__((aligned(16))) float Ps[2][2 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int grp = wave >> 2, wb = wave & 3;
+  const int a0 = blockIdx.x * 2, z = blockIdx.y;
+  const int nbeg = z * rows_per_split;
+  const int nend = min(rows_pad, nbeg + rows_per_split);
+  const int nchunks = (nend - nbeg) / 32;   // rows_per_split and rows_pad are multiples of 32
+
+  f32x16 acc[4], tot[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { acc[cb][t] = 0.f; tot[cb][t] = 0.f; }
+
+  uint4 pr0, pr1, pr2;
+  float4 pq0, pq1;
+  float pp = 0.f;
+  const int qb0 = tid >> 3, qn4 = tid & 7;                 // q^T pieces: rows qb0 and qb0 + 64
+#define WG_GLOAD(n0_)                                                                   \
+  {                                                                                     \
+    const uint4* rb = Rq + (long)((n0_) >> 4) * 768 + tid;                              \
+    pr0 = rb[0]; pr1 = rb[512]; pr2 = rb[1024];                                         \
+    pq0 = *reinterpret_cast<const float4*>(qT + (long)qb0 * rows_pad + (n0_) + 4 * qn4);        \
+    pq1 = *reinterpret_cast<const float4*>(qT + (long)(qb0 + 64) * rows_pad + (n0_) + 4 * qn4); \
+    if (tid < 64) {                                                                     \
+      const int aa = a0 + (tid >> 5);                                                   \
+      pp = aa < NA ? pT[(long)aa * rows_pad + (n0_) + (tid & 31)] : 0.f;                \
+    }                                                                                   \
+  }
+#define WG_LSTORE(buf_)                                                                 \
+  {                                                                                     \
+    uint4* lb = &Rs[buf_][tid];                                                         \
+    lb[0] = pr0; lb[512] = pr1; lb[1024] = pr2;                                         \
+    *reinterpret_cast<float4*>(&Qs[buf_][qb0 * QP + 4 * qn4]) = pq0;                    \
+    *reinterpret_cast<float4*>(&Qs[buf_][(qb0 + 64) * QP + 4 * qn4]) = pq1;             \
+    if (tid < 64) Ps[buf_][tid] = pp;                                                   \
+  }
+  if (nchunks > 0) {
+    WG_GLOAD(nbeg);
+    WG_LSTORE(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) WG_GLOAD(nbeg + (c + 1) * 32);
+    if ((c & 15) == 0 && c > 0) {   // two-level summation over the long row dimension (512-row partials)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        tot[cb] += acc[cb];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[cb][t] = 0.f;
+      }
+    }
+    const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Rs[cur][hi * 32 + r]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4* q4 = reinterpret_cast<const float4*>(&Qs[cur][(wb * 32 + r) * QP + ks * 16 + 8 * hi]);
+      const float4* p4 = reinterpret_cast<const float4*>(&Ps[cur][grp * 32 + ks * 16 + 8 * hi]);
+      const float4 qa = q4[0], qb = q4[1], pa = p4[0], pb = p4[1];
+      const float av[8] = {pa.x * qa.x, pa.y * qa.y, pa.z * qa.z, pa.w * qa.w,
+                           pb.x * qb.x, pb.y * qb.y, pb.z * qb.z, pb.w * qb.w};
+      bf16x8 a1, a2v, a3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 x1, x2, x3;
+        split3_bf16(av[j], x1, x2, x3);
+        a1[j] = x1; a2v[j] = x2; a3[j] = x3;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];
+        const bf16x8 b2 = bs[((ks * 3 + 1) * 4 + cb) * 64];
+        if (PASSES >= 6) {
+          const bf16x8 b3 = bs[((ks * 3 + 2) * 4 + cb) * 64];
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b2, acc[cb], 0, 0, 0);
+        }
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b1, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[cb], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) WG_LSTORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef WG_GLOAD
+#undef WG_LSTORE
+  const int a = a0 + grp;
+  if (a >= NA) return;
+  float* o = slab + ((long)z * NA + a) * 128 * 128;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    acc[cb] += tot[cb];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int b = wb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hi;
+      o[(long)b * 128 + cb * 32 + r] = acc[cb][t];
+    }
+  }
+}
+
 static int wgrad_splits(int nrows, int NA) {
   int s = cdiv(512, NA);                 // aim at >= 2 workgroups per CU
   int maxs = nrows / 256;                // at least 8 chunks of 32 rows per split
@@ -454,13 +831,65 @@ static bool wgrad_fast(const float* q, long ldq, const float* r, long ldr, int N
          (((uintptr_t)r) & 15) == 0 && !force_generic();
 }
 
+static int wgrad_bf16_splits(int NA) { return cdiv(256, cdiv(NA, 2)); }   // one 512-thread workgroup per CU
+static size_t wgrad_bf16_ws(int nrows, int NA, size_t* o_pT, size_t* o_qT, size_t* o_Rq, size_t* o_slab) {
+  const size_t np = (size_t)cdiv(nrows, 32) * 32;
+  size_t off = 0;
+  *o_pT = off; off += ws_round(np * 128, 4);
+  *o_qT = off; off += ws_round(np * 128, 4);
+  *o_Rq = off; off += ws_round(np * 128 * 3, 2);
+  *o_slab = off; off += ws_round((size_t)wgrad_bf16_splits(NA) * NA * 128 * 128, 4);
+  return off;
+}
+
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
-  if (NB == 128 && NC == 128) return ws_round((size_t)wgrad_splits(nrows, NA) * NA * NB * NC, 4);
+  if (NB == 128 && NC == 128) {
+    size_t a, b, c, d;
+    size_t bf = wgrad_bf16_ws(nrows, NA, &a, &b, &c, &d);
+    size_t f32 = ws_round((size_t)wgrad_splits(nrows, NA) * NA * NB * NC, 4);
+    return bf > f32 ? bf : f32;
+  }
   return 0;
 }
 
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (wgrad_fast(q, ldq, r, ldr, NB, NC) && bilinear_mode() != 0 && nrows > 0) {
+    size_t o_pT, o_qT, o_Rq, o_slab;
+    const size_t need = wgrad_bf16_ws(nrows, NA, &o_pT, &o_qT, &o_Rq, &o_slab);
+    if (!ws || ws_bytes < need) {
+      cgat_set_error("bilinear_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+      return CGAT_ERR_WORKSPACE;
+    }
+    const int np = cdiv(nrows, 32) * 32;
+    float* pT = (float*)((char*)ws + o_pT);
+    float* qT = (float*)((char*)ws + o_qT);
+    __bf16* Rq = (__bf16*)((char*)ws + o_Rq);
+    float* slab = (float*)((char*)ws + o_slab);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, cdiv(NA, 32)), dim3(256), 0, stream, p, ldp, nrows, NA, np, pT);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, 4), dim3(256), 0, stream, q, ldq, nrows, 128, np, qT);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(split_rows_bf16_kernel, dim3(cdiv((long)np * 128, 256)), dim3(256), 0, stream, r, ldr, nrows, np, Rq);
+    CGAT_LAUNCH_CHECK();
+    int splits = wgrad_bf16_splits(NA);
+    int rps = cdiv(np / 32, splits) * 32;
+    splits = cdiv(np, rps);
+    {
+      CGAT_PROF("bilinear_wgrad", stream);
+      if (bilinear_mode() == 6)
+        hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<6>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
+                           (const uint4*)Rq, slab, np, rps, NA);
+      else
+        hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<3>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
+                           (const uint4*)Rq, slab, np, rps, NA);
+    }
+    CGAT_LAUNCH_CHECK();
+    long n = (long)NA * NB * NC;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const float*)slab, splits, n, out);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   if (wgrad_fast(q, ldq, r, ldr, NB, NC)) {
     int splits = wgrad_splits(nrows, NA);
     size_t need = ws_round((size_t)splits * NA * NB * NC, 4);
@@ -523,6 +952,13 @@ int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int pe
 int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                        hipStream_t stream) {
   int dims[3] = {n0, n1, n2};
+  if (bilinear_T_interleaved(dims[perm1], dims[perm2]) && bilinear_mode() != 0) {
+    long total = (long)n0 * n1 * n2;
+    hipLaunchKernelGGL(prepare_T_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, n0, n1, n2,
+                       perm0, perm1, perm2);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   return permute3_launch(src, dst, n0, n1, n2, perm0, perm1, perm2,
                          bilinear_T_interleaved(dims[perm1], dims[perm2]) ? 1 : 0, stream);
 }

@@ -53,6 +53,9 @@ size_t gemm_ws_bytes(const GemmParams& p);
 // out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T3[a,b,c], with T = bilinear_prepare_T(T3 source):
 // a permuted copy whose columns are interleaved for the MFMA kernel when NB == NC == 128.
 bool bilinear_T_interleaved(int NB, int NC);
+int bilinear_mode();               // 0 f32 MFMA, 6 / 3: split-bf16 passes
+void bilinear_set_mode(int m);
+size_t bilinear_T_floats(int NA, int NB, int NC);  // workspace floats of the prepared T
 int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                        hipStream_t stream);
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);

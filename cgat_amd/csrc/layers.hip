@@ -520,7 +520,7 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
                              float* saved) {
   const int W = p->W;
   const size_t WW = (size_t)W * W;
-  float* Tp = c.take<float>(WW * W);
+  float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
   c.seal();
   HnetSaved sv = hnet_saved(saved, rows, p);
   const float* hin = h0;
@@ -567,7 +567,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const int W = p->W;
   const size_t WW = (size_t)W * W;
   const size_t rw = (size_t)rows * W;
-  float* Tp = c.take<float>(WW * W);
+  float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
   float* g_hin = c.take<float>(rw);
   float* g_u = c.take<float>(rw);
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};

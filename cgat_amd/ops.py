@@ -389,6 +389,21 @@ def segment_sum(x, index_plan, index):
     return SegmentSumFn.apply(x.index_select(0, perm), index_plan.rowptr, index.index_select(0, perm))
 
 
+_MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3}
+
+
+def set_bilinear_mode(mode):
+    """Arithmetic of the width-128 hypernetwork contractions: "bf16x6" (default; operands split into
+    three bf16 pieces, six bf16-MFMA passes, fp32 accumulate -- measured fp32-equivalent), "f32"
+    (f32-input MFMA, exact fp32 fmaf chains) or "bf16x3" (three passes, ~4e-6 relative)."""
+    lib.cgat_set_bilinear_mode(_MODES[mode])
+
+
+def get_bilinear_mode():
+    m = lib.cgat_get_bilinear_mode()
+    return {v: k for k, v in _MODES.items()}[m]
+
+
 def prof_enable(on=True):
     lib.cgat_prof_enable(1 if on else 0)
 

@@ -193,6 +193,11 @@ size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, 
 int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T, const float* init,
                        int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA, int32_t NB, int32_t NC,
                        void* ws, size_t ws_bytes, void* stream);
+/* Arithmetic of the width-128 trilinear contractions: 0 = f32-input MFMA (exact fp32 fmaf chains, default),
+ * 6 = operands split into three bf16 pieces, six bf16-MFMA passes with fp32 accumulation (measured
+ * fp32-equivalent accuracy, 2.67x higher matrix-core ceiling), 3 = three passes (~4e-6 relative). */
+void cgat_set_bilinear_mode(int32_t mode);
+int32_t cgat_get_bilinear_mode(void);
 /* out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c] */
 size_t cgat_bilinear_wgrad_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC);
 int cgat_bilinear_wgrad(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* r, int64_t ldr,

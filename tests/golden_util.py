@@ -68,9 +68,10 @@ def check_case(fname, cname, case, *, device="cpu", tol=1e-4, grad_tol=None, rep
             want = ref["gpn." + name[3:]]
             got = recipe.grad_probe(g)
             n = g.numel()
-            # probe entries: sum, L2, max, ramp-dot, first 8 values -> convert each to a per-element-scale error
-            abs_err = max(abs(got[0] - want[0]) / np.sqrt(n), abs(got[1] - want[1]) / np.sqrt(n), abs(got[2] - want[2]),
-                          abs(got[3] - want[3]) / np.sqrt(n), np.abs(got[4:] - want[4:]).max())
+            # probe entries: sum, L2, max, ramp-dot, first 8 values -> each converted to a rigorous lower bound
+            # of the max element error: |sum e| <= n max|e|, |ramp . e| <= n max|e|, | ||a|| - ||b|| | <= sqrt(n) max|e|
+            abs_err = max(abs(got[0] - want[0]) / n, abs(got[1] - want[1]) / np.sqrt(n), abs(got[2] - want[2]),
+                          abs(got[3] - want[3]) / n, np.abs(got[4:] - want[4:]).max())
         allowed = max(grad_tol * ref_max, NOISE_MULT * nf_abs, 1e-6 * case_scale)
         errs[name] = abs_err / max(ref_max, 1e-300)
         if report is not None:
