@@ -243,7 +243,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_k
   float pa = p[rowc * ldp + a_beg];
   __syncthreads();
   int buf = 0;
+  // The bf16 MFMA's internal alignment drops low bits floor-wise (measured: a sign-independent bias of
+  // about -5e-11 of the running sum per accumulation step, tools/bf16x3_probe.hip; the f32-input MFMA
+  // rounds to nearest).  Successive flush groups therefore accumulate +a*b and -a*b alternately and
+  // are added / subtracted at the flush: the per-group biases cancel instead of adding up.
   for (int a2 = a_beg; a2 < a_end; a2 += FLUSH) {
+    const float sgn = (((a2 - a_beg) / FLUSH) & 1) ? -1.f : 1.f;
     f32x16 part[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_k
     for (int a = a2; a < a2 + FLUSH && a < a_end; ++a) {
       const int an = (a + 1 < a_end) ? a + 1 : a;
       const float pa_next = p[rowc * ldp + an];
+      const float pas = sgn * pa;
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         if constexpr (!(ABL & 2)) { if (ch + 1 < NCH) BF_GLOAD(a, ch + 1) else BF_GLOAD(an, 0); }
@@ -263,11 +269,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_k
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if constexpr (ABL & 4) {  // no split arithmetic: reuse one conversion for all three pieces
-              const __bf16 x = (__bf16)(pa + qreg[8 * (KS * ch + ks) + j]);
+              const __bf16 x = (__bf16)(pas + qreg[8 * (KS * ch + ks) + j]);
               a1[j] = x; a2v[j] = x; a3[j] = x;
             } else {
               __bf16 x1, x2, x3;
-              split3_bf16(pa * qreg[8 * (KS * ch + ks) + j], x1, x2, x3);
+              split3_bf16(pas * qreg[8 * (KS * ch + ks) + j], x1, x2, x3);
               a1[j] = x1; a2v[j] = x2; a3[j] = x3;
             }
           }
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_k
       pa = pa_next;
     }
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb];
+    for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb] * sgn;
   }
 #undef BF_G1
 #undef BF_S1
@@ -397,8 +403,8 @@ int bilinear_mode();
 static int rows_per_wg() {
   if (bilinear_mode() == 0) return 128;
   const char* ab = getenv("CGAT_BF16_VARIANT");
-  const int var = ab ? atoi(ab) : 82;
-  return (var / 10 == 8) ? 256 : 128;
+  const int var = ab ? atoi(ab) : 822;
+  return (var / 10 == 8 || var / 100 == 8) ? 256 : 128;
 }
 
 bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
@@ -453,20 +459,24 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
     }
     if (bilinear_mode() != 0) {
       CGAT_PROF("bilinear_rows", stream);
-      const char* ab = getenv("CGAT_BF16_VARIANT");   // dev knob: <waves><ks>, e.g. 44, 82, 84
-      const int var = ab ? atoi(ab) : 82;
-      const int rows_wg = (var / 10 == 8) ? 256 : 128;
+      const char* ab = getenv("CGAT_BF16_VARIANT");   // dev knob: <waves><ks>[<flush>], e.g. 44, 82, 84, 822 (default), 824
+      const int var = ab ? atoi(ab) : 822;
+      const int rows_wg = (var / 10 == 8 || var / 100 == 8) ? 256 : 128;
       const int tiles2 = cdiv(nrows, rows_wg);
-#define BF_LAUNCH(P_, W_, K_)                                                                                       \
-  hipLaunchKernelGGL((bilinear_rows128_bf16_kernel<P_, 1, W_, K_>), dim3(tiles2 * sp), dim3(64 * W_), 0, stream, p, \
+#define BF_LAUNCHF(P_, F_, W_, K_)                                                                                   \
+  hipLaunchKernelGGL((bilinear_rows128_bf16_kernel<P_, F_, W_, K_>), dim3(tiles2 * sp), dim3(64 * W_), 0, stream, p, \
                      ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride)
+#define BF_LAUNCH(P_, W_, K_) BF_LAUNCHF(P_, 1, W_, K_)
       const bool six = bilinear_mode() == 6;
       switch (var) {
         case 44: if (six) BF_LAUNCH(6, 4, 4); else BF_LAUNCH(3, 4, 4); break;
+        case 822: if (six) BF_LAUNCHF(6, 2, 8, 2); else BF_LAUNCHF(3, 2, 8, 2); break;
+        case 824: if (six) BF_LAUNCHF(6, 4, 8, 2); else BF_LAUNCHF(3, 4, 8, 2); break;
         case 84: if (six) BF_LAUNCH(6, 8, 4); else BF_LAUNCH(3, 8, 4); break;
         default: if (six) BF_LAUNCH(6, 8, 2); else BF_LAUNCH(3, 8, 2); break;
       }
 #undef BF_LAUNCH
+#undef BF_LAUNCHF
     } else {
       CGAT_PROF("bilinear_rows", stream);
       static int variant = -1;  // dev knob: CGAT_BIL_VARIANT = <JS><FLUSH>, e.g. 161, 162, 322, 324
@@ -743,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
     if (tid < 64) {                                                                     \
       const int aa = a0 + (tid >> 5);                                                   \
       pp = aa < NA ? pT[(long)aa * rows_pad + (n0_) + (tid & 31)] : 0.f;                \
+      if (((((n0_) - nbeg) >> 5) >> 4) & 1) pp = -pp; /* odd flush groups accumulate -p*q*r */ \
     }                                                                                   \
   }
 #define WG_LSTORE(buf_)                                                                 \
@@ -761,10 +772,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
   for (int c = 0; c < nchunks; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunks) WG_GLOAD(nbeg + (c + 1) * 32);
-    if ((c & 15) == 0 && c > 0) {   // two-level summation over the long row dimension (512-row partials)
+    if ((c & 15) == 0 && c > 0) {   // two-level summation over the long row dimension (512-row partials);
+      // groups alternate in sign (see bilinear_rows128_bf16_kernel: cancels the bf16 MFMA's floor bias)
+      const float sg = (((c >> 4) - 1) & 1) ? -1.f : 1.f;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        tot[cb] += acc[cb];
+        tot[cb] += acc[cb] * sg;
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[cb][t] = 0.f;
       }
@@ -807,9 +820,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
   const int a = a0 + grp;
   if (a >= NA) return;
   float* o = slab + ((long)z * NA + a) * 128 * 128;
+  const float sg_last = (nchunks > 0 && (((nchunks - 1) >> 4) & 1)) ? -1.f : 1.f;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    acc[cb] += tot[cb];
+    acc[cb] = acc[cb] * sg_last + tot[cb];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int b = wb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hi;

@@ -44,8 +44,12 @@ struct TileLoader {
   bool vec;          // 16-byte loads legal
   long blk;          // 128-wide column-block stride (0 = plain layout)
   long roff[4];      // !KM: precomputed row offsets (elements), -1 = out of range
+  bool fast;         // the whole 128-row tile is in range and 16-byte loads are legal: no per-piece predicates
+  long coff;         // KM: precomputed offset of this thread's 4 columns
 
   __device__ void init(int tid) {
+    fast = vec && (r0 + 128 <= R);
+    coff = 0;
     if (!KM) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -58,10 +62,28 @@ struct TileLoader {
           roff[i] = -1;
         }
       }
+    } else {
+      const int r = r0 + 4 * (tid & 31);
+      coff = blk ? (long)(r >> 7) * blk + (r & 127) : (long)r;
     }
   }
 
   __device__ void load(int tid, int k0, int kend, float4 (&v)[4]) const {
+    if (fast && k0 + 32 <= kend) {  // wave-uniform: interior tile and chunk, straight 16-byte loads
+      if (!KM) {
+        const long ko = (blk ? (long)(k0 >> 7) * blk + (k0 & 127) : (long)k0) + 4 * (tid & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(base + roff[i] + ko);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = k0 + (tid >> 5) + 8 * i;
+          const long krow = kgather ? (long)kgather[k] : (long)k;
+          v[i] = *reinterpret_cast<const float4*>(base + krow * ld + coff);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int f = tid + 256 * i;
@@ -120,7 +142,7 @@ struct TileLoader {
   }
 };
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int ABL = 0>  // ABL: timing-only ablations (1 no barrier, 2 no global loads, 4 no LDS stores)
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int PA = AKM ? 132 : 129;
   constexpr int PB = BKM ? 132 : 129;
@@ -165,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   const int kbeg = z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
-  TileLoader<AKM> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, p.a_block, {0, 0, 0, 0}};
-  TileLoader<BKM> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, 0, {0, 0, 0, 0}};
+  TileLoader<AKM> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, p.a_block, {0, 0, 0, 0}, false, 0};
+  TileLoader<BKM> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, 0, {0, 0, 0, 0}, false, 0};
   la.init(tid);
   lb.init(tid);
 
@@ -213,9 +235,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
           for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
         }
     }
-    if (c + 1 < nchunks) {
-      la.load(tid, CHUNK_K(c + 1), kend, ra);
-      lb.load(tid, CHUNK_K(c + 1), kend, rb);
+    if constexpr (!(ABL & 2)) {
+      if (c + 1 < nchunks) {
+        la.load(tid, CHUNK_K(c + 1), kend, ra);
+        lb.load(tid, CHUNK_K(c + 1), kend, rb);
+      }
     }
     const float* as = As[cur] + hi * PA + wm + r;
     const float* bs = Bs[cur] + hi * PB + wn + r;
@@ -228,11 +252,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (c + 1 < nchunks) {
-      la.template store<PA>(tid, As[cur ^ 1], ra);
-      lb.template store<PB>(tid, Bs[cur ^ 1], rb);
+    if constexpr (!(ABL & 4)) {
+      if (c + 1 < nchunks) {
+        la.template store<PA>(tid, As[cur ^ 1], ra);
+        lb.template store<PB>(tid, Bs[cur ^ 1], rb);
+      }
     }
-    __syncthreads();
+    if constexpr (!(ABL & 1)) __syncthreads();
   }
 
 #undef CHUNK_K
@@ -424,7 +450,14 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   dim3 grid(8 * inner * cdiv(outer, 8));
   {
     CGAT_PROF("gemm_f32", stream);
-    if (!p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    const char* ab = getenv("CGAT_GEMM_ABL");
+    const int abl = ab ? atoi(ab) : 0;
+    if (abl == 1 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+    else if (abl == 2 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, stream, p);
+    else if (abl == 4 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4>), grid, dim3(256), 0, stream, p);
+    else if (abl == 6 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 6>), grid, dim3(256), 0, stream, p);
+    else if (abl == 7 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 7>), grid, dim3(256), 0, stream, p);
+    else if (!p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, p);
     else if (!p.a_kmajor && p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, p);
     else if (p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, p);

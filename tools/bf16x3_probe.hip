@@ -53,8 +53,9 @@ int main() {
   for (int K : {128, 2048, 16384}) {
     std::vector<float> A(32 * K), B(K * 32);
     srand(1);
-    for (auto& v : A) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
-    for (auto& v : B) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+    const bool positive = getenv("PROBE_POSITIVE") != nullptr;
+    for (auto& v : A) v = positive ? 0.25f + rand() / (float)RAND_MAX : (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+    for (auto& v : B) v = positive ? (getenv("PROBE_NEGATIVE") ? -1.f : 1.f) * (0.25f + rand() / (float)RAND_MAX) : (rand() / (float)RAND_MAX - 0.5f) * 2.f;
     std::vector<double> ref(1024, 0.0), absref(1024, 0.0);
     for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) for (int k = 0; k < K; ++k) {
       ref[i * 32 + j] += (double)A[i * K + k] * B[k * 32 + j];
@@ -66,12 +67,14 @@ int main() {
     std::vector<float> C(1024);
     auto report = [&](const char* name) {
       (void)hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);
-      double maxabs = 0, maxerr = 0, maxrel_sumabs = 0;
+      double maxabs = 0, maxerr = 0, maxrel_sumabs = 0, meanrel = 0;
       for (int i = 0; i < 1024; ++i) {
         maxabs = fmax(maxabs, fabs(ref[i])); maxerr = fmax(maxerr, fabs(C[i] - ref[i]));
         maxrel_sumabs = fmax(maxrel_sumabs, fabs(C[i] - ref[i]) / absref[i]);
+        meanrel += (C[i] - ref[i]) / absref[i] / 1024.0;
       }
-      printf("K=%6d %-22s max-norm rel err %.3e   err / sum|a*b| %.3e\n", K, name, maxerr / maxabs, maxrel_sumabs);
+      printf("K=%6d %-22s max-norm rel err %.3e   err / sum|a*b| %.3e   MEAN signed err / sum|a*b| %+.3e\n", K, name,
+             maxerr / maxabs, maxrel_sumabs, meanrel);
     };
     k_f32<<<1, 64>>>(dA, dB, dC, K); (void)hipDeviceSynchronize(); report("fp32 mfma 32x32x2");
     for (int np : {1, 3, 6}) {

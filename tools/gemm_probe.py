@@ -70,3 +70,9 @@ run("trunk layer [N,128]x[128,128] tanh", 2.0 * N * 128 * 128, M=N, N=128, K=128
 run("node proj [N,128]x[128,1536]", 2.0 * N * 128 * W2, M=N, N=W2, K=128, A=x, lda=128, B=Wcat, ldb=D, C=Pi, ldc=W2)
 A4 = torch.randn(8192, 4096, generator=g).to(dev); B4 = torch.randn(4096, 4096, generator=g).to(dev); C4 = torch.empty(8192, 4096, device=dev)
 run("square-ish 8192x4096x4096 NT", 2.0 * 8192 * 4096 * 4096, M=8192, N=4096, K=4096, A=A4, lda=4096, B=B4, ldb=4096, C=C4, ldc=4096)
+
+import os
+for abl in ("0", "1", "2", "4", "6", "7"):
+    os.environ["CGAT_GEMM_ABL"] = abl
+    run(f"square NT, ablation {abl} (1 no barrier, 2 no gloads, 4 no LDS stores)", 2.0 * 8192 * 4096 * 4096, M=8192, N=4096, K=4096, A=A4, lda=4096, B=B4, ldb=4096, C=C4, ldc=4096)
+os.environ["CGAT_GEMM_ABL"] = "0"
