@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mfma_bf16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -157,187 +158,264 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------
-// Split-bf16 form of the same contraction.  Every fp32 operand x is written x = x1 + x2 + x3 with
-// bf16 pieces (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 significant bits in
-// all) and the product a*b is accumulated in fp32 as a3b1 + a1b3 + a2b2 + a2b1 + a1b2 + a1b1
-// with v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in fp32; the dropped terms are
-// <= 2^-24 relative).  Measured on MI355X (tools/bf16x3_probe.hip): max-norm relative error vs fp64
-// 4.0e-7 / 9.4e-7 / 3.2e-6 at K = 128 / 2048 / 16384, against 4.5e-7 / 1.2e-6 / 4.2e-6 for the
-// f32-input MFMA chain -- the same accuracy, at a matrix-core ceiling of 2500/6 = 417 TFLOP/s of
-// fp32-equivalent work instead of 157.  PASSES = 3 keeps only a2b1 + a1b2 + a1b1 (~4e-6).
+// Split-bf16 form of the same contraction (the default arithmetic, "bf16x6").  Every fp32 operand x is
+// written x = x1 + x2 + x3 with bf16 pieces (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
+// 24 significant bits in all) and a product a*b is accumulated in fp32 as
+//     a3b1 + a1b3 + a2b2 + a2b1 + a1b2 + a1b1        (six bf16 MFMA passes, smallest terms first);
+// products of bf16 pairs are exact in fp32 and the dropped terms are <= 2^-24 relative.  Measured on
+// MI355X (tools/bf16x3_probe.hip): max-norm relative error vs fp64 4.0e-7 / 9.4e-7 / 3.2e-6 at K = 128 /
+// 2048 / 16384, against 4.5e-7 / 1.2e-6 / 4.2e-6 for the f32-input MFMA chain -- the same accuracy, at
+// a matrix-core ceiling of 2500/6 = 417 TFLOP/s of fp32-equivalent work instead of 157.  PASSES = 3
+// keeps only a2b1 + a1b2 + a1b1 (~3e-6; mode "bf16x3", never the default).
 //
-// T arrives pre-split and pre-arranged by bilinear_prepare_T_bf16 in MFMA B-fragment order
-//   Tq[a][s = b/16][piece][cb = c/32][h = (b/8)%2][r = c%32][j = b%8]   (bf16)
-// so a chunk of four k-steps is one contiguous 48 KB block and a B fragment is one ds_read_b128.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The bf16 MFMA's accumulator alignment drops low bits floor-wise (measured: a sign-independent bias of
+// about -5e-11 of the running sum per accumulation step; the f32-input MFMA rounds to nearest), which
+// over 16 384-term sums is coherent across rows.  Consecutive partial sums are therefore accumulated
+// with opposite product signs ((-1)^a folded into the prepared T and into p) so the biases cancel.
+//
+// "Scale-after" evaluation order:
+//     out[n,c] = init[n,c] + sum_a p[n,a] * ( sum_b q[n,b] T[a,b,c] )
+// The inner sum is a K = 128 GEMM whose row operand q never changes: its three bf16 planes are split
+// ONCE and stay in 96 VGPRs for the whole kernel, T arrives pre-split, so the loop holds no operand
+// arithmetic at all -- LDS fragment reads and MFMAs only.  The 128*6 exact products of one `a` go into
+// fresh fp32 accumulators (the inner level of the two-level summation), which are then scaled by
+// p[n,a] and added to the totals (one v_fma per 3 MFMAs).  The product is computed transposed
+// (D[c,n]: T fragment = the MFMA's A operand, q fragment = B) so that every accumulator register of a
+// lane belongs to one of its two rows and p[n,a] is a per-lane scalar.
+//
+// T reaches LDS by LDS-DMA (global_load_lds: no staging VGPRs, no ds_write) into a 4-slot ring of 24-KB
+// chunks with the loads of chunk i+3 in flight while chunk i is consumed; one raw s_barrier per chunk
+// behind a counted vmcnt.  The p column of each `a` is staged the same way two `a` ahead.  Fragments
+// are read one 12-MFMA group ahead -- across the barrier too, because chunk i+1 was already retired
+// and published by the barrier that ended chunk i-1 -- so a wave never waits on LDS latency with an
+// empty matrix pipe.
+//   RAW: chunk j is issued in iteration j-3, retired by this wave's `vmcnt(3)` at the end of iteration
+//        j-2, published by the barrier that follows; first read in iteration j-1 (group-0 prefetch).
+//   WAR: chunk j+3 overwrites the slot of chunk j-1, all of whose reads were consumed by MFMAs issued
+//        before the barrier that ended iteration j-1; the glds is issued after that barrier.
+// The LDS-DMA is issued from inline asm: hipcc would otherwise wait vmcnt(0) before every ds_read that
+// follows a glds builtin (it cannot tell ring slots apart).  No other vector-memory instruction may
+// appear in the loop, so the counts are exact: per iteration 3 T loads, preceded (chunk 0 of each `a`)
+// by one p load.
+//
+// MFMA shape: v_mfma_f32_16x16x32_bf16.  Same flop per cycle as 32x32x16, but under the chip's power
+// management it sustains a higher clock (MI355X_MICROARCH.md "DVFS give-back" item 7); measured here
+// on the same kernel structure: 1.39 ms vs 1.54 ms per 83 340-row launch.
+// Wave tile 32 rows x 128 columns = 2 row blocks x 8 column blocks of 16; a lane owns rows
+// n = (lane & 15) and 16 + (lane & 15) and, per column block, columns 4 (lane >> 4) + 0..3.
+// T layout (prepare_T_bf16_kernel), holding (-1)^a T[a]:
+//   Tq[a][half = c/64][kh = b/64][s2 = (b/32)%2][piece][cb = (c%64)/16][kg = (b%32)/8][i = c%16][j = b%8]
+// one chunk = (a, half, kh) = 2 k-steps x 3 planes x 4 column blocks x 1 KB; a fragment is one ds_read_b128.
 
-__device__ __forceinline__ void split3_bf16(float a, __bf16& x1, __bf16& x2, __bf16& x3) {
-  x1 = (__bf16)a;
-  const float r1 = a - (float)x1;
-  x2 = (__bf16)r1;
-  x3 = (__bf16)(r1 - (float)x2);
-}
-
-// WAVES waves per workgroup (32 rows each) share every T chunk of KS k-steps; WAVES = 8 runs two waves
-// per SIMD so that one wave's operand-split VALU work overlaps the other's MFMAs.
-template <int PASSES, int FLUSH, int WAVES, int KS, int ABL = 0>  // ABL (timing only, wrong results): 2 no T loads, 4 no split
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void bilinear_rows128_bf16_kernel(
+template <int PASSES, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const uint4* __restrict__ Tq,
     const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo, int nrows, int NA, int tiles, int asplit,
-    long slab_stride) {
-  constexpr int NT = 64 * WAVES;
-  constexpr int CH16 = KS * 3 * 4 * 2 * 32;   // 16-byte pieces per chunk
-  constexpr int NPC = CH16 / NT;              // pieces per thread per chunk
-  constexpr int NCH = 8 / KS;                 // chunks per `a`
-  static_assert(CH16 % NT == 0 && NPC <= 12 && 8 % KS == 0, "unsupported chunking");
-  __shared__ uint4 Bs[2][CH16];
+    long slab_stride, int vec_io) {
+  constexpr int CH16 = 2 * 3 * 4 * 64;          // 16-byte pieces per chunk = 24 KB
+  constexpr int PST = 8 * 64;
+  __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hi = lane >> 5;
+  const int n16 = lane & 15, kg = lane >> 4;
   const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
-  const int row0 = tile * (32 * WAVES) + wave * 32;
-  const int myrow = row0 + r;
-  const long rowc = myrow < nrows ? myrow : nrows - 1;
+  const int row_w = tile * 256 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;           // the lane's two output rows
+  const long rowc_a = row_a < nrows ? row_a : nrows - 1, rowc_b = row_b < nrows ? row_b : nrows - 1;
+  const int row_st = row_w + (lane & 31);                            // the row whose p this lane stages
+  const long rowc_st = row_st < nrows ? row_st : nrows - 1;
   if (asplit > 1) {
     out += (long)split * slab_stride;
     if (split > 0) init = nullptr;
   }
-  // q[row, 16 s + 8 hi + j], s < 8, j < 8 stays in registers: qreg[8 s + j]
-  float qreg[64];
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
+  p += (long)tile * 256 * ldp;                                       // scalar tile base + 32-bit lane offsets
+  const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 256) * ldp * 4);
+  const unsigned t_off = (unsigned)tid * 16;
+  const long last_chunk = (long)a_end * 4 - 1;
+
+  // q[row, 32 s + 8 kg + j] for both row blocks as three bf16 planes: qf[plane][2 s + nb]
+  bf16x8 q1[8], q2[8], q3[8];
 #pragma unroll
-  for (int s8 = 0; s8 < 8; ++s8) {
-    const float4* qp = reinterpret_cast<const float4*>(q + rowc * ldq + 16 * s8 + 8 * hi);
-    float4 t0 = qp[0], t1 = qp[1];
-    qreg[8 * s8 + 0] = t0.x; qreg[8 * s8 + 1] = t0.y; qreg[8 * s8 + 2] = t0.z; qreg[8 * s8 + 3] = t0.w;
-    qreg[8 * s8 + 4] = t1.x; qreg[8 * s8 + 5] = t1.y; qreg[8 * s8 + 6] = t1.z; qreg[8 * s8 + 7] = t1.w;
-  }
-  f32x16 acc[4];
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+    for (int nb = 0; nb < 2; ++nb) {
+      const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+      const float4 t0 = qp[0], t1 = qp[1];
+      const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      float v = 0.f;
-      if (init) {
-        int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
-        if (orow < nrows) v = init[(long)orow * ldi + cb * 32 + r];
+      for (int j = 0; j < 8; ++j) {
+        __bf16 x1, x2, x3;
+        split3_bf16(v[j], x1, x2, x3);
+        q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
       }
-      acc[cb][t] = v;
     }
-  uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7, pre8, pre9, pre10, pre11;
-#define BF_G1(i_, reg_) if constexpr ((i_) < NPC) reg_ = tb[(i_) * NT];
-#define BF_S1(i_, reg_) if constexpr ((i_) < NPC) lb[(i_) * NT] = reg_;
-#define BF_GLOAD(a_, ch_)                                                                        \
-  {                                                                                              \
-    const uint4* tb = Tq + ((long)(a_) * NCH + (ch_)) * CH16 + tid;                              \
-    BF_G1(0, pre0) BF_G1(1, pre1) BF_G1(2, pre2) BF_G1(3, pre3) BF_G1(4, pre4) BF_G1(5, pre5)    \
-    BF_G1(6, pre6) BF_G1(7, pre7) BF_G1(8, pre8) BF_G1(9, pre9) BF_G1(10, pre10) BF_G1(11, pre11) \
+  // acc[2 cb8 + nb][t] = out[row(nb)][16 cb8 + 4 kg + t]
+  f32x4 acc[16];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = nb ? row_b : row_a;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (init && row < nrows) {
+        const float* ip = init + (long)row * ldi + 16 * cb + 4 * kg;
+        if (vec_io) v = *reinterpret_cast<const float4*>(ip);
+        else v = make_float4(ip[0], ip[1], ip[2], ip[3]);
+      }
+      acc[2 * cb + nb][0] = v.x; acc[2 * cb + nb][1] = v.y; acc[2 * cb + nb][2] = v.z; acc[2 * cb + nb][3] = v.w;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define RG_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Tq + gi * CH16;                                                          \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+    glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
   }
-#define BF_LSTORE(buf_)                                                                          \
-  {                                                                                              \
-    uint4* lb = &Bs[buf_][tid];                                                                  \
-    BF_S1(0, pre0) BF_S1(1, pre1) BF_S1(2, pre2) BF_S1(3, pre3) BF_S1(4, pre4) BF_S1(5, pre5)    \
-    BF_S1(6, pre6) BF_S1(7, pre7) BF_S1(8, pre8) BF_S1(9, pre9) BF_S1(10, pre10) BF_S1(11, pre11) \
+#define RG_PLOAD(a_)                                                                           \
+  {                                                                                            \
+    const int aa = (a_) < a_end ? (a_) : a_end - 1;                                            \
+    glds_b32(p + aa, prow_off, wave_p + (unsigned)((a_) & 3) * (PST * 4));                     \
   }
-  BF_GLOAD(a_beg, 0);
-  BF_LSTORE(0);
-  float pa = p[rowc * ldp + a_beg];
-  __syncthreads();
-  int buf = 0;
-  // The bf16 MFMA's internal alignment drops low bits floor-wise (measured: a sign-independent bias of
-  // about -5e-11 of the running sum per accumulation step, tools/bf16x3_probe.hip; the f32-input MFMA
-  // rounds to nearest).  Successive flush groups therefore accumulate +a*b and -a*b alternately and
-  // are added / subtracted at the flush: the per-group biases cancel instead of adding up.
-  for (int a2 = a_beg; a2 < a_end; a2 += FLUSH) {
-    const float sgn = (((a2 - a_beg) / FLUSH) & 1) ? -1.f : 1.f;
-    f32x16 part[4];
+  RG_PLOAD(a_beg);
+  RG_PLOAD(a_beg + 1);
+  RG_TLOAD((long)a_beg * 4 + 0);
+  RG_TLOAD((long)a_beg * 4 + 1);
+  RG_TLOAD((long)a_beg * 4 + 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+  // group (s2, cb): the three planes of one 16-column block at one k-step
+#define RG_READ(F1_, F2_, F3_, slot_, s2_, cb_)                                                \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * (CH16) + (((s2_) * 3) * 4 + (cb_)) * 64;               \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[4 * 64];                                                                          \
+    if (PASSES >= 6) F3_ = fp[8 * 64];                                                         \
+  }
+#define RG_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
+  {                                                                                            \
+    if (PASSES >= 6) {                                                                         \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+    }                                                                                          \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+  }
+#define RG_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
+  {                                                                                            \
+    RG_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                 \
+    RG_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
+  }
+  RG_READ(fa1, fa2, fa3, 0, 0, 0);
+  f32x4 part[8];
+  for (int a = a_beg; a < a_end; ++a) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int ch = 0; ch < 4; ++ch) {
+      const int half = ch >> 1, c2 = ch & 1;
+      if constexpr (!(ABL & 2)) {
+        if (ch == 0) RG_PLOAD(a + 2);
+        RG_TLOAD((long)a * 4 + ch + 3);
+      }
+      if (c2 == 0) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) part[cb][t] = 0.f;
-    for (int a = a2; a < a2 + FLUSH && a < a_end; ++a) {
-      const int an = (a + 1 < a_end) ? a + 1 : a;
-      const float pa_next = p[rowc * ldp + an];
-      const float pas = sgn * pa;
+        for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        if constexpr (!(ABL & 2)) { if (ch + 1 < NCH) BF_GLOAD(a, ch + 1) else BF_GLOAD(an, 0); }
-        const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Bs[buf][hi * 32 + r]);
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int s = 2 * c2 + s2;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          // A fragments: the lane's 8 products p[n,a] * q[n,b], split into three bf16 planes
-          bf16x8 a1, a2v, a3;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if constexpr (ABL & 4) {  // no split arithmetic: reuse one conversion for all three pieces
-              const __bf16 x = (__bf16)(pas + qreg[8 * (KS * ch + ks) + j]);
-              a1[j] = x; a2v[j] = x; a3[j] = x;
-            } else {
-              __bf16 x1, x2, x3;
-              split3_bf16(pas * qreg[8 * (KS * ch + ks) + j], x1, x2, x3);
-              a1[j] = x1; a2v[j] = x2; a3[j] = x3;
-            }
-          }
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            // piece index (ks*3 + piece)*4 + cb, 64 sixteen-byte slots each
-            const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];
-            const bf16x8 b2 = bs[((ks * 3 + 1) * 4 + cb) * 64];
-            if (PASSES >= 6) {
-              const bf16x8 b3 = bs[((ks * 3 + 2) * 4 + cb) * 64];
-              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, part[cb], 0, 0, 0);
-              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, part[cb], 0, 0, 0);
-              part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b2, part[cb], 0, 0, 0);
-            }
-            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b1, part[cb], 0, 0, 0);
-            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, part[cb], 0, 0, 0);
-            part[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, part[cb], 0, 0, 0);
-          }
+        for (int cbp = 0; cbp < 2; ++cbp) {
+          // column block 2 cbp on set A (read 2 cbp + 1 into set B first), then 2 cbp + 1 on set B
+          RG_READ(fb1, fb2, fb3, ch, s2, 2 * cbp + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          RG_MFMA(fa1, fa2, fa3, s, 2 * cbp);
+          if (cbp == 0) RG_READ(fa1, fa2, fa3, ch, s2, 2)
+          else if (s2 == 0) RG_READ(fa1, fa2, fa3, ch, 1, 0)
+          else RG_READ(fa1, fa2, fa3, (ch + 1) & 3, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          RG_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
         }
-        if constexpr (!(ABL & 2)) BF_LSTORE(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
       }
-      pa = pa_next;
+      if (c2 == 1) {
+        const float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
+        const float pas_a = (a & 1) ? -pva : pva, pas_b = (a & 1) ? -pvb : pvb;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[2 * (4 * half + cb) + 0][t] = fmaf(pas_a, part[2 * cb + 0][t], acc[2 * (4 * half + cb) + 0][t]);
+            acc[2 * (4 * half + cb) + 1][t] = fmaf(pas_b, part[2 * cb + 1][t], acc[2 * (4 * half + cb) + 1][t]);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb] += part[cb] * sgn;
   }
-#undef BF_G1
-#undef BF_S1
-#undef BF_GLOAD
-#undef BF_LSTORE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef RG_TLOAD
+#undef RG_PLOAD
+#undef RG_READ
+#undef RG_MFMA1
+#undef RG_MFMA
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+  for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      int orow = row0 + (t & 3) + 8 * (t >> 2) + 4 * hi;
-      if (orow < nrows) out[(long)orow * ldo + cb * 32 + r] = acc[cb][t];
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = nb ? row_b : row_a;
+      if (row < nrows) {
+        float* op = out + (long)row * ldo + 16 * cb + 4 * kg;
+        const f32x4 v = acc[2 * cb + nb];
+        if (vec_io) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+      }
     }
 }
 
-// Tq[a][s][piece][cb][h][r][j] (bf16) from a [n0,n1,n2] fp32 tensor viewed with permuted indices
-// (dst dims (n[perm0], n[perm1], n[perm2]) = (NA, 128, 128)).
-__global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int n0, int n1, int n2,
-                                      int perm0, int perm1, int perm2) {
+// sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
+// (layout in the header above); element (a, b, c) of the [NA,128,128] operand is src[a*sa + b*sb + c*sc].
+__global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int NA, long sa, long sb,
+                                      long sc, int alternate) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)n0 * n1 * n2;
-  if (i >= total) return;
-  int dims[3] = {n0, n1, n2};
-  const int d1 = dims[perm1], d2 = dims[perm2];   // 128, 128
-  const int c = (int)(i % d2);
-  const int b = (int)((i / d2) % d1);
-  const int a = (int)(i / ((long)d2 * d1));
-  int idx[3];
-  idx[perm0] = a; idx[perm1] = b; idx[perm2] = c;
-  const float v = src[((long)idx[0] * n1 + idx[1]) * n2 + idx[2]];
+  if (i >= (long)NA * 128 * 128) return;
+  // thread order follows the fastest source stride so that reads coalesce
+  int a = (int)(i >> 14), b, c;
+  if (sc == 1) { b = (int)((i >> 7) & 127); c = (int)(i & 127); }
+  else { c = (int)((i >> 7) & 127); b = (int)(i & 127); }
+  float v = src[a * sa + b * sb + c * sc];
+  if (alternate && (a & 1)) v = -v;
   __bf16 x1, x2, x3;
   split3_bf16(v, x1, x2, x3);
-  const int s = b >> 4, h = (b >> 3) & 1, j = b & 7, cb = c >> 5, r = c & 31;
-  const long base = (((long)a * 8 + s) * 3) * 4;   // in units of [cb][h][r][j] blocks of 2*32*8
-  const long o1 = ((((base + 0 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
-  const long o2 = ((((base + 1 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
-  const long o3 = ((((base + 2 * 4 + cb) * 2 + h) * 32 + r) * 8) + j;
-  dst[o1] = x1; dst[o2] = x2; dst[o3] = x3;
+  const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+  const int kh = b >> 6, s2 = (b >> 5) & 1, kg = (b & 31) >> 3, j = b & 7;
+  const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * 3;   // planes of one k-step, each [cb][kg][i][j]
+  const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+  dst[(blk + 0) * 2048 + in] = x1;
+  dst[(blk + 1) * 2048 + in] = x2;
+  dst[(blk + 2) * 2048 + in] = x3;
+}
+
+int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
+                          hipStream_t stream) {
+  long total = (long)NA * 128 * 128;
+  if (total <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_T_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA, sa, sb,
+                     sc, alternate);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
 }
 
 // out[n, c] = sum_s slab[s][n][c]   (fixed order)
@@ -399,13 +477,8 @@ static int rows_asplit(int nrows, int rows_wg) {
 }
 
 int bilinear_mode();
-// rows per workgroup of the kernel variant that will run (the split-bf16 kernel uses 8 waves = 256 rows)
-static int rows_per_wg() {
-  if (bilinear_mode() == 0) return 128;
-  const char* ab = getenv("CGAT_BF16_VARIANT");
-  const int var = ab ? atoi(ab) : 822;
-  return (var / 10 == 8 || var / 100 == 8) ? 256 : 128;
-}
+// rows per workgroup of the kernel that will run (the split-bf16 ring kernel uses 8 waves = 256 rows)
+static int rows_per_wg() { return bilinear_mode() == 0 ? 128 : 256; }
 
 bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
 
@@ -459,24 +532,19 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
     }
     if (bilinear_mode() != 0) {
       CGAT_PROF("bilinear_rows", stream);
-      const char* ab = getenv("CGAT_BF16_VARIANT");   // dev knob: <waves><ks>[<flush>], e.g. 44, 82, 84, 822 (default), 824
-      const int var = ab ? atoi(ab) : 822;
-      const int rows_wg = (var / 10 == 8 || var / 100 == 8) ? 256 : 128;
-      const int tiles2 = cdiv(nrows, rows_wg);
-#define BF_LAUNCHF(P_, F_, W_, K_)                                                                                   \
-  hipLaunchKernelGGL((bilinear_rows128_bf16_kernel<P_, F_, W_, K_>), dim3(tiles2 * sp), dim3(64 * W_), 0, stream, p, \
-                     ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride)
-#define BF_LAUNCH(P_, W_, K_) BF_LAUNCHF(P_, 1, W_, K_)
-      const bool six = bilinear_mode() == 6;
-      switch (var) {
-        case 44: if (six) BF_LAUNCH(6, 4, 4); else BF_LAUNCH(3, 4, 4); break;
-        case 822: if (six) BF_LAUNCHF(6, 2, 8, 2); else BF_LAUNCHF(3, 2, 8, 2); break;
-        case 824: if (six) BF_LAUNCHF(6, 4, 8, 2); else BF_LAUNCHF(3, 4, 8, 2); break;
-        case 84: if (six) BF_LAUNCH(6, 8, 4); else BF_LAUNCH(3, 8, 4); break;
-        default: if (six) BF_LAUNCH(6, 8, 2); else BF_LAUNCH(3, 8, 2); break;
+      const int tiles2 = cdiv(nrows, 256);
+      const int vec_io = ((ldo % 4) == 0 && (dld % 4) == 0 && (((uintptr_t)dst) & 15) == 0 &&
+                          (!init || ((ldi % 4) == 0 && (((uintptr_t)init) & 15) == 0))) ? 1 : 0;
+      if (ldp >= (1l << 22)) {   // the kernel addresses p with 32-bit lane offsets inside a 256-row tile
+        cgat_set_error("bilinear_rows: ldp %ld too large", ldp);
+        return CGAT_ERR_ARG;
       }
-#undef BF_LAUNCH
-#undef BF_LAUNCHF
+      if (bilinear_mode() == 6)
+        hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<6>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io);
+      else
+        hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<3>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io);
     } else {
       CGAT_PROF("bilinear_rows", stream);
       static int variant = -1;  // dev knob: CGAT_BIL_VARIANT = <JS><FLUSH>, e.g. 161, 162, 322, 324
@@ -967,11 +1035,8 @@ int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int
                        hipStream_t stream) {
   int dims[3] = {n0, n1, n2};
   if (bilinear_T_interleaved(dims[perm1], dims[perm2]) && bilinear_mode() != 0) {
-    long total = (long)n0 * n1 * n2;
-    hipLaunchKernelGGL(prepare_T_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, n0, n1, n2,
-                       perm0, perm1, perm2);
-    CGAT_LAUNCH_CHECK();
-    return CGAT_OK;
+    long st[3] = {(long)n1 * n2, (long)n2, 1};   // source strides of dims 0, 1, 2
+    return prepare_T_bf16_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
   }
   return permute3_launch(src, dst, n0, n1, n2, perm0, perm1, perm2,
                          bilinear_T_interleaved(dims[perm1], dims[perm2]) ? 1 : 0, stream);

@@ -30,30 +30,7 @@ for rnd in range(5):
         e1.record(); torch.cuda.synchronize()
         res.setdefault(mode, []).append(e0.elapsed_time(e1) / 4)
 fl = 2.0 * rows * W ** 3
-for var in ("82", "822", "824", "82", "822", "824"):
-    os.environ["CGAT_BF16_VARIANT"] = var
-    for mode in (6,):
-        _lib.lib.cgat_set_bilinear_mode(mode)
-        ws2 = torch.empty(_lib.lib.cgat_bilinear_rows_workspace_bytes(rows, W, W, W), dtype=torch.uint8, device=dev)
-        ws = ws2 if ws2.numel() > ws.numel() else ws
-        call(); torch.cuda.synchronize()
-        err = float((out[sel].double().cpu() - ref).abs().max() / ref.abs().max())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(6): call()
-        e1.record(); torch.cuda.synchronize()
-        print(f"mode {mode} variant {var} (waves,ks): {e0.elapsed_time(e1) / 6:.3f} ms   err {err:.2e}")
-os.environ["CGAT_BF16_VARIANT"] = "82"
-_lib.lib.cgat_set_bilinear_mode(6)
-for abl in ():
-    os.environ["CGAT_BF16_ABL"] = abl
-    call(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(6): call()
-    e1.record(); torch.cuda.synchronize()
-    print(f"mode 6 ablation {abl} (2 = no T loads, 4 = no split VALU, 6 = both): {e0.elapsed_time(e1) / 6:.3f} ms")
-os.environ["CGAT_BF16_ABL"] = "0"
+print("CGAT_BF16_VARIANT =", os.environ.get("CGAT_BF16_VARIANT", "(default)"))
 for mode, t in res.items():
     t = sorted(t); med = t[len(t) // 2]
     print(f"mode {mode}: median {med:.3f} ms incl. T preparation + slab sum -> {fl / med / 1e9:.1f} TFLOP/s (fp32-equivalent)")
