@@ -1,0 +1,219 @@
+// Edge pre-activations of both message networks, the per-edge part of the operand-split first conv
+// (reference CGAT.py:96 MultiHeadNetwork.fc_in applied to cat([x_i, edge_attr, x_j]), CGAT.py:316-318):
+//     Z[t, :] = W_e e[perm[t]] + Pi[dst[t], :] + Pj[src[t], :]            t = destination-sorted edge slot
+// fused with the attention logits of MH_A (CGAT.py:97-98: fc_out(LeakyReLU(fc_in(.))), one output per head):
+//     a[t, h] = b_A[h] + sum_j leaky(Z[t, h*Hd + j]) * w_A[h*Hd + j]
+//
+// Shape: E x 1536 outputs with K = Ce = 128.  The product runs on the matrix cores in the split-bf16
+// arithmetic of bilinear.hip (three bf16 planes per fp32 operand, six v_mfma_f32_16x16x32_bf16 passes,
+// fp32 accumulation: fp32-equivalent), organised like the hypernetwork kernel: a wave's 32 edge rows are
+// split once and stay in 96 VGPRs, the pre-split weight column blocks stream through a 4-slot LDS ring by
+// LDS-DMA (12-KB chunks = one 32-deep k-step of 64 columns), fragments are read one group ahead.  The
+// kernel is bound by its epilogue traffic -- per edge 6 KB of Z written and 6 KB of Pj gathered (Pi rows
+// are shared by the edges of a destination segment and hit L2) -- so two 4-wave workgroups share a CU:
+// while one gathers/stores a 64-column slice, the other one runs MFMAs.
+//
+// vmcnt bookkeeping: the ring's counted waits assume that the three LDS-DMA loads of the current
+// iteration are the youngest vector-memory operations; the epilogue's ordinary loads and stores are older
+// than the next iteration's LDS-DMA loads, so a counted wait can only be stricter than needed, never looser
+// (vmcnt retires in order).  RAW/WAR reasoning of the ring: bilinear.hip.
+//
+// Packed math: when hipcc SLP-packs the two rows' logit accumulations into v_pk_mul/v_pk_fma_f32, the logits come
+// out slightly wrong and differ from run to run on MI355X (Z, computed from the same registers, stays bit-exact;
+// found by tests/test_hip_golden.py::test_determinism_bitwise, bisected with an empty asm between the two
+// accumulations).  This file is therefore built with -fno-slp-vectorize and the two accumulators are pinned apart.
+#include "common.h"
+#include "kernels.h"
+#include "mfma_bf16.h"
+
+template <int PASSES>
+__global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict__ e, long lde,
+                                                        const int* __restrict__ perm, const uint4* __restrict__ Wq,
+                                                        int ncb, const float* __restrict__ Pi,
+                                                        const int* __restrict__ dsti, const float* __restrict__ Pj,
+                                                        const int* __restrict__ srci, long ld_add,
+                                                        float* __restrict__ Z, long ldz, int E,
+                                                        const float* __restrict__ wA, const float* __restrict__ bA,
+                                                        int H, int cb_per_head, float* __restrict__ a_out) {
+  constexpr int CH16 = 3 * 4 * 64;              // 16-byte pieces per chunk = 12 KB
+  __shared__ uint4 smem[4 * CH16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int row_w = blockIdx.x * 128 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_a + 16;
+  const int rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned t_off = (unsigned)tid * 16;
+  const long last_chunk = (long)ncb * 8 - 1;
+
+  // the lane's two edge rows, split once: q[plane][2 s + nb] holds e[row(nb), 32 s + 8 kg + 0..7]
+  bf16x8 q1[8], q2[8], q3[8];
+  {
+    const long ea = perm ? perm[rca] : rca, eb = perm ? perm[rcb] : rcb;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          __bf16 x1, x2, x3;
+          split3_bf16(v[j], x1, x2, x3);
+          q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
+        }
+      }
+  }
+  const float* pia = Pi + (long)dsti[rca] * ld_add;
+  const float* pib = Pi + (long)dsti[rcb] * ld_add;
+  const float* pja = Pj + (long)srci[rca] * ld_add;
+  const float* pjb = Pj + (long)srci[rcb] * ld_add;
+  float* za = Z + (long)rca * ldz;
+  float* zb = Z + (long)rcb * ldz;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define EZ_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Wq + gi * CH16;                                                          \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 256, t_off, dst + 4096);                                                    \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+  }
+  EZ_TLOAD(0l);
+  EZ_TLOAD(1l);
+  EZ_TLOAD(2l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+  // group = the three planes of one 16-column block of the chunk in ring slot slot_
+#define EZ_READ(F1_, F2_, F3_, slot_, cb_)                                                     \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[4 * 64];                                                                          \
+    if (PASSES >= 6) F3_ = fp[8 * 64];                                                         \
+  }
+#define EZ_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
+  {                                                                                            \
+    if (PASSES >= 6) {                                                                         \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+    }                                                                                          \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+  }
+#define EZ_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
+  {                                                                                            \
+    EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                 \
+    EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
+  }
+  EZ_READ(fa1, fa2, fa3, 0, 0);
+  f32x4 part[8];
+  float dot_a = 0.f, dot_b = 0.f;
+  const int ncbA = a_out ? H * cb_per_head : 0;      // column blocks that belong to the attention network
+  for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                  // chunk (cb, half, s) sits in ring slot s
+        EZ_TLOAD((long)cb * 8 + half * 4 + s + 3);
+#pragma unroll
+        for (int cbp = 0; cbp < 2; ++cbp) {
+          EZ_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          EZ_MFMA(fa1, fa2, fa3, s, 2 * cbp);
+          if (cbp == 0) EZ_READ(fa1, fa2, fa3, s, 2)
+          else EZ_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          EZ_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      // ---- epilogue of the 64-column slice: z = part + Pi[dst] + Pj[src]; store; logits ----
+      const int col0 = cb * 128 + half * 64 + 4 * kg;
+      const bool isA = cb < ncbA;
+#pragma unroll
+      for (int c16 = 0; c16 < 4; ++c16) {
+        const int col = col0 + 16 * c16;
+        const float4 ia = *reinterpret_cast<const float4*>(pia + col);
+        const float4 ja = *reinterpret_cast<const float4*>(pja + col);
+        const float4 ib = *reinterpret_cast<const float4*>(pib + col);
+        const float4 jb = *reinterpret_cast<const float4*>(pjb + col);
+        const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
+        const float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
+        const float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
+        if (row_a < E) *reinterpret_cast<float4*>(za + col) = va;
+        if (row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
+        if (isA) {
+          const float4 w = *reinterpret_cast<const float4*>(wA + col);
+          dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
+                   (va.z > 0.f ? va.z : 0.01f * va.z) * w.z + (va.w > 0.f ? va.w : 0.01f * va.w) * w.w;
+          asm volatile("" : "+v"(dot_a));   // keep the two accumulations apart: see the note on packed math above
+          dot_b += (vb.x > 0.f ? vb.x : 0.01f * vb.x) * w.x + (vb.y > 0.f ? vb.y : 0.01f * vb.y) * w.y +
+                   (vb.z > 0.f ? vb.z : 0.01f * vb.z) * w.z + (vb.w > 0.f ? vb.w : 0.01f * vb.w) * w.w;
+          asm volatile("" : "+v"(dot_b));
+        }
+      }
+      if (isA && half == 1 && (cb + 1) % cb_per_head == 0) {   // a head is complete: reduce over the 4 lane groups
+        const int h = cb / cb_per_head;
+        float da = dot_a, db = dot_b;
+        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        if (kg == 0) {
+          const float bh = bA ? bA[h] : 0.f;
+          if (row_a < E) a_out[(long)row_a * H + h] = da + bh;
+          if (row_b < E) a_out[(long)row_b * H + h] = db + bh;
+        }
+        dot_a = 0.f; dot_b = 0.f;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef EZ_TLOAD
+#undef EZ_READ
+#undef EZ_MFMA1
+#undef EZ_MFMA
+}
+
+bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz, const void* e, const void* Pi,
+                 const void* Pj, const void* Z, const void* wA) {
+  return bilinear_mode() != 0 && Ce == 128 && W2 % 128 == 0 && Hd % 128 == 0 && H * Hd * 2 == W2 && (lde % 4) == 0 &&
+         (ld_add % 4) == 0 && (ldz % 4) == 0 &&
+         ((((uintptr_t)e) | ((uintptr_t)Pi) | ((uintptr_t)Pj) | ((uintptr_t)Z) | ((uintptr_t)wA)) & 15) == 0;
+}
+
+// floats of workspace for the pre-split weight
+size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
+
+// We: the edge_attr slice of the stacked first-layer weight, element (out, k) at We[out * ldw + k].
+int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
+                  const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
+                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream) {
+  if (E <= 0) return CGAT_OK;
+  const int ncb = W2 / 128;
+  // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
+  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
+  CGAT_PROF("edge_z", stream);
+  const int grid = cdiv(E, 128);
+  if (bilinear_mode() == 6)
+    hipLaunchKernelGGL(edge_z_kernel<6>, dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi, dsti,
+                       Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
+  else
+    hipLaunchKernelGGL(edge_z_kernel<3>, dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi, dsti,
+                       Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}

@@ -66,6 +66,16 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream);
+// three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
+int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
+                          hipStream_t stream);
+// ---- fused edge pre-activations + attention logits, edgez.hip ----
+bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz, const void* e, const void* Pi,
+                 const void* Pj, const void* Z, const void* wA);
+size_t edge_z_wq_floats(int W2);
+int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
+                  const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
+                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

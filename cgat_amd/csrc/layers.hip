@@ -286,6 +286,7 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   float* Pi = c.take<float>((size_t)d.N * d.W2);
   float* Pj = c.take<float>((size_t)d.N * d.W2);
   float* a = c.take<float>((size_t)d.E * d.H);
+  float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(saved, d);
 
@@ -298,7 +299,14 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
     g = gemm_params(d.N, d.W2, d.C, x, d.C, Wcat + d.C + d.Ce, d.D, Pj, d.W2);
     CGAT_TRY(c.gemm(g));
   }
-  {  // Z[t] = W_e e[perm[t]] + Pi[dst[t]] + Pj[src[t]]      (x_i = x[edge_index[1]], x_j = x[edge_index[0]])
+  // Z[t] = W_e e[perm[t]] + Pi[dst[t]] + Pj[src[t]]      (x_i = x[edge_index[1]], x_j = x[edge_index[0]])
+  // and the attention logits a[t,h] = fc_out_A(leaky(zA)): one fused split-bf16 kernel at the benchmark widths,
+  // the generic GEMM + row-dot otherwise (and in the f32 arithmetic mode)
+  const bool fused_z = !c.dry && edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Pi, Pj, sv.Z, p->A_out_w);
+  if (fused_z) {
+    RUN(edge_z_launch(e, d.Ce, plan->dst_perm, Wcat + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted,
+                      d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
+  } else {
     GemmParams g = gemm_params(d.E, d.W2, d.Ce, e, d.Ce, Wcat + d.C, d.D, sv.Z, d.W2);
     g.a_rgather = plan->dst_perm;
     g.add1 = Pi; g.add1_idx = plan->dst_sorted;
@@ -306,8 +314,8 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
     g.ld_add = d.W2;
     CGAT_TRY(c.gemm(g));
   }
-  // attention logits a[t,h] = fc_out_A(leaky(zA))
-  RUN(rowdot_launch(sv.Z, d.W2, CGAT_ACT_LEAKY, p->A_out_w, 0, nullptr, p->A_out_b, nullptr, d.E, d.H, d.Hd, a, c.s));
+  if (!fused_z)
+    RUN(rowdot_launch(sv.Z, d.W2, CGAT_ACT_LEAKY, p->A_out_w, 0, nullptr, p->A_out_b, nullptr, d.E, d.H, d.Hd, a, c.s));
   RUN(seg_softmax_fwd_launch(a, nullptr, plan->dst_rowptr, d.N, d.H, 1e-16f, sv.alpha, sv.ssum, c.s));
   // S[n,h,:] = sum_{t -> n} alpha[t,h] leaky(zM[t,h,:])  -- fc_out of MH_M commutes with the weighted sum
   RUN(seg_wsum_launch(sv.Z + d.HHd, d.W2, nullptr, sv.alpha, d.H, d.Hd, plan->dst_rowptr, d.N, d.HHd, CGAT_ACT_LEAKY,

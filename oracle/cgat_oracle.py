@@ -48,6 +48,38 @@ def seg_softmax(src, index, n):
 
 
 # ----------------------------------------------------------------------------------------
+# LeakyReLU(0.01) with a test probe.  The derivative of LeakyReLU jumps from 0.01 to 1 at 0: two correct fp32
+# evaluations of a pre-activation |z| <~ 1e-6 max|z| can disagree on its sign, which changes every gradient
+# upstream of that element by a finite amount (the reference's own fp32 and fp64 runs disagree the same way).
+# `flip_probe(tau)` makes the oracle evaluate all pre-activations with |z| < tau * max|z| with the OTHER slope
+# (values change by < tau*max|z|, derivatives swap): the gradient difference against the plain run is the
+# sensitivity of each gradient tensor to such sign flips, which the parity tests add to their tolerance.
+# ----------------------------------------------------------------------------------------
+_FLIP_TAU = None
+
+
+class flip_probe:
+    def __init__(self, tau):
+        self.tau = tau
+
+    def __enter__(self):
+        global _FLIP_TAU
+        self.prev, _FLIP_TAU = _FLIP_TAU, self.tau
+
+    def __exit__(self, *exc):
+        global _FLIP_TAU
+        _FLIP_TAU = self.prev
+
+
+def leaky(z):
+    out = F.leaky_relu(z, 0.01)
+    if _FLIP_TAU is None:
+        return out
+    near = z.detach().abs() < _FLIP_TAU * z.detach().abs().max()
+    return torch.where(near, torch.where(z > 0, 0.01 * z, z), out)
+
+
+# ----------------------------------------------------------------------------------------
 # MLP blocks  (CGAT/message_changed.py:31-138, CGAT/roost_message.py:324-355)
 # ----------------------------------------------------------------------------------------
 class SimpleNetwork(nn.Module):
@@ -62,7 +94,7 @@ class SimpleNetwork(nn.Module):
 
     def forward(self, fea):
         for fc in self.fcs:
-            fea = F.leaky_relu(fc(fea), 0.01)
+            fea = leaky(fc(fea))
         return self.fc_out(fea)
 
 
@@ -250,7 +282,7 @@ class MultiHeadNetwork(nn.Module):
 
     def forward(self, fea):
         fea = fea.reshape(-1, self.input_dim, 1).repeat(1, self.nb_heads, 1)      # 105/107
-        fea = F.leaky_relu(self.fc_in(fea), 0.01)
+        fea = leaky(self.fc_in(fea))
         return self.fc_out(fea).view(-1, self.nb_heads, self.output_dim)          # 109
 
 
