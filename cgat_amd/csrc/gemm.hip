@@ -361,14 +361,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 }
 
 // out[m*ldc + n] = act(alpha * sum_z slab[z][m][n] + bias[n]) + beta * out
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N, float* __restrict__ C,
-                                     long ldc, float alpha, float beta, const float* __restrict__ bias, int act) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)M * N;
-  if (i >= total) return;
-  int m = (int)(i / N), n = (int)(i % N);
+// Fixed summation tree (deterministic): the z range is cut into ZG contiguous groups summed in order by ZG threads
+// per output, whose partial sums are then added in group order.  With hundreds of slabs and a few thousand outputs
+// (the [128,128] weight gradients) one thread per output is a 300-long chain of dependent loads.
+template <int ZG>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                                            float* __restrict__ C, long ldc, float alpha, float beta,
+                                                            const float* __restrict__ bias, int act) {
+  constexpr int OUT = 256 / ZG;                  // outputs per workgroup
+  __shared__ float part[ZG][OUT];
+  const int o = threadIdx.x % OUT, zg = threadIdx.x / OUT;
+  const long total = (long)M * N;
+  const long i = (long)blockIdx.x * OUT + o;
+  const int per = (splits + ZG - 1) / ZG;
+  const int z0 = zg * per, z1 = min(splits, z0 + per);
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slab[(long)z * total + i];
+  if (i < total)
+    for (int z = z0; z < z1; ++z) s += slab[(long)z * total + i];
+  if (ZG > 1) {
+    part[zg][o] = s;
+    __syncthreads();
+    if (zg != 0) return;
+    s = part[0][o];
+#pragma unroll
+    for (int g = 1; g < ZG; ++g) s += part[g][o];
+  }
+  if (i >= total) return;
+  const int m = (int)(i / N), n = (int)(i % N);
   s *= alpha;
   if (bias) s += bias[n];
   s = act_apply(s, act);
@@ -465,8 +484,12 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   CGAT_LAUNCH_CHECK();
   if (p.splits > 1) {
     long total = (long)p.M * p.N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.slab, p.splits, p.M, p.N,
-                       p.C, p.ldc, p.alpha, p.beta, p.bias, p.act);
+    if (total < 256 * 1024 && p.splits >= 32)   // few outputs, many slabs: spread the slab loop over 8 threads
+      hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(256), 0, stream, p.slab, p.splits, p.M,
+                         p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.slab, p.splits, p.M,
+                         p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act);
     CGAT_LAUNCH_CHECK();
   }
   return CGAT_OK;

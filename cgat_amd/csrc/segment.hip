@@ -111,9 +111,57 @@ __global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int
   }
 }
 
+// Same sum, four consecutive features per thread (16-byte loads) and the rows of a segment fetched four at a time
+// before they are added in CSR order: the loads of a batch are independent, so a 12-row segment costs three memory
+// round trips instead of twelve.  Needs F % 4 == 0, fw % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void seg_wsum_vec_kernel(const float* __restrict__ x, long ldx,
+                                                           const int* __restrict__ ridx, const float* __restrict__ w,
+                                                           int wF, int fw, const int* __restrict__ rowptr, int F, int act,
+                                                           float* __restrict__ out, long ldo, long xblock) {
+  const int s = blockIdx.x;
+  const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
+    const int wf = w ? f / fw : 0;
+    const float* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
+    const long pitch = xblock ? 128 : ldx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; r += 4) {
+      float4 v[4];
+      float wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u < r1 ? r + u : r1 - 1;
+        const long row = ridx ? (long)ridx[rr] : (long)rr;
+        v[u] = *reinterpret_cast<const float4*>(xb + row * pitch);
+        wv[u] = w ? w[(long)rr * wF + wf] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u < r1) {
+          acc.x += act_f(v[u].x, act) * wv[u];
+          acc.y += act_f(v[u].y, act) * wv[u];
+          acc.z += act_f(v[u].z, act) * wv[u];
+          acc.w += act_f(v[u].w, act) * wv[u];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + (long)s * ldo + f) = acc;
+  }
+}
+
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
                     int F, int act, float* out, long ldo, hipStream_t s, long xblock) {
   if (S <= 0 || F <= 0) return CGAT_OK;
+  const bool vec = (F % 4) == 0 && (!w || (fw % 4) == 0) && (ldx % 4) == 0 && (ldo % 4) == 0 && (xblock % 4) == 0 &&
+                   ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
+  if (vec) {
+    int threads = F >= 1024 ? 256 : (F >= 512 ? 192 : (F >= 256 ? 64 : 64));
+    if (F / 4 < threads) threads = ((F / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(seg_wsum_vec_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out,
+                       ldo, xblock);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   int threads = F >= 256 ? 256 : (F >= 128 ? 128 : 64);
   hipLaunchKernelGGL(seg_wsum_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out, ldo,
                      xblock);
