@@ -76,6 +76,10 @@ size_t edge_z_wq_floats(int W2);
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
+// ---- split-bf16 backward products over gZ, edgebwd.hip ----
+bool edge_ge_fast(int Ce, int W2, long gzb, long ldo, const void* gZ, const void* out);
+int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* Wq, int W2, float* out, long ldo,
+                   const int* scatter, int E, hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

@@ -353,6 +353,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   float* partial = c.take<float>((size_t)chunks * d.HHd);
   float* Gi = c.take<float>((size_t)d.N * d.W2);
   float* Gj = c.take<float>((size_t)d.N * d.W2);
+  float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(const_cast<float*>(saved), d);
   const float invH = 1.f / d.H;
@@ -406,14 +407,18 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   }
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
-  {  // grad edge_attr[perm[t]] = gZ[t] @ W_e
+  // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
+  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gzb, d.Ce, gZ, g_e)) {
+    RUN(edge_ge_launch(gZ, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, c.s));
+  } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = gzb;
     g.b_kmajor = 1;
     g.c_scatter = plan->dst_perm;
     CGAT_TRY(c.gemm(g));
-    // grad W_e = gZ^T @ e[perm]
-    g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
+  }
+  {  // grad W_e = gZ^T @ e[perm]
+    GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = gzb;
     g.a_kmajor = 1; g.b_kmajor = 1;
     g.b_kgather = plan->dst_perm;
