@@ -135,6 +135,195 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------
+//     g_W_e[col, :] = sum_t gZ[t, col] * e[perm[t], :]           (edge_gw_kernel,  K = E, 1536 x 128 outputs)
+// Both operands of this product are needed with t (the edge slot) as the MFMA's k index, i.e. transposed with
+// respect to their [t][feature] storage:
+//   * e[perm[t]] is pre-split ONCE per step into fragment-ordered planes (prepare_T_bf16 with a row gather:
+//     operand (a = t/128, b = t%128, c = k) -- 0.77 GB at E = 1M, zero-padded past E) and streamed through a
+//     double-buffered LDS tile shared by all waves of the workgroup;
+//   * gZ tiles (32 slots x 128 columns = 16 KB contiguous in the blocked layout) are loaded coalesced, split in
+//     registers, written as bf16 planes into an XOR-swizzled [32][128] LDS image and read back transposed with
+//     ds_read_b64_tr_b16 (image (b) of cdna_hip_programming.md T10: conflict-free writes and transposed reads).
+// A workgroup owns two 128-column blocks (8 waves x 32 columns, all 128 outputs k per wave: 64 accumulator
+// VGPRs) and a contiguous range of k-steps; the workgroups of one range (one per column-block pair) are adjacent
+// in the grid so that the e planes they share are fetched from HBM once and hit the Infinity Cache afterwards.
+// Two-level summation through memory: every FLUSH k-steps (2048 slots) the accumulators are added into the
+// workgroup's private slab tile and cleared; consecutive groups accumulate products of opposite sign (the split
+// multiplies the raw gZ values by +-1), which cancels the bf16 MFMA's floor bias (bilinear.hip).  The slabs of
+// all ranges are then summed in fixed order by splitk_reduce.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int PASSES>
+__global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long gzb,
+                                                         const uint4* __restrict__ Eq, float* __restrict__ slab,
+                                                         int E, int ncb, int nsteps, int S) {
+  constexpr int FLUSH = 64;
+  __shared__ uint4 Es[2][1536];                          // e planes of one k-step: [half][plane][cb][lane]
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[2][2][3][8192];   // [buffer][column block][plane][32 x 256 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int grp = wave >> 2, wq = wave & 3;              // column block of the pair, 32-column slice in it
+  const int npair = ncb / 2;
+  const int pair = blockIdx.x % npair, split = blockIdx.x / npair;
+  const int ks0 = (int)((long)nsteps * split / S), ks1 = (int)((long)nsteps * (split + 1) / S);
+  const int cb128 = pair * 2 + grp;
+  const float* gblk = gZ + (long)cb128 * gzb;
+  const int gt = tid & 255;                              // thread within the column block's group
+
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 se0, se1, se2;
+  const int p1 = tid + 512, p2 = tid + 1024;
+#define GW_ELOAD(ks_)                                                                                    \
+  {                                                                                                      \
+    const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
+    const uint4* h0 = Eq + ((a_ * 2 + 0) * 4 + s_) * 768;                                                \
+    const uint4* h1 = Eq + ((a_ * 2 + 1) * 4 + s_) * 768;                                                \
+    se0 = h0[tid];                                                                                       \
+    se1 = p1 < 768 ? h0[p1] : h1[p1 - 768];                                                              \
+    se2 = h1[p2 - 768];                                                                                  \
+  }
+#define GW_ESTORE(buf_)                                                                                  \
+  {                                                                                                      \
+    Es[buf_][tid] = se0; Es[buf_][p1] = se1; Es[buf_][p2] = se2;                                         \
+  }
+  // raw gZ tile pieces: float4 number gt + 256 i of the k-step's contiguous [32][128] tile, i < 4
+  float4 r0, r1, r2, r3, s0, s1, s2, s3;
+#define GW_G1(ks_, i_, R_)                                                                               \
+  {                                                                                                      \
+    const int idx = gt + 256 * (i_);                                                                     \
+    const long t = (long)(ks_) * 32 + (idx >> 5);                                                        \
+    R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * 128 + 4 * (idx & 31))                       \
+               : make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+  }
+#define GW_GLOAD(ks_, A_, B_, C_, D_) { GW_G1(ks_, 0, A_) GW_G1(ks_, 1, B_) GW_G1(ks_, 2, C_) GW_G1(ks_, 3, D_) }
+  // split one float4 (row idx >> 5, columns 4 (idx & 31) ...) and store 8 bytes per plane into image (b)
+#define GW_S1(i_, R_, buf_, sg_)                                                                         \
+  {                                                                                                      \
+    const int idx = gt + 256 * (i_);                                                                     \
+    const int row = idx >> 5, c4 = idx & 31;                                                             \
+    const int off = 256 * row + 16 * ((c4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (c4 & 1); \
+    const float v[4] = {R_.x * sg_, R_.y * sg_, R_.z * sg_, R_.w * sg_};                                 \
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));                                           \
+    bf16x4 x1, x2, x3;                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+      __bf16 y1, y2, y3;                                                                                 \
+      split3_bf16(v[j], y1, y2, y3);                                                                     \
+      x1[j] = y1; x2[j] = y2; x3[j] = y3;                                                                \
+    }                                                                                                    \
+    *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][0][off]) = x1;                                             \
+    *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][1][off]) = x2;                                             \
+    if (PASSES >= 6) *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][2][off]) = x3;                            \
+  }
+  // transposed fragment of plane pl_, column block nb_ of this wave: k = 8 kg + j  <->  slot 8 kg + j
+  const int l16q = n16 >> 2, l16p = n16 & 3;
+#define GW_TRADDR(nb_, h_)                                                                               \
+  ({                                                                                                     \
+    const int row = 8 * kg + 4 * (h_) + l16q;                                                            \
+    const int ch = 4 * wq + 2 * (nb_) + (l16p >> 1);                                                     \
+    256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (l16p & 1);                      \
+  })
+  const int tr00 = GW_TRADDR(0, 0), tr01 = GW_TRADDR(0, 1), tr10 = GW_TRADDR(1, 0), tr11 = GW_TRADDR(1, 1);
+#define GW_TRREAD(buf_, pl_, o0_, o1_)                                                                   \
+  ({                                                                                                     \
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&Gs[buf_][grp][pl_][o0_]));   \
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&Gs[buf_][grp][pl_][o1_]));   \
+    typedef short s16x8 __attribute__((ext_vector_type(8)));                                             \
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                         \
+    __builtin_bit_cast(bf16x8, both);                                                                    \
+  })
+#define GW_MFMA1(F1_, F2_, F3_, Q1_, Q2_, Q3_, P_)                                                       \
+  {                                                                                                      \
+    if (PASSES >= 6) {                                                                                   \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, Q1_, P_, 0, 0, 0);                               \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q3_, P_, 0, 0, 0);                               \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q2_, P_, 0, 0, 0);                               \
+    }                                                                                                    \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q1_, P_, 0, 0, 0);                                 \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q2_, P_, 0, 0, 0);                                 \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q1_, P_, 0, 0, 0);                                 \
+  }
+  // the workgroup's slab tile: rows = its 256 columns of gZ, 128 outputs each
+  float* tile = slab + ((long)split * ncb * 128 + (long)cb128 * 128 + 32 * wq) * 128;
+#define GW_FLUSH(first_, sg_)                                                                            \
+  {                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g)                                                        \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                   \
+      float4* o = reinterpret_cast<float4*>(tile + (long)(16 * nb + n16) * 128 + 16 * g + 4 * kg);       \
+      const f32x4 v = acc[2 * g + nb];                                                                   \
+      float4 w = make_float4(v[0] * sg_, v[1] * sg_, v[2] * sg_, v[3] * sg_);                            \
+      if (!(first_)) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }            \
+      *o = w;                                                                                            \
+      acc[2 * g + nb] = f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
+    }                                                                                                    \
+  }
+  if (ks1 <= ks0) {   // empty range: the reducer still sums this slab
+    GW_FLUSH(true, 1.f);
+    return;
+  }
+  GW_ELOAD(ks0);
+  GW_GLOAD(ks0, r0, r1, r2, r3);
+  GW_ESTORE(0);
+  GW_S1(0, r0, 0, 1.f) GW_S1(1, r1, 0, 1.f) GW_S1(2, r2, 0, 1.f) GW_S1(3, r3, 0, 1.f)
+  r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ks0 + 1 < ks1) GW_GLOAD(ks0 + 1, r0, r1, r2, r3);
+  __syncthreads();
+  bool first = true;
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int rel = ks - ks0, buf = rel & 1;
+    // sign of the flush group the NEXT k-step belongs to (its tile is split during this iteration)
+    const float sgn_next = (((rel + 1) / FLUSH) & 1) ? -1.f : 1.f;
+    if (ks + 1 < ks1) GW_ELOAD(ks + 1);
+    if (ks + 2 < ks1) GW_GLOAD(ks + 2, s0, s1, s2, s3);
+    const bf16x8* es = reinterpret_cast<const bf16x8*>(&Es[buf][lane]);
+    // this wave's two transposed gZ fragments (32 columns x 32 slots), three planes each
+    bf16x8 qa1 = GW_TRREAD(buf, 0, tr00, tr01), qa2 = GW_TRREAD(buf, 1, tr00, tr01), qa3;
+    bf16x8 qb1 = GW_TRREAD(buf, 0, tr10, tr11), qb2 = GW_TRREAD(buf, 1, tr10, tr11), qb3;
+    if (PASSES >= 6) { qa3 = GW_TRREAD(buf, 2, tr00, tr01); qb3 = GW_TRREAD(buf, 2, tr10, tr11); }
+    bf16x8 f1 = es[0], f2 = es[256], f3;
+    if (PASSES >= 6) f3 = es[512];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {                // 16 outputs k = 16 g ... : e fragment g = (half, cb)
+      bf16x8 n1, n2, n3;
+      if (g < 7) {
+        const int o = ((g + 1) >> 2) * 768 + ((g + 1) & 3) * 64;
+        n1 = es[o]; n2 = es[o + 256];
+        if (PASSES >= 6) n3 = es[o + 512];
+      }
+      GW_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);
+      if (ks + 1 < ks1) {
+        if (g == 0) GW_S1(0, r0, buf ^ 1, sgn_next)
+        if (g == 2) GW_S1(1, r1, buf ^ 1, sgn_next)
+        if (g == 4) GW_S1(2, r2, buf ^ 1, sgn_next)
+        if (g == 6) GW_S1(3, r3, buf ^ 1, sgn_next)
+      }
+      GW_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);
+      if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }
+    }
+    if (ks + 1 < ks1) GW_ESTORE(buf ^ 1);
+    if ((rel + 1) % FLUSH == 0 || ks + 1 == ks1) {
+      const float sg = ((rel / FLUSH) & 1) ? -1.f : 1.f;
+      GW_FLUSH(first, sg);
+      first = false;
+    }
+    __syncthreads();
+    r0 = s0; r1 = s1; r2 = s2; r3 = s3;
+  }
+#undef GW_ELOAD
+#undef GW_ESTORE
+#undef GW_G1
+#undef GW_GLOAD
+#undef GW_S1
+#undef GW_TRADDR
+#undef GW_TRREAD
+#undef GW_MFMA1
+#undef GW_FLUSH
+}
+
 bool edge_ge_fast(int Ce, int W2, long gzb, long ldo, const void* gZ, const void* out) {
   return bilinear_mode() != 0 && Ce == 128 && W2 % 128 == 0 && gzb != 0 && (gzb % 4) == 0 && (ldo % 4) == 0 &&
          ((((uintptr_t)gZ) | ((uintptr_t)out)) & 15) == 0;
@@ -157,4 +346,44 @@ int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* 
                        scatter, E);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
+}
+
+bool edge_gw_fast(int Ce, int W2, long gzb, const void* gZ) {
+  return bilinear_mode() != 0 && Ce == 128 && W2 % 256 == 0 && gzb != 0 && (gzb % 4) == 0 && (((uintptr_t)gZ) & 15) == 0;
+}
+static int edge_gw_splits(int W2) {   // ranges x column-block pairs ~ one workgroup per CU
+  const int npair = W2 / 256;
+  if (npair <= 0) return 1;
+  return 256 / npair > 0 ? 256 / npair : 1;
+}
+// workspace floats: e planes (zero-padded to a multiple of 128 slots) + slabs
+size_t edge_gw_ws_floats(int E, int W2) {
+  const size_t planes = ((size_t)cdiv(E, 128) * 128 * 128 * 3 + 1) / 2;
+  return planes + (size_t)edge_gw_splits(W2) * W2 * 128 + 64;
+}
+
+// out[col * ldo + k] = sum_t gZ[t, col] * e[perm[t] * lde + k]
+int edge_gw_launch(const float* gZ, long gzb, const float* e, long lde, const int* perm, int E, int W2, float* ws,
+                   float* out, long ldo, hipStream_t stream) {
+  if (E <= 0) {
+    GemmParams z = gemm_params(W2, 128, 0, nullptr, 1, nullptr, 1, out, ldo);
+    return gemm_launch(z, nullptr, 0, stream);   // K = 0: zero fill
+  }
+  const int ncb = W2 / 128, na = cdiv(E, 128), S = edge_gw_splits(W2);
+  float* planes = ws;
+  float* slab = ws + (((size_t)na * 128 * 128 * 3 + 1) / 2 + 15) / 16 * 16;
+  // operand (a = slot block, b = slot in block, c = k) = e[perm[128 a + b] * lde + c], zero past E
+  CGAT_TRY(prepare_T_bf16_rows_launch(e, lde, perm, E, planes, na, stream));
+  {
+    CGAT_PROF("edge_gw", stream);
+    const int nsteps = cdiv(E, 32);
+    if (bilinear_mode() == 6)
+      hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, gzb, (const uint4*)planes, slab,
+                         E, ncb, nsteps, S);
+    else
+      hipLaunchKernelGGL(edge_gw_kernel<3>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, gzb, (const uint4*)planes, slab,
+                         E, ncb, nsteps, S);
+    CGAT_LAUNCH_CHECK();
+  }
+  return splitk_reduce_launch(slab, S, W2, 128, out, ldo, stream);
 }

@@ -396,6 +396,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *d = s;
 }
 
+int splitk_reduce_launch(const float* slab, int splits, int M, int N, float* C, long ldc, hipStream_t stream, float alpha,
+                         float beta, const float* bias, int act) {
+  const long total = (long)M * N;
+  if (total <= 0) return CGAT_OK;
+  if (total < 256 * 1024 && splits >= 32)   // few outputs, many slabs: spread the slab loop over 8 threads
+    hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(256), 0, stream, slab, splits, M, N, C, ldc,
+                       alpha, beta, bias, act);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, stream, slab, splits, M, N, C, ldc,
+                       alpha, beta, bias, act);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 size_t gemm_ws_bytes(const GemmParams& p) { return p.splits > 1 ? ws_round((size_t)p.splits * p.M * p.N, 4) : 0; }
 
 // Chooses a split count for reductions with a long K and few output tiles.  Workgroups are
@@ -484,13 +498,7 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   CGAT_LAUNCH_CHECK();
   if (p.splits > 1) {
     long total = (long)p.M * p.N;
-    if (total < 256 * 1024 && p.splits >= 32)   // few outputs, many slabs: spread the slab loop over 8 threads
-      hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(cdiv(total, 32)), dim3(256), 0, stream, p.slab, p.splits, p.M,
-                         p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act);
-    else
-      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, stream, p.slab, p.splits, p.M,
-                         p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act);
-    CGAT_LAUNCH_CHECK();
+    CGAT_TRY(splitk_reduce_launch(p.slab, p.splits, p.M, p.N, p.C, p.ldc, stream, p.alpha, p.beta, p.bias, p.act));
   }
   return CGAT_OK;
 }

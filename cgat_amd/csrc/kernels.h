@@ -47,6 +47,9 @@ static inline GemmParams gemm_params(int M, int N, int K, const float* A, long l
 
 int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream);
 int gemm_pick_splits(int M, int N, int K);
+// C[m*ldc + n] = act(alpha * sum_z slab[z][m][n] + bias[n]) + beta * C   (fixed summation tree)
+int splitk_reduce_launch(const float* slab, int splits, int M, int N, float* C, long ldc, hipStream_t stream,
+                         float alpha = 1.f, float beta = 0.f, const float* bias = nullptr, int act = 0);
 size_t gemm_ws_bytes(const GemmParams& p);
 
 // ---- bilinear (hypernetwork) contractions, bilinear.hip ----
@@ -76,7 +79,13 @@ size_t edge_z_wq_floats(int W2);
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
+int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
+                               hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
+bool edge_gw_fast(int Ce, int W2, long gzb, const void* gZ);
+size_t edge_gw_ws_floats(int E, int W2);
+int edge_gw_launch(const float* gZ, long gzb, const float* e, long lde, const int* perm, int E, int W2, float* ws,
+                   float* out, long ldo, hipStream_t stream);
 bool edge_ge_fast(int Ce, int W2, long gzb, long ldo, const void* gZ, const void* out);
 int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* Wq, int W2, float* out, long ldo,
                    const int* scatter, int E, hipStream_t stream);

@@ -354,6 +354,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   float* Gi = c.take<float>((size_t)d.N * d.W2);
   float* Gj = c.take<float>((size_t)d.N * d.W2);
   float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
+  float* gw_ws = c.take<float>(edge_gw_ws_floats(d.E, d.W2));
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(const_cast<float*>(saved), d);
   const float invH = 1.f / d.H;
@@ -417,7 +418,10 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     g.c_scatter = plan->dst_perm;
     CGAT_TRY(c.gemm(g));
   }
-  {  // grad W_e = gZ^T @ e[perm]
+  // grad W_e = gZ^T @ e[perm]
+  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gzb, gZ)) {
+    RUN(edge_gw_launch(gZ, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
+  } else {
     GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = gzb;
     g.a_kmajor = 1; g.b_kmajor = 1;
