@@ -102,6 +102,9 @@ PROTOTYPES = {
     "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
+    "cgat_bilinear_dual_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgat_bilinear_dual": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, vp,
+                                     C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_size_t, vp]),
     "cgat_bilinear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, vp, C.c_size_t, vp]),

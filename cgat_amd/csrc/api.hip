@@ -178,6 +178,34 @@ extern "C" int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, voi
 }
 extern "C" void cgat_set_bilinear_mode(int32_t mode) { bilinear_set_mode(mode); }
 extern "C" int32_t cgat_get_bilinear_mode(void) { return bilinear_mode(); }
+extern "C" size_t cgat_bilinear_dual_workspace_bytes(int32_t rows) {
+  const size_t tq = ws_round((size_t)128 * 128 * 128 * 3 / 2 + 4, 4);
+  const size_t a = bilinear_dual_ws_bytes(rows), b = bilinear_rows_ws_bytes(rows, 128, 128, 128);
+  return tq + (a > b ? a : b) + 256;
+}
+extern "C" int cgat_bilinear_dual(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* zz, int64_t ldz,
+                                  const float* T, const float* init1, int64_t ldi1, float* out1, int64_t ldo1,
+                                  const float* init2, int64_t ldi2, float* out2, int64_t ldo2, int32_t rows, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(rows >= 0, "bilinear_dual: rows < 0");
+  if (ws_bytes < cgat_bilinear_dual_workspace_bytes(rows)) {
+    cgat_set_error("bilinear_dual: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  float* Tq = (float*)ws;
+  const size_t off = ws_round((size_t)128 * 128 * 128 * 3 / 2 + 4, 4);
+  void* rest = (char*)ws + off;
+  hipStream_t s = (hipStream_t)stream;
+  if (bilinear_dual_fast(128, 128, 128)) {
+    CGAT_TRY(bilinear_prepare_T(T, Tq, 128, 128, 128, 0, 1, 2, s));
+    return bilinear_dual_launch(p, ldp, q, ldq, zz, ldz, Tq, init1, ldi1, out1, ldo1, init2, ldi2, out2, ldo2, rows, rest,
+                                ws_bytes - off, s);
+  }
+  CGAT_TRY(bilinear_prepare_T(T, Tq, 128, 128, 128, 0, 1, 2, s));
+  CGAT_TRY(bilinear_rows_launch(p, ldp, q, ldq, Tq, init1, ldi1, out1, ldo1, rows, 128, 128, 128, rest, ws_bytes - off, s));
+  CGAT_TRY(bilinear_prepare_T(T, Tq, 128, 128, 128, 2, 1, 0, s));   // [c][b][a]: out2[n,a] = sum_{c,b} zz[c] q[b] T[a,b,c]
+  return bilinear_rows_launch(zz, ldz, q, ldq, Tq, init2, ldi2, out2, ldo2, rows, 128, 128, 128, rest, ws_bytes - off, s);
+}
 extern "C" size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
   return ws_round((size_t)NA * NB * NC * 3 / 2 + 4, 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
 }

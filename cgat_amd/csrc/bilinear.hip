@@ -385,6 +385,227 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two gradients from one contraction (hypernetwork backward, reference Hypernetworksmp.py:77-83 under autograd):
+//     out1[n,c] = init1[n,c] + sum_a p[n,a] * M[n,a,c]              M[n,a,c] = sum_b q[n,b] T[a,b,c]
+//     dv  [n,a] =              sum_c zz[n,c] * M[n,a,c]
+// With T[a=i][b=o][c=k] = head_w[o,i,k], p = v (layer input), q = g (gradient of the layer's pre-norm output) and
+// zz = z (trunk output), out1 is the gradient wrt z and dv the bilinear part of the gradient wrt v: the scale-after
+// kernel already holds M[n,a,:] in its partial accumulators when it finishes an `a`, so the second gradient is one
+// more multiply-add per accumulator register and a 4-lane reduction -- instead of a second 350-GFLOP launch.
+// Layout differences from bilinear_rows128_ring16_kernel: zz must stay in registers (32 VGPRs per 64 columns), so
+// a wave owns 32 rows x 64 columns and the eight waves of a workgroup are 4 row groups x 2 column halves (128
+// rows); a ring slot holds one 32-deep k-step of BOTH column halves (two 12-KB pieces of the prepared T), every
+// wave reads its own half.  dv comes out as two partial sums per row (one per column half) in dvp[half][n][a].
+template <int PASSES>
+__global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
+    const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const float* __restrict__ zz, long ldz,
+    const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
+    float* __restrict__ dvp, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io) {
+  constexpr int CH16 = 2 * 3 * 4 * 64;          // 16-byte pieces per ring slot = 24 KB: [half][plane][cb][lane]
+  constexpr int PST = 8 * 64;
+  __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int rg = wave & 3, hf = wave >> 2;      // row group, column half
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
+  const int row_w = tile * 128 + rg * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;
+  const long rowc_a = row_a < nrows ? row_a : nrows - 1, rowc_b = row_b < nrows ? row_b : nrows - 1;
+  const int row_st = row_w + (lane & 31);
+  const long rowc_st = row_st < nrows ? row_st : nrows - 1;
+  if (asplit > 1) {
+    out += (long)split * slab_stride;
+    if (split > 0) init = nullptr;
+  }
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + hf * 768 + lane;
+  const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
+  p += (long)tile * 128 * ldp;
+  const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 128) * ldp * 4);
+  const unsigned l_off = (unsigned)lane * 16;
+  const long last_step = (long)a_end * 4 - 1;
+  // the three 1-KB pieces this wave moves per k-step: piece index P = 64 wave + 512 i of the [half0 | half1] image
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the LDS-DMA base pointers must be SGPRs
+  const int P0 = 64 * wave_u, P1 = 64 * wave_u + 512, P2 = 64 * wave_u + 1024;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + (unsigned)P0 * 16);
+
+  bf16x8 q1[8], q2[8], q3[8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+      const float4 t0 = qp[0], t1 = qp[1];
+      const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 x1, x2, x3;
+        split3_bf16(v[j], x1, x2, x3);
+        q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
+      }
+    }
+  // acc[2 cb + nb][j] = out[row(nb)][64 hf + 16 cb + 4 kg + j];  zr the same elements of zz
+  f32x4 acc[8], zr[8];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = nb ? row_b : row_a;
+      const long rowc = nb ? rowc_b : rowc_a;
+      const int col = 64 * hf + 16 * cb + 4 * kg;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (init && row < nrows) {
+        const float* ip = init + (long)row * ldi + col;
+        if (vec_io) v = *reinterpret_cast<const float4*>(ip);
+        else v = make_float4(ip[0], ip[1], ip[2], ip[3]);
+      }
+      acc[2 * cb + nb] = f32x4{v.x, v.y, v.z, v.w};
+      const float* zp = zz + rowc * ldz + col;
+      zr[2 * cb + nb] = f32x4{zp[0], zp[1], zp[2], zp[3]};
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define DU_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_step ? (gi_) : last_step;                                     \
+    const long a_ = gi >> 2, s_ = gi & 3;                                                      \
+    const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * 768;                                      \
+    const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * 768;                                      \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    glds_b128(h0 + P0, l_off, dst);                                                            \
+    glds_b128(P1 < 768 ? h0 + P1 : h1 + (P1 - 768), l_off, dst + 8192);                        \
+    glds_b128(h1 + (P2 - 768), l_off, dst + 16384);                                            \
+  }
+#define DU_PLOAD(a_)                                                                           \
+  {                                                                                            \
+    const int aa = (a_) < a_end ? (a_) : a_end - 1;                                            \
+    glds_b32(p + aa, prow_off, wave_p + (unsigned)((a_) & 3) * (PST * 4));                     \
+  }
+  DU_PLOAD(a_beg);
+  DU_PLOAD(a_beg + 1);
+  DU_TLOAD((long)a_beg * 4 + 0);
+  DU_TLOAD((long)a_beg * 4 + 1);
+  DU_TLOAD((long)a_beg * 4 + 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+#define DU_READ(F1_, F2_, F3_, slot_, cb_)                                                     \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[4 * 64];                                                                          \
+    if (PASSES >= 6) F3_ = fp[8 * 64];                                                         \
+  }
+#define DU_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
+  {                                                                                            \
+    if (PASSES >= 6) {                                                                         \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
+      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+    }                                                                                          \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
+    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+  }
+#define DU_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
+  {                                                                                            \
+    DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                 \
+    DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
+  }
+  DU_READ(fa1, fa2, fa3, 0, 0);
+  f32x4 part[8];
+  const int dv_a = (int)(((long)hf * nrows + rowc_a) * NA);   // 32-bit offsets: the launcher checks 2 nrows NA < 2^31
+  const int dv_b = (int)(((long)hf * nrows + rowc_b) * NA);
+  for (int a = a_beg; a < a_end; ++a) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                // k-step (a, s) sits in ring slot s
+      if (s == 0) DU_PLOAD(a + 2);
+      DU_TLOAD((long)a * 4 + s + 3);
+#pragma unroll
+      for (int cbp = 0; cbp < 2; ++cbp) {
+        DU_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        DU_MFMA(fa1, fa2, fa3, s, 2 * cbp);
+        if (cbp == 0) DU_READ(fa1, fa2, fa3, s, 2)
+        else DU_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DU_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
+      }
+      if (s == 3) {
+        // part = (-1)^a M[n,a,:] (the prepared T alternates in sign): scale-after flush and the second gradient
+        const float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
+        const float sg = (a & 1) ? -1.f : 1.f;
+        const float pas_a = sg * pva, pas_b = sg * pvb;
+        float da = 0.f, db = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[2 * cb + 0][t] = fmaf(pas_a, part[2 * cb + 0][t], acc[2 * cb + 0][t]);
+            acc[2 * cb + 1][t] = fmaf(pas_b, part[2 * cb + 1][t], acc[2 * cb + 1][t]);
+            da = fmaf(part[2 * cb + 0][t], zr[2 * cb + 0][t], da);
+            db = fmaf(part[2 * cb + 1][t], zr[2 * cb + 1][t], db);
+          }
+        asm volatile("" : "+v"(da));             // keep the two sums out of v_pk_* (note in edgez.hip)
+        asm volatile("" : "+v"(db));
+        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        if (kg == 0) {
+          if (row_a < nrows) dvp[dv_a + a] = sg * da;
+          if (row_b < nrows) dvp[dv_b + a] = sg * db;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef DU_TLOAD
+#undef DU_PLOAD
+#undef DU_READ
+#undef DU_MFMA1
+#undef DU_MFMA
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = nb ? row_b : row_a;
+      if (row < nrows) {
+        float* op = out + (long)row * ldo + 64 * hf + 16 * cb + 4 * kg;
+        const f32x4 v = acc[2 * cb + nb];
+        if (vec_io) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+      }
+    }
+}
+
+// out1 = sum of the a-split slabs (if any); out2[n,a] = init2[n,a] + dvp[0][n,a] + dvp[1][n,a]
+__global__ void dual_finish_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
+                                   float* __restrict__ out1, long ldo1, const float* __restrict__ dvp,
+                                   const float* __restrict__ init2, long ldi2, float* __restrict__ out2, long ldo2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nrows * 128) return;
+  const long n = i >> 7;
+  const int c = (int)(i & 127);
+  if (splits > 1) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(long)z * slab_stride + i];
+    out1[n * ldo1 + c] = s;
+  }
+  float d = init2 ? init2[n * ldi2 + c] : 0.f;
+  d += dvp[i];
+  d += dvp[(long)nrows * 128 + i];
+  out2[n * ldo2 + c] = d;
+}
+
 // sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
 // (layout in the header above); element (a, b, c) of the [NA,128,128] operand is src[a*sa + b*sb + c*sc].
 __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int NA, long sa, long sb,
@@ -538,6 +759,50 @@ size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
 }
 
 // T must come from bilinear_prepare_T (interleaved columns iff bilinear_T_interleaved(NB, NC))
+// ---- fused pair of contractions (see bilinear_rows128_dual_kernel); widths 128, split-bf16 modes only ----
+bool bilinear_dual_fast(int NA, int NB, int NC) {
+  return bilinear_mode() != 0 && NA == 128 && NB == 128 && NC == 128 && !force_generic();
+}
+size_t bilinear_dual_ws_bytes(int nrows) {
+  const int sp = rows_asplit(nrows, 128);
+  return ws_round((size_t)2 * nrows * 128 + (sp > 1 ? (size_t)sp * nrows * 128 : 0), 4);
+}
+// T: bilinear_prepare_T of the [NA,128,128] operand.  out1 = init1 + sum_a p[:,a] M[:,a,:], out2 = init2 + M . zz
+int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
+                         const float* init1, long ldi1, float* out1, long ldo1, const float* init2, long ldi2,
+                         float* out2, long ldo2, int nrows, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (nrows <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG((ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)T) & 15) == 0 && ldp < (1l << 22) &&
+                     (long)nrows * 256 < (1l << 31),
+                 "bilinear_dual: q and T must be 16-byte aligned with ldq %% 4 == 0, nrows < 2^23");
+  const int tiles = cdiv(nrows, 128);
+  const int sp = rows_asplit(nrows, 128);
+  if (!ws || ws_bytes < bilinear_dual_ws_bytes(nrows)) {
+    cgat_set_error("bilinear_dual: workspace too small (%zu < %zu)", ws_bytes, bilinear_dual_ws_bytes(nrows));
+    return CGAT_ERR_WORKSPACE;
+  }
+  float* dvp = (float*)ws;
+  float* slab = dvp + (size_t)2 * nrows * 128;
+  float* dst = sp > 1 ? slab : out1;
+  const long dld = sp > 1 ? 128 : ldo1, stride = sp > 1 ? (long)nrows * 128 : 0;
+  const int vec_io = ((dld % 4) == 0 && (((uintptr_t)dst) & 15) == 0 &&
+                      (!init1 || ((ldi1 % 4) == 0 && (((uintptr_t)init1) & 15) == 0))) ? 1 : 0;
+  {
+    CGAT_PROF("bilinear_rows", stream);
+    if (bilinear_mode() == 6)
+      hipLaunchKernelGGL((bilinear_rows128_dual_kernel<6>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, nrows, 128, tiles, sp, stride, vec_io);
+    else
+      hipLaunchKernelGGL((bilinear_rows128_dual_kernel<3>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, nrows, 128, tiles, sp, stride, vec_io);
+    CGAT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv((long)nrows * 128, 256)), dim3(256), 0, stream, slab, sp, stride, nrows,
+                     out1, ldo1, dvp, init2, ldi2, out2, ldo2);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
                          long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
                          hipStream_t stream) {

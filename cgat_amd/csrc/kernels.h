@@ -65,6 +65,12 @@ size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
                          long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
                          hipStream_t stream);
+// fused pair (bilinear.hip, bilinear_rows128_dual_kernel): T = bilinear_prepare_T of the [128,128,128] operand
+bool bilinear_dual_fast(int NA, int NB, int NC);
+size_t bilinear_dual_ws_bytes(int nrows);
+int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
+                         const float* init1, long ldi1, float* out1, long ldo1, const float* init2, long ldi2,
+                         float* out2, long ldo2, int nrows, void* ws, size_t ws_bytes, hipStream_t stream);
 // out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c]      (workspace: slabs)
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,

@@ -55,6 +55,14 @@ struct Ctx {
     if (dry) return CGAT_OK;
     return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, scratch, scratch_bytes, s);
   }
+  int dual(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
+           const float* init1, long ldi1, float* out1, long ldo1, const float* init2, long ldi2, float* out2, long ldo2,
+           int rows) {
+    need(bilinear_dual_ws_bytes(rows));
+    if (dry) return CGAT_OK;
+    return bilinear_dual_launch(p, ldp, q, ldq, zz, ldz, T, init1, ldi1, out1, ldo1, init2, ldi2, out2, ldo2, rows,
+                                scratch, scratch_bytes, s);
+  }
   int mix_bwd(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb, float* gd, long n) {
     need(4096);
     if (dry) return CGAT_OK;
@@ -623,16 +631,22 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g));
     }
-    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 1, 2, c.s));
-    CGAT_TRY(c.bilinear(gu, W, vin, W, Tp, g_t, W, g_t, W, rows, W, W, W));
-    // ---- g_vin = gu @ Bm + sum_{o,k} gu[o] z[k] T[o,i,k]   (T re-laid as [o,k,i]) ----
+    // ---- g_vin = gu @ Bm + sum_{o,k} gu[o] z[k] T[o,i,k] ----
     {
       GemmParams g = gemm_params(rows, W, W, gu, W, L.head_b, W, g_vin, W);
       g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g));
     }
-    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 2, 1, c.s));
-    CGAT_TRY(c.bilinear(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W));
+    if (bilinear_dual_fast(W, W, W)) {
+      // both bilinear parts from one contraction: M[n,i,k] = sum_o gu[o] T[o,i,k];  g_z += vin . M,  g_vin += M . z
+      RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 1, 0, 2, c.s));   // operand [a = i][b = o][c = k]
+      CGAT_TRY(c.dual(vin, W, gu, W, z, W, Tp, g_t, W, g_t, W, g_vin, W, g_vin, W, rows));
+    } else {
+      RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 1, 2, c.s));
+      CGAT_TRY(c.bilinear(gu, W, vin, W, Tp, g_t, W, g_t, W, rows, W, W, W));
+      RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 2, 1, c.s));   // T re-laid as [o,k,i]
+      CGAT_TRY(c.bilinear(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W));
+    }
     // ---- trunk backward (g_t holds the gradient wrt the trunk output z) ----
     for (int s = p->n_fc - 1; s >= 0; --s) {
       const float* tout = c.dry ? nullptr : sv.act(l, s);

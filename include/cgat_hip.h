@@ -193,9 +193,19 @@ size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, 
 int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T, const float* init,
                        int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA, int32_t NB, int32_t NC,
                        void* ws, size_t ws_bytes, void* stream);
-/* Arithmetic of the width-128 trilinear contractions: 0 = f32-input MFMA (exact fp32 fmaf chains, default),
- * 6 = operands split into three bf16 pieces, six bf16-MFMA passes with fp32 accumulation (measured
- * fp32-equivalent accuracy, 2.67x higher matrix-core ceiling), 3 = three passes (~4e-6 relative). */
+/* Two gradients of the hypernetwork's trilinear form from ONE contraction (backward of reference
+ * Hypernetworksmp.py:77-83, HyperLinear.forward; widths fixed at 128):
+ *   out1[n,c] = init1[n,c] + sum_{a,b} p[n,a] q[n,b] T[(a*128+b)*128 + c]
+ *   out2[n,a] = init2[n,a] + sum_{b,c} zz[n,c] q[n,b] T[(a*128+b)*128 + c]
+ * (init1/init2 may be NULL or alias their outputs).  In the f32 arithmetic mode it runs as two contractions. */
+size_t cgat_bilinear_dual_workspace_bytes(int32_t rows);
+int cgat_bilinear_dual(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* zz, int64_t ldz,
+                       const float* T, const float* init1, int64_t ldi1, float* out1, int64_t ldo1, const float* init2,
+                       int64_t ldi2, float* out2, int64_t ldo2, int32_t rows, void* ws, size_t ws_bytes, void* stream);
+/* Arithmetic of the width-128 trilinear contractions: 0 = f32-input MFMA (exact fp32 fmaf chains),
+ * 6 (default) = operands split into three bf16 pieces, six bf16-MFMA passes with fp32 accumulation (measured
+ * fp32-equivalent accuracy, 2.67x higher matrix-core ceiling), 3 = three passes (~4e-6 relative).  The mode also
+ * selects the split-bf16 edge kernels (edgez.hip, edgebwd.hip) over the f32 GEMM engine. */
 void cgat_set_bilinear_mode(int32_t mode);
 int32_t cgat_get_bilinear_mode(void);
 /* out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c] */

@@ -160,6 +160,41 @@ def test_bilinear_rows(env, W, rows, with_init, mode):
     assert rel(out[sel], ref) <= TOL
 
 
+@pytest.mark.parametrize("rows", [1, 127, 128, 300, 1000, 83340])
+@pytest.mark.parametrize("with_init", [False, True])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3"])
+def test_bilinear_dual(env, rows, with_init, mode):
+    """The fused pair of hypernetwork gradients (one contraction, two outputs) against fp64 einsums; the f32 mode
+    runs the same entry point as two contractions."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode(mode)
+    W = 128
+    g = torch.Generator().manual_seed(7 * rows + 1)
+    p, q, z = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))
+    T = (torch.randn(W, W, W, generator=g) / W).to(dev)
+    i1 = torch.randn(rows, W, generator=g).to(dev) if with_init else None
+    i2 = torch.randn(rows, W, generator=g).to(dev) if with_init else None
+    o1 = torch.full((rows, W), float("nan"), device=dev)
+    o2 = torch.full((rows, W), float("nan"), device=dev)
+    sel = torch.arange(rows) if rows <= 5000 else torch.cat([torch.arange(160), torch.arange(rows - 160, rows),
+                                                             torch.randint(0, rows, (320,), generator=g)])
+    M = torch.einsum("nb,abc->nac", q[sel].double(), T.double())
+    r1 = torch.einsum("na,nac->nc", p[sel].double(), M)
+    r2 = torch.einsum("nc,nac->na", z[sel].double(), M)
+    if with_init:
+        r1, r2 = r1 + i1[sel].double(), r2 + i2[sel].double()
+    ws = torch.empty(max(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), 256), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, q.data_ptr(), W, z.data_ptr(), W, T.data_ptr(),
+                                           None if i1 is None else i1.data_ptr(), W, o1.data_ptr(), W,
+                                           None if i2 is None else i2.data_ptr(), W, o2.data_ptr(), W, rows,
+                                           ws.data_ptr(), ws.numel(), None), "bilinear_dual")
+    torch.cuda.synchronize()
+    ops.set_bilinear_mode("bf16x6")
+    assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+    assert rel(o1[sel], r1) <= TOL
+    assert rel(o2[sel], r2) <= TOL
+
+
 @pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45), (128, 33), (128, 20001)])
 @pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3"])
 def test_bilinear_wgrad(env, W, rows, mode):
