@@ -632,30 +632,38 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
 // Row-gathered variant for operands whose k index is a row number: element (a, b, c) = rows[gather[128 a + b]][c]
 // for 128 a + b < nrows, zero beyond (the last block is padded).
 __global__ void prepare_T_bf16_rows_kernel(const float* __restrict__ rows, long ld, const int* __restrict__ gather,
-                                           int nrows, __bf16* __restrict__ dst, int NA) {
+                                           int nrows, uint4* __restrict__ dst, int NA) {
+  // one thread per 16-byte fragment piece: (a, k-step s, kg, column c) -> the 8 rows t = 128 a + 32 s + 8 kg + j of
+  // column c; lanes run over c, so the eight row reads are coalesced and the three stores are 16 B at 16-B pitch
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)NA * 128 * 128) return;
-  const int a = (int)(i >> 14), b = (int)((i >> 7) & 127), c = (int)(i & 127);
-  const long t = (long)a * 128 + b;
-  float v = 0.f;
-  if (t < nrows) v = rows[(gather ? (long)gather[t] : t) * ld + c];
-  __bf16 x1, x2, x3;
-  split3_bf16(v, x1, x2, x3);
+  if (i >= (long)NA * 16 * 128) return;
+  const int c = (int)(i & 127), kg = (int)((i >> 7) & 3), s = (int)((i >> 9) & 3);
+  const long a = i >> 11;
+  const long t0 = a * 128 + 32 * s + 8 * kg;
+  bf16x8 x1, x2, x3;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long t = t0 + j;
+    float v = 0.f;
+    if (t < nrows) v = rows[(gather ? (long)gather[t] : t) * ld + c];
+    __bf16 y1, y2, y3;
+    split3_bf16(v, y1, y2, y3);
+    x1[j] = y1; x2[j] = y2; x3[j] = y3;
+  }
   const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
-  const int kh = b >> 6, s2 = (b >> 5) & 1, kg = (b & 31) >> 3, j = b & 7;
-  const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * 3;
-  const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
-  dst[(blk + 0) * 2048 + in] = x1;
-  dst[(blk + 1) * 2048 + in] = x2;
-  dst[(blk + 2) * 2048 + in] = x3;
+  const long blk = ((a * 2 + half) * 4 + s) * 3;          // planes of one k-step, each [cb][kg][i] x 16 bytes
+  const long in = ((long)cb * 4 + kg) * 16 + i16;
+  dst[(blk + 0) * 256 + in] = __builtin_bit_cast(uint4, x1);
+  dst[(blk + 1) * 256 + in] = __builtin_bit_cast(uint4, x2);
+  dst[(blk + 2) * 256 + in] = __builtin_bit_cast(uint4, x3);
 }
 
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream) {
-  long total = (long)NA * 128 * 128;
+  long total = (long)NA * 16 * 128;
   if (total <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_T_bf16_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, rows, ld, gather, nrows,
-                     (__bf16*)dst, NA);
+                     (uint4*)dst, NA);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -13,18 +13,20 @@
 // Wq: prepare_T_bf16 planes of the operand (a = 128-column block of gZ, b = column in block, c = output) =
 // W_e[128 a + b][c]; chunk (a, half, s) = 12 KB at Wq + ((a*2 + half)*4 + s) * 768 uint4.
 template <int PASSES>
-__global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long gzb,
+__global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Wq, int ncb,
                                                          float* __restrict__ out, long ldo,
-                                                         const int* __restrict__ scatter, int E) {
+                                                         const int* __restrict__ scatter, int E, int accumulate) {
   __shared__ uint4 Bs[2][1536];                  // [buffer][half][plane][cb][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
   const int row_w = blockIdx.x * 256 + wave * 32;
   const int row_a = row_w + n16, row_b = row_a + 16;
   const long rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
-  const float* ga = gZ + rca * 128 + 8 * kg;     // + a * gzb + 32 s
-  const float* gb = gZ + rcb * 128 + 8 * kg;
+  // element (t, 128 a + j) of the operand lives at gZ[t * ldg + a * gzb + j]: (ldg, gzb) = (128, E * 128) for the
+  // column-blocked gZ, (W2, 128) for a plain row-major matrix
+  const float* ga = gZ + rca * ldg + 8 * kg;     // + a * gzb + 32 s
+  const float* gb = gZ + rcb * ldg + 8 * kg;
   const int nk = ncb * 4;
 
   f32x4 acc[16];
@@ -126,11 +128,17 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   for (int g = 0; g < 8; ++g) {
     if (row_a < E) {
       const f32x4 v = acc[2 * g + 0];
-      *reinterpret_cast<float4*>(out + oa * ldo + 16 * g + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
+      float4* o = reinterpret_cast<float4*>(out + oa * ldo + 16 * g + 4 * kg);
+      float4 w = make_float4(v[0], v[1], v[2], v[3]);
+      if (accumulate) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }
+      *o = w;
     }
     if (row_b < E) {
       const f32x4 v = acc[2 * g + 1];
-      *reinterpret_cast<float4*>(out + ob * ldo + 16 * g + 4 * kg) = make_float4(v[0], v[1], v[2], v[3]);
+      float4* o = reinterpret_cast<float4*>(out + ob * ldo + 16 * g + 4 * kg);
+      float4 w = make_float4(v[0], v[1], v[2], v[3]);
+      if (accumulate) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }
+      *o = w;
     }
   }
 }
@@ -156,7 +164,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 template <int PASSES>
-__global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long gzb,
+__global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Eq, float* __restrict__ slab,
                                                          int E, int ncb, int nsteps, int S) {
   constexpr int FLUSH = 64;
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   {                                                                                                      \
     const int idx = gt + 256 * (i_);                                                                     \
     const long t = (long)(ks_) * 32 + (idx >> 5);                                                        \
-    R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * 128 + 4 * (idx & 31))                       \
+    R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * ldg + 4 * (idx & 31))                       \
                : make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
   }
 #define GW_GLOAD(ks_, A_, B_, C_, D_) { GW_G1(ks_, 0, A_) GW_G1(ks_, 1, B_) GW_G1(ks_, 2, C_) GW_G1(ks_, 3, D_) }
@@ -324,14 +332,14 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
 #undef GW_FLUSH
 }
 
-bool edge_ge_fast(int Ce, int W2, long gzb, long ldo, const void* gZ, const void* out) {
-  return bilinear_mode() != 0 && Ce == 128 && W2 % 128 == 0 && gzb != 0 && (gzb % 4) == 0 && (ldo % 4) == 0 &&
-         ((((uintptr_t)gZ) | ((uintptr_t)out)) & 15) == 0;
+bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out) {
+  return bilinear_mode() != 0 && Ce == 128 && W2 % 128 == 0 && gzb != 0 && (gzb % 4) == 0 && (ldg % 4) == 0 &&
+         (ldo % 4) == 0 && ((((uintptr_t)gZ) | ((uintptr_t)out)) & 15) == 0;
 }
 
 // We: element (col, k) at We[col * ldw + k] (col < W2, k < 128).  Wq: edge_z_wq_floats(W2) floats of workspace.
-int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* Wq, int W2, float* out, long ldo,
-                   const int* scatter, int E, hipStream_t stream) {
+int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long ldw, float* Wq, int W2, float* out,
+                   long ldo, const int* scatter, int E, int accumulate, hipStream_t stream) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * ldw + c]
@@ -339,17 +347,18 @@ int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* 
   CGAT_PROF("edge_ge", stream);
   const int grid = cdiv(E, 256);
   if (bilinear_mode() == 6)
-    hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E);
+    hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
+                       scatter, E, accumulate);
   else
-    hipLaunchKernelGGL(edge_ge_kernel<3>, dim3(grid), dim3(512), 0, stream, gZ, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E);
+    hipLaunchKernelGGL(edge_ge_kernel<3>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
+                       scatter, E, accumulate);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
 
-bool edge_gw_fast(int Ce, int W2, long gzb, const void* gZ) {
-  return bilinear_mode() != 0 && Ce == 128 && W2 % 256 == 0 && gzb != 0 && (gzb % 4) == 0 && (((uintptr_t)gZ) & 15) == 0;
+bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ) {
+  return bilinear_mode() != 0 && Ce == 128 && W2 % 256 == 0 && gzb != 0 && (gzb % 4) == 0 && (ldg % 4) == 0 &&
+         (((uintptr_t)gZ) & 15) == 0;
 }
 static int edge_gw_splits(int W2) {   // ranges x column-block pairs ~ one workgroup per CU
   const int npair = W2 / 256;
@@ -362,9 +371,9 @@ size_t edge_gw_ws_floats(int E, int W2) {
   return planes + (size_t)edge_gw_splits(W2) * W2 * 128 + 64;
 }
 
-// out[col * ldo + k] = sum_t gZ[t, col] * e[perm[t] * lde + k]
-int edge_gw_launch(const float* gZ, long gzb, const float* e, long lde, const int* perm, int E, int W2, float* ws,
-                   float* out, long ldo, hipStream_t stream) {
+// out[col * ldo + k] = sum_t G[t, col] * e[perm[t] * lde + k],   G[t, 128 a + j] at gZ[t * ldg + a * gzb + j]
+int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
+                   float* ws, float* out, long ldo, hipStream_t stream) {
   if (E <= 0) {
     GemmParams z = gemm_params(W2, 128, 0, nullptr, 1, nullptr, 1, out, ldo);
     return gemm_launch(z, nullptr, 0, stream);   // K = 0: zero fill
@@ -378,11 +387,11 @@ int edge_gw_launch(const float* gZ, long gzb, const float* e, long lde, const in
     CGAT_PROF("edge_gw", stream);
     const int nsteps = cdiv(E, 32);
     if (bilinear_mode() == 6)
-      hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, gzb, (const uint4*)planes, slab,
-                         E, ncb, nsteps, S);
+      hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
+                         slab, E, ncb, nsteps, S);
     else
-      hipLaunchKernelGGL(edge_gw_kernel<3>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, gzb, (const uint4*)planes, slab,
-                         E, ncb, nsteps, S);
+      hipLaunchKernelGGL(edge_gw_kernel<3>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
+                         slab, E, ncb, nsteps, S);
     CGAT_LAUNCH_CHECK();
   }
   return splitk_reduce_launch(slab, S, W2, 128, out, ldo, stream);

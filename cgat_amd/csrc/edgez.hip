@@ -26,7 +26,7 @@
 #include "kernels.h"
 #include "mfma_bf16.h"
 
-template <int PASSES>
+template <int PASSES, bool ADDS>
 __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict__ e, long lde,
                                                         const int* __restrict__ perm, const uint4* __restrict__ Wq,
                                                         int ncb, const float* __restrict__ Pi,
@@ -67,10 +67,12 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         }
       }
   }
-  const float* pia = Pi + (long)dsti[rca] * ld_add;
-  const float* pib = Pi + (long)dsti[rcb] * ld_add;
-  const float* pja = Pj + (long)srci[rca] * ld_add;
-  const float* pjb = Pj + (long)srci[rcb] * ld_add;
+  // ADDS: gathered addends Pi[dst], Pj[src] (the edge kernel).  !ADDS: a plain product plus bias, Pi = the bias
+  // vector or null (the per-node projections x W_i^T + b and x W_j^T, same kernel with e = x)
+  const float* pia = ADDS ? Pi + (long)dsti[rca] * ld_add : Pi;
+  const float* pib = ADDS ? Pi + (long)dsti[rcb] * ld_add : Pi;
+  const float* pja = ADDS ? Pj + (long)srci[rca] * ld_add : nullptr;
+  const float* pjb = ADDS ? Pj + (long)srci[rcb] * ld_add : nullptr;
   float* za = Z + (long)rca * ldz;
   float* zb = Z + (long)rcb * ldz;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -148,10 +150,11 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 #pragma unroll
       for (int c16 = 0; c16 < 4; ++c16) {
         const int col = col0 + 16 * c16;
-        const float4 ia = *reinterpret_cast<const float4*>(pia + col);
-        const float4 ja = *reinterpret_cast<const float4*>(pja + col);
-        const float4 ib = *reinterpret_cast<const float4*>(pib + col);
-        const float4 jb = *reinterpret_cast<const float4*>(pjb + col);
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ia = (ADDS || pia) ? *reinterpret_cast<const float4*>(pia + col) : zero4;
+        const float4 ja = ADDS ? *reinterpret_cast<const float4*>(pja + col) : zero4;
+        const float4 ib = ADDS ? *reinterpret_cast<const float4*>(pib + col) : ia;
+        const float4 jb = ADDS ? *reinterpret_cast<const float4*>(pjb + col) : zero4;
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
         const float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
         const float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
@@ -199,6 +202,8 @@ bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz,
 size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
 
 // We: the edge_attr slice of the stacked first-layer weight, element (out, k) at We[out * ldw + k].
+// With Pj == nullptr the kernel computes the plain product Z = e We^T + bias (Pi = bias vector or nullptr, no logits):
+// the per-node projections of the operand split.
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream) {
@@ -208,12 +213,13 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
   CGAT_PROF("edge_z", stream);
   const int grid = cdiv(E, 128);
-  if (bilinear_mode() == 6)
-    hipLaunchKernelGGL(edge_z_kernel<6>, dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi, dsti,
-                       Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
-  else
-    hipLaunchKernelGGL(edge_z_kernel<3>, dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi, dsti,
-                       Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
+#define EZ_GO(P_, A_)                                                                                                \
+  hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
+  const bool adds = Pj != nullptr;
+  if (bilinear_mode() == 6) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
+  else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }
+#undef EZ_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

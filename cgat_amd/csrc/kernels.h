@@ -88,13 +88,14 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
-bool edge_gw_fast(int Ce, int W2, long gzb, const void* gZ);
+// operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
+bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);
 size_t edge_gw_ws_floats(int E, int W2);
-int edge_gw_launch(const float* gZ, long gzb, const float* e, long lde, const int* perm, int E, int W2, float* ws,
-                   float* out, long ldo, hipStream_t stream);
-bool edge_ge_fast(int Ce, int W2, long gzb, long ldo, const void* gZ, const void* out);
-int edge_ge_launch(const float* gZ, long gzb, const float* We, long ldw, float* Wq, int W2, float* out, long ldo,
-                   const int* scatter, int E, hipStream_t stream);
+int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
+                   float* ws, float* out, long ldo, hipStream_t stream);
+bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
+int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long ldw, float* Wq, int W2, float* out,
+                   long ldo, const int* scatter, int E, int accumulate, hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

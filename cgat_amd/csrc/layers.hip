@@ -300,7 +300,12 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
 
   CGAT_TRY(stack_in_weights(c, p, d, Wcat, bcat));
   // first conv layer split by operand: W_in [x_i;e;x_j] = W_i x_i + W_e e + W_j x_j
-  {
+  if (!c.dry && d.N > 0 && edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Pi, Pj, Pi, bcat)) {
+    RUN(edge_z_launch(x, d.C, nullptr, Wcat, d.D, Wq, d.W2, bcat, nullptr, nullptr, nullptr, 0, Pi, d.W2, d.N, nullptr,
+                      nullptr, d.H, d.Hd, nullptr, c.s));
+    RUN(edge_z_launch(x, d.C, nullptr, Wcat + d.C + d.Ce, d.D, Wq, d.W2, nullptr, nullptr, nullptr, nullptr, 0, Pj, d.W2,
+                      d.N, nullptr, nullptr, d.H, d.Hd, nullptr, c.s));
+  } else {
     GemmParams g = gemm_params(d.N, d.W2, d.C, x, d.C, Wcat, d.D, Pi, d.W2);
     g.bias = bcat;
     CGAT_TRY(c.gemm(g));
@@ -417,8 +422,8 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
-  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gzb, d.Ce, gZ, g_e)) {
-    RUN(edge_ge_launch(gZ, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, c.s));
+  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
+    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, c.s));
   } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = gzb;
@@ -427,8 +432,8 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     CGAT_TRY(c.gemm(g));
   }
   // grad W_e = gZ^T @ e[perm]
-  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gzb, gZ)) {
-    RUN(edge_gw_launch(gZ, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
+  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
+    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
   } else {
     GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = gzb;
@@ -439,7 +444,16 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   // segment sum of gZ by source (x_j side); the destination side came out of the fused kernel
   RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
                       c.s, gzb));
-  {
+  // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
+  // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
+  // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
+  if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
+      ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
+    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, c.s));
+    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, c.s));
+    RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s));
+    RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s));
+  } else {
     GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
     g.b_kmajor = 1;
     CGAT_TRY(c.gemm(g));
