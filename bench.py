@@ -154,36 +154,54 @@ def main():
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        n_l, ms_l = ops.prof_get("bilinear_rows")
-        flops_per_launch = 2.0 * N * C_FEA ** 3           # 2*C^3 flop per row (C*(C*C)*2)
-        roof = None
-        if n_l:
-            avg_ms = ms_l / n_l
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            mode = P.get_bilinear_mode()
-            if mode == "f32":
-                peak, kname = MFMA_F32_PEAK_TFLOPS, "bilinear_rows128_kernel"
-                note = "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32"
-            else:
-                passes = 6 if mode == "bf16x6" else 3
-                peak, kname = MFMA_BF16_PEAK_TFLOPS / passes, "bilinear_rows128_bf16_kernel"
-                note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_32x32x16_bf16 passes per product, fp32 "
-                        f"accumulate (measured fp32-equivalent accuracy): executed MFMA flop = {passes} x algorithmic, so the "
-                        f"roof for ALGORITHMIC flop is the dense bf16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {passes}; the "
-                        f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
-            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
-                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": n_l / args.steps, "avg_launch_ms": round(avg_ms, 4),
-                    "flops_per_launch": flops_per_launch, "arithmetic": note}
-        shares = {}
-        for tag in ("bilinear_rows", "bilinear_wgrad", "gemm_f32"):
+        # The three hypernetwork contraction kernels execute 2*N*C^3 flop per launch each (C*(C*C)*2
+        # per row; the fused backward kernel produces two gradients from ONE such contraction, so it is priced at
+        # what it executes, not at the two contractions the reference's autograd performs).  The roofline object is
+        # for the one with the largest share of the step.
+        flops_per_launch = 2.0 * N * C_FEA ** 3
+        mode = P.get_bilinear_mode()
+        kernels = {"bilinear_wgrad": "bilinear_wgrad128_bf16_kernel", "bilinear_dual": "bilinear_rows128_dual_kernel",
+                   "bilinear_rows": "bilinear_rows128_ring16_kernel"}
+        if mode == "f32":
+            kernels = {"bilinear_wgrad": "bilinear_wgrad128_kernel", "bilinear_rows": "bilinear_rows128_kernel"}
+            peak = MFMA_F32_PEAK_TFLOPS
+            note = "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32"
+        else:
+            passes = 6 if mode == "bf16x6" else 3
+            peak = MFMA_BF16_PEAK_TFLOPS / passes
+            note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_16x16x32_bf16 passes per product, fp32 "
+                    f"accumulate (measured fp32-equivalent accuracy): executed MFMA flop = {passes} x algorithmic, so the "
+                    f"roof for ALGORITHMIC flop is the dense bf16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {passes}; the "
+                    f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json")
+        traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        per_kernel, roof = {}, None
+        for tag, kname in kernels.items():
             n_t, ms_t = ops.prof_get(tag)
-            shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_bilinear_rows.json")
-        if roof is not None and os.path.exists(traffic_file):
-            # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
-            roof["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+            if not n_t:
+                continue
+            avg_ms = ms_t / n_t
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            per_kernel[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1),
+                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
+                               # per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
+                               "traffic": traffic.get(kname, {}).get("hbm_bytes_per_launch"),
+                               "launches_per_step": n_t / args.steps, "avg_launch_ms": round(avg_ms, 4),
+                               "ms_per_step": round(ms_t / args.steps, 3), "flops_per_launch": flops_per_launch}
+        if per_kernel:
+            dom = max(per_kernel, key=lambda t: per_kernel[t]["ms_per_step"])
+            roof = dict(per_kernel[dom])
+            roof["arithmetic"] = note
+            roof["other_contraction_kernels"] = {t: {k: v[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
+                                                                        "ms_per_step", "traffic")}
+                                                 for t, v in per_kernel.items() if t != dom}
+        shares = {}
+        for tag in ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_seg_bwd", "edge_ge", "edge_gw",
+                    "gemm_f32"):
+            n_t, ms_t = ops.prof_get(tag)
+            if n_t:
+                shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
         metric = ("edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch" if args.workload == "layer"
                   else "batch-edges/sec through the full CGAT stack (4 layers, fwd+bwd), 1M-edge batch [informational]")
         out = {

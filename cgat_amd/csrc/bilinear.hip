@@ -401,7 +401,7 @@ template <int PASSES>
 __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const float* __restrict__ zz, long ldz,
     const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
-    float* __restrict__ dvp, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io) {
+    float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io) {
   constexpr int CH16 = 2 * 3 * 4 * 64;          // 16-byte pieces per ring slot = 24 KB: [half][plane][cb][lane]
   constexpr int PST = 8 * 64;
   __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
@@ -519,8 +519,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   }
   DU_READ(fa1, fa2, fa3, 0, 0);
   f32x4 part[8];
-  const int dv_a = (int)(((long)hf * nrows + rowc_a) * NA);   // 32-bit offsets: the launcher checks 2 nrows NA < 2^31
-  const int dv_b = (int)(((long)hf * nrows + rowc_b) * NA);
+  // dvp[half][a][row]: the 32 rows of a wave are 128 contiguous bytes per `a` (row-major [row][a] would be 4-byte
+  // stores at a 512-byte stride: 12x write amplification, measured with WRITE_SIZE).  32-bit offsets: the launcher
+  // checks 2 * dv_ld * NA < 2^31
+  const int dv_a = hf * NA * dv_ld + row_a, dv_b = hf * NA * dv_ld + row_b;
   for (int a = a_beg; a < a_end; ++a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -558,8 +560,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
         da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
         db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
         if (kg == 0) {
-          if (row_a < nrows) dvp[dv_a + a] = sg * da;
-          if (row_b < nrows) dvp[dv_b + a] = sg * db;
+          dvp[dv_a + a * dv_ld] = sg * da;         // dv_ld >= the tile-padded row count: no bounds check needed
+          dvp[dv_b + a * dv_ld] = sg * db;
         }
       }
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -587,23 +589,32 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     }
 }
 
-// out1 = sum of the a-split slabs (if any); out2[n,a] = init2[n,a] + dvp[0][n,a] + dvp[1][n,a]
-__global__ void dual_finish_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
-                                   float* __restrict__ out1, long ldo1, const float* __restrict__ dvp,
-                                   const float* __restrict__ init2, long ldi2, float* __restrict__ out2, long ldo2) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)nrows * 128) return;
-  const long n = i >> 7;
-  const int c = (int)(i & 127);
-  if (splits > 1) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(long)z * slab_stride + i];
-    out1[n * ldo1 + c] = s;
+// out1 = sum of the a-split slabs (if any); out2[n,a] = init2[n,a] + dvp[0][a][n] + dvp[1][a][n].
+// One workgroup per 32 rows: the [128 a][32 n] pieces of dvp are read coalesced and transposed through LDS.
+__global__ __launch_bounds__(256) void dual_finish_kernel(const float* __restrict__ slab, int splits, long slab_stride,
+                                                          int nrows, float* __restrict__ out1, long ldo1,
+                                                          const float* __restrict__ dvp, int dv_ld, int NA,
+                                                          const float* __restrict__ init2, long ldi2,
+                                                          float* __restrict__ out2, long ldo2) {
+  __shared__ float tile[128][33];
+  const int n0 = blockIdx.x * 32, tid = threadIdx.x;
+  for (int idx = tid; idx < 128 * 32; idx += 256) {   // idx = a * 32 + n
+    const int a = idx >> 5, n = idx & 31;
+    const long o = (long)a * dv_ld + n0 + n;
+    tile[a][n] = dvp[o] + dvp[(long)NA * dv_ld + o];
   }
-  float d = init2 ? init2[n * ldi2 + c] : 0.f;
-  d += dvp[i];
-  d += dvp[(long)nrows * 128 + i];
-  out2[n * ldo2 + c] = d;
+  __syncthreads();
+  for (int idx = tid; idx < 32 * 128; idx += 256) {   // idx = n * 128 + c
+    const int n = idx >> 7, c = idx & 127;
+    const long row = n0 + n;
+    if (row >= nrows) continue;
+    if (splits > 1) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += slab[(long)z * slab_stride + row * 128 + c];
+      out1[row * ldo1 + c] = s;
+    }
+    out2[row * ldo2 + c] = (init2 ? init2[row * ldi2 + c] : 0.f) + tile[c][n];
+  }
 }
 
 // sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
@@ -771,9 +782,10 @@ size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
 bool bilinear_dual_fast(int NA, int NB, int NC) {
   return bilinear_mode() != 0 && NA == 128 && NB == 128 && NC == 128 && !force_generic();
 }
+static int dual_dv_ld(int nrows) { return cdiv(nrows, 128) * 128; }   // rows padded to whole 128-row tiles
 size_t bilinear_dual_ws_bytes(int nrows) {
   const int sp = rows_asplit(nrows, 128);
-  return ws_round((size_t)2 * nrows * 128 + (sp > 1 ? (size_t)sp * nrows * 128 : 0), 4);
+  return ws_round((size_t)2 * dual_dv_ld(nrows) * 128 + (sp > 1 ? (size_t)sp * nrows * 128 : 0), 4);
 }
 // T: bilinear_prepare_T of the [NA,128,128] operand.  out1 = init1 + sum_a p[:,a] M[:,a,:], out2 = init2 + M . zz
 int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
@@ -781,7 +793,7 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
                          float* out2, long ldo2, int nrows, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (nrows <= 0) return CGAT_OK;
   CGAT_CHECK_ARG((ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)T) & 15) == 0 && ldp < (1l << 22) &&
-                     (long)nrows * 256 < (1l << 31),
+                     (long)dual_dv_ld(nrows) * 256 < (1l << 31),
                  "bilinear_dual: q and T must be 16-byte aligned with ldq %% 4 == 0, nrows < 2^23");
   const int tiles = cdiv(nrows, 128);
   const int sp = rows_asplit(nrows, 128);
@@ -789,24 +801,25 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
     cgat_set_error("bilinear_dual: workspace too small (%zu < %zu)", ws_bytes, bilinear_dual_ws_bytes(nrows));
     return CGAT_ERR_WORKSPACE;
   }
+  const int dv_ld = dual_dv_ld(nrows);
   float* dvp = (float*)ws;
-  float* slab = dvp + (size_t)2 * nrows * 128;
+  float* slab = dvp + (size_t)2 * dv_ld * 128;
   float* dst = sp > 1 ? slab : out1;
   const long dld = sp > 1 ? 128 : ldo1, stride = sp > 1 ? (long)nrows * 128 : 0;
   const int vec_io = ((dld % 4) == 0 && (((uintptr_t)dst) & 15) == 0 &&
                       (!init1 || ((ldi1 % 4) == 0 && (((uintptr_t)init1) & 15) == 0))) ? 1 : 0;
   {
-    CGAT_PROF("bilinear_rows", stream);
+    CGAT_PROF("bilinear_dual", stream);
     if (bilinear_mode() == 6)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<6>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
-                         (const uint4*)T, init1, ldi1, dst, dld, dvp, nrows, 128, tiles, sp, stride, vec_io);
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io);
     else
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<3>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
-                         (const uint4*)T, init1, ldi1, dst, dld, dvp, nrows, 128, tiles, sp, stride, vec_io);
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io);
     CGAT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv((long)nrows * 128, 256)), dim3(256), 0, stream, slab, sp, stride, nrows,
-                     out1, ldo1, dvp, init2, ldi2, out2, ldo2);
+  hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv(nrows, 32)), dim3(256), 0, stream, slab, sp, stride, nrows, out1, ldo1,
+                     dvp, dv_ld, 128, init2, ldi2, out2, ldo2);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -1,0 +1,48 @@
+"""Turns the rocprofv3 PMC passes of `bench.py` (separate FETCH_SIZE / WRITE_SIZE runs, --kernel-trace only) into
+profiles/pmc_contraction_kernels.json (HBM bytes per launch of the three hypernetwork contraction kernels, read by
+bench.py for roofline.traffic) and a per-kernel CSV.
+
+    python tools/pmc_summary.py gpurun_out/pmcF_FETCH_SIZE gpurun_out/pmcF_WRITE_SIZE r01
+
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at half their bytes, so the read
+side is doubled; WRITE_SIZE is exact for 16-byte streaming stores.  Both counters are in KiB."""
+import collections, csv, glob, json, os, sys
+
+fetch_dir, write_dir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
+    return agg, f
+
+
+fetch, ff = load(fetch_dir, "FETCH_SIZE")
+write, wf = load(write_dir, "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write), key=lambda k: -(sum(fetch.get(k, [0])) * 2 + sum(write.get(k, [0])))):
+    nf, nw = len(fetch.get(k, [])), len(write.get(k, []))
+    f_kb = sum(fetch.get(k, [0])) / max(nf, 1)
+    w_kb = sum(write.get(k, [0])) / max(nw, 1)
+    rows.append((k, max(nf, nw), f_kb, w_kb, int((2 * f_kb + w_kb) * 1024)))
+with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") as f:
+    f.write("kernel,dispatches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+    for r in rows:
+        f.write("%s,%d,%.1f,%.1f,%d\n" % r)
+N, C = 83340, 128
+alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 6,           # p, q, init, out + bf16x3 T
+       "bilinear_rows128_dual_kernel": 7 * N * C * 4 + C ** 3 * 6,             # p, q, zz, init1, out1, init2, out2 + T
+       "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 6 + C ** 3 * 4}  # pT, qT, r planes + out
+out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py "
+                  "--steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
+       "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE halves wide coalesced reads)"}
+for k, n, f_kb, w_kb, b in rows:
+    if k in alg:
+        out[k] = {"dispatches": n, "FETCH_SIZE_KB_per_launch": round(f_kb, 1), "WRITE_SIZE_KB_per_launch": round(w_kb, 1),
+                  "hbm_bytes_per_launch": b, "algorithmic_bytes_per_launch": alg[k]}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
