@@ -197,7 +197,7 @@ def main():
                                                                         "ms_per_step", "traffic")}
                                                  for t, v in per_kernel.items() if t != dom}
         shares = {}
-        for tag in ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_seg_bwd", "edge_ge", "edge_gw",
+        for tag in ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_seg_bwd", "edge_ge", "edge_gw", "linear128",
                     "gemm_f32"):
             n_t, ms_t = ops.prof_get(tag)
             if n_t:

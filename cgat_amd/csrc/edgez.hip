@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
                                                         const int* __restrict__ srci, long ld_add,
                                                         float* __restrict__ Z, long ldz, int E,
                                                         const float* __restrict__ wA, const float* __restrict__ bA,
-                                                        int H, int cb_per_head, float* __restrict__ a_out) {
+                                                        int H, int cb_per_head, float* __restrict__ a_out, int act,
+                                                        int accumulate) {
   constexpr int CH16 = 3 * 4 * 64;              // 16-byte pieces per chunk = 12 KB
   __shared__ uint4 smem[4 * CH16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,8 +157,18 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         const float4 ib = ADDS ? *reinterpret_cast<const float4*>(pib + col) : ia;
         const float4 jb = ADDS ? *reinterpret_cast<const float4*>(pjb + col) : zero4;
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
-        const float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
-        const float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
+        float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
+        float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
+        if (!ADDS) {   // the dense-layer form: out = act(x W^T + b) [+ out]
+          if (act == CGAT_ACT_TANH) {
+            va = make_float4(tanhf(va.x), tanhf(va.y), tanhf(va.z), tanhf(va.w));
+            vb = make_float4(tanhf(vb.x), tanhf(vb.y), tanhf(vb.z), tanhf(vb.w));
+          }
+          if (accumulate) {
+            if (row_a < E) { const float4 u = *reinterpret_cast<const float4*>(za + col); va.x += u.x; va.y += u.y; va.z += u.z; va.w += u.w; }
+            if (row_b < E) { const float4 u = *reinterpret_cast<const float4*>(zb + col); vb.x += u.x; vb.y += u.y; vb.z += u.z; vb.w += u.w; }
+          }
+        }
         if (row_a < E) *reinterpret_cast<float4*>(za + col) = va;
         if (row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
         if (isA) {
@@ -215,11 +226,38 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
-                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, 0, 0)
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 6) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
   else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }
 #undef EZ_GO
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ---- dense layer at width 128: out[n, :] = act(in[n, :] W^T + bias) + beta * out[n, :],  W(o, k) = W[o*so + k*sk] ----
+// The hypernetwork trunks (Linear + Tanh, reference Hypernetworksmp.py:24-60) and the linear terms of the predicted
+// layers are [rows,128] x [128,128] products; on the generic 128x128x32 GEMM tile they are all prologue and epilogue.
+// Here they run as the one-column-block case of the kernel above (rows split once into registers, 96 KB of weight
+// planes through the LDS-DMA ring).
+bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out) {
+  return bilinear_mode() != 0 && K == 128 && N == 128 && (ldi % 4) == 0 && (ldo % 4) == 0 &&
+         ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+}
+size_t linear128_ws_bytes() { return ws_round((size_t)128 * 128 * 3 / 2 + 4, 4); }
+int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream) {
+  if (rows <= 0) return CGAT_OK;
+  // operand (a = 0, b = k, c = output) = W[c * so + b * sk]
+  CGAT_TRY(prepare_T_bf16_launch(W, ws, 1, 0, sk, so, 0, stream));
+  CGAT_PROF("linear128", stream);
+  const int grid = cdiv(rows, 128);
+#define L128_GO(P_)                                                                                                   \
+  hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
+                     (const uint4*)ws, 1, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l,  \
+                     out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate)
+  if (bilinear_mode() == 6) L128_GO(6); else L128_GO(3);
+#undef L128_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -87,6 +87,11 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream);
+// dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]
+bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out);
+size_t linear128_ws_bytes();
+int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
 // operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);

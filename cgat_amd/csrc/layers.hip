@@ -35,7 +35,15 @@ struct Ctx {
   int gemm(GemmParams p, bool auto_split = false) {
     if (auto_split) p.splits = gemm_pick_splits(p.M, p.N, p.K);
     if (p.splits > 1) need(ws_round((size_t)p.splits * p.M * p.N, 4));
+    // [rows,128] x [128,128] dense layers (trunks, linear terms of the predicted layers): the split-bf16 kernel
+    const bool dense128 = p.K == 128 && p.N == 128 && !p.a_kmajor && !p.a_rgather && !p.a_block && !p.b_kgather &&
+                          !p.c_scatter && !p.add1 && !p.add2 && p.splits <= 1 && p.alpha == 1.f &&
+                          (p.beta == 0.f || p.beta == 1.f) && (p.act == CGAT_ACT_NONE || p.act == CGAT_ACT_TANH);
+    if (dense128) need(linear128_ws_bytes());
     if (dry) return CGAT_OK;
+    if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes())
+      return linear128_launch(p.A, p.lda, p.B, p.b_kmajor ? 1 : p.ldb, p.b_kmajor ? p.ldb : 1, p.bias, p.act,
+                              p.beta == 1.f, p.C, p.ldc, p.M, scratch, s);
     return gemm_launch(p, scratch, scratch_bytes, s);
   }
   int colsum(const float* x, long ldx, int rows, int cols, float* out, float alpha) {
