@@ -155,14 +155,12 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < HHd; c += 256) pw[c] = 0.f;
   const int n0 = blockIdx.x * SEGB_NODES, n1 = min(N, n0 + SEGB_NODES);
+  // The three steps run over ALL segments of the workgroup before the next one starts: two barriers per workgroup
+  // instead of three per node.
+  // ---- 1. g_alpha: one wave per edge row, wave-level reductions only ----
   for (int n = n0; n < n1; ++n) {
     const int r0 = rowptr[n], r1 = rowptr[n + 1];
-    if (r1 == r0) {  // no incoming edge: zero row of the segment sum
-      for (int c = tid; c < W2; c += 256) Gi[(long)n * W2 + c] = 0.f;
-      continue;
-    }
     const float* gSn = gS + (long)n * HHd;
-    // ---- 1. g_alpha: one wave per row, wave-level reductions only ----
     for (int t = r0 + wave; t < r1; t += 4) {
       const float* zM = Z + (long)t * W2 + HHd;
       for (int h = 0; h < H; ++h) {
@@ -185,16 +183,26 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
         if (lane == 0) tt[(long)t * H + h] = part + gs[(long)n * H + h];
       }
     }
-    __syncthreads();
-    // ---- 2. softmax backward over the segment ----
-    if (tid < H) {
-      float dot = 0.f;
-      for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + tid] * tt[(long)t * H + tid];
-      for (int t = r0; t < r1; ++t) ga[(long)t * H + tid] = alpha[(long)t * H + tid] * (tt[(long)t * H + tid] - dot);
+  }
+  __syncthreads();
+  // ---- 2. softmax backward, one thread per (segment, head) ----
+  if (tid < (n1 - n0) * H) {
+    const int n = n0 + tid / H, h = tid % H;
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    float dot = 0.f;
+    for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
+    for (int t = r0; t < r1; ++t) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+  }
+  __syncthreads();
+  // ---- 3. gZ rows, their segment sum, partial sums for grad wA_out (a thread keeps its columns for all segments) ----
+  for (int n = n0; n < n1; ++n) {
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    if (r1 == r0) {  // no incoming edge: zero row of the segment sum
+      for (int c = tid; c < W2; c += 256) Gi[(long)n * W2 + c] = 0.f;
+      continue;
     }
-    __syncthreads();
-    // ---- 3. gZ rows, their segment sum, partial sums for grad wA_out ----
-    if (VEC) {  // four consecutive columns per thread (a head boundary is a multiple of 4)
+    const float* gSn = gS + (long)n * HHd;
+    if (VEC) {  // four consecutive columns per thread (a head boundary is a multiple of 4); rows four at a time
       for (int c4 = tid; c4 < W2 / 4; c4 += 256) {
         const int col = 4 * c4;
         const bool isA = col < HHd;
@@ -202,23 +210,38 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
         const int h = cc / Hd;
         const float4 wv = isA ? *reinterpret_cast<const float4*>(wA_out + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 gsv = isA ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gSn + cc);
+        const float* coef = isA ? ga : alpha;
         float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), ps = gi;
-        for (int t = r0; t < r1; ++t) {
-          const float4 z = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
-          const float4 d = make_float4(z.x > 0.f ? 1.f : 0.01f, z.y > 0.f ? 1.f : 0.01f, z.z > 0.f ? 1.f : 0.01f,
-                                       z.w > 0.f ? 1.f : 0.01f);
-          float4 g;
-          if (isA) {
-            const float gav = ga[(long)t * H + h];
-            g = make_float4(gav * wv.x * d.x, gav * wv.y * d.y, gav * wv.z * d.z, gav * wv.w * d.w);
-            ps.x += gav * z.x * d.x; ps.y += gav * z.y * d.y; ps.z += gav * z.z * d.z; ps.w += gav * z.w * d.w;
-          } else {
-            const float al = alpha[(long)t * H + h];
-            g = make_float4(al * gsv.x * d.x, al * gsv.y * d.y, al * gsv.z * d.z, al * gsv.w * d.w);
+        for (int tb = r0; tb < r1; tb += 4) {
+          float4 zv[4];
+          float cf[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + u < r1 ? tb + u : r1 - 1;
+            zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+            cf[u] = coef[(long)t * H + h];
           }
-          float* dst = gz_block ? gZ + (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : gZ + (long)t * W2 + col;
-          *reinterpret_cast<float4*>(dst) = g;
-          gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + u;
+            if (t < r1) {
+              const float4 z = zv[u];
+              const float4 d = make_float4(z.x > 0.f ? 1.f : 0.01f, z.y > 0.f ? 1.f : 0.01f, z.z > 0.f ? 1.f : 0.01f,
+                                           z.w > 0.f ? 1.f : 0.01f);
+              float4 g;
+              if (isA) {
+                const float gav = cf[u];
+                g = make_float4(gav * wv.x * d.x, gav * wv.y * d.y, gav * wv.z * d.z, gav * wv.w * d.w);
+                ps.x += gav * z.x * d.x; ps.y += gav * z.y * d.y; ps.z += gav * z.z * d.z; ps.w += gav * z.w * d.w;
+              } else {
+                const float al = cf[u];
+                g = make_float4(al * gsv.x * d.x, al * gsv.y * d.y, al * gsv.z * d.z, al * gsv.w * d.w);
+              }
+              float* dst = gz_block ? gZ + (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : gZ + (long)t * W2 + col;
+              *reinterpret_cast<float4*>(dst) = g;
+              gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
+            }
+          }
         }
         *reinterpret_cast<float4*>(Gi + (long)n * W2 + col) = gi;
         if (isA) {
@@ -252,8 +275,8 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
         if (isA) pw[cc] += ps;
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int c = tid; c < HHd; c += 256) partialW[(long)blockIdx.x * HHd + c] = pw[c];
 }
 
