@@ -11,8 +11,9 @@ from .mlp import ResidualNetwork, Rezero, SimpleNetwork
 from .nets import CGAtNet, GATConvEdges, GATConvNodes, MHAttention, MultiHeadNetwork
 from .roost import MessageLayer, Roost, WeightedAttention
 from .graph import GraphBatch, synthetic_batch
+from .collate import PackedDataset
 from .ops import get_bilinear_mode, set_bilinear_mode
 
 __all__ = ["CGAtNet", "GATConvNodes", "GATConvEdges", "MultiHeadNetwork", "MHAttention", "H_Net", "H_Net_0",
            "HyperFC", "SimpleNetwork", "ResidualNetwork", "Rezero", "Roost", "MessageLayer", "WeightedAttention",
-           "GraphBatch", "synthetic_batch", "set_bilinear_mode", "get_bilinear_mode"]
+           "GraphBatch", "synthetic_batch", "PackedDataset", "set_bilinear_mode", "get_bilinear_mode"]

@@ -30,6 +30,17 @@ class Plan(C.Structure):
                 ("src_sorted", vp), ("src_rowptr", vp), ("src_pos", vp)]
 
 
+class PackedDatasetStruct(C.Structure):
+    _fields_ = [("n_graphs", C.c_int32), ("fea", C.c_int32), ("max_nbr", C.c_int32), ("n_elem", C.c_int32),
+                ("table", vp), ("atom_ptr", vp), ("atom_elem", vp), ("shell", vp), ("self_idx", vp), ("nbr_idx", vp),
+                ("comp_ptr", vp), ("comp_elem", vp), ("comp_weight", vp), ("y_val", vp)]
+
+
+class CollatedStruct(C.Structure):
+    _fields_ = [("x", vp), ("edge_index", vp), ("edge_attr", vp), ("y", vp), ("batch", vp), ("comp_weight", vp),
+                ("comp_fea", vp), ("comp_self", vp), ("comp_nbr", vp), ("comp_crystal", vp)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("C", C.c_int32), ("Ce", C.c_int32), ("H", C.c_int32), ("Hd", C.c_int32),
                 ("A_in_w", vp), ("A_in_b", vp), ("A_out_w", vp), ("A_out_b", vp),
@@ -102,6 +113,8 @@ PROTOTYPES = {
     "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
+    "cgat_collate_batch": (C.c_int, [C.POINTER(PackedDatasetStruct), vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64,
+                                     C.POINTER(CollatedStruct), vp]),
     "cgat_bilinear_dual_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgat_bilinear_dual": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, vp,
                                      C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_size_t, vp]),

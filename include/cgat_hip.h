@@ -57,6 +57,43 @@ size_t cgat_csr_workspace_bytes(int32_t S);
 int cgat_csr_from_keys(const int32_t* keys, int32_t n, int32_t S, int32_t* rowptr, int32_t* perm, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* ---- batch collation on the device (the step before the hot path) -----------
+ * replaces, per training step, CGAT/data.py:61-144 (CompositionData.__getitem__ for every crystal of the batch),
+ * PyG Batch.from_data_list (CGAT/lightning_module.py:200) and CGAT/roost_message.py:400-458 (collate_batch).
+ * The dataset lives on the device in packed int32 form (built once): per-atom element ids into the embedding table,
+ * the neighbour tables already sliced to max_nbr columns, the per-crystal composition (unique elements in
+ * first-appearance order and their weights) and y = target * n_atoms (or the plain target for 'volume'). */
+typedef struct cgat_packed_dataset {
+  int32_t n_graphs, fea, max_nbr, n_elem;
+  const float* table;        /* [n_elem, fea] element embedding */
+  const int32_t* atom_ptr;   /* [n_graphs+1] */
+  const int32_t* atom_elem;  /* [atoms] row of `table` */
+  const int32_t* shell;      /* [atoms, max_nbr] edge_attr ids */
+  const int32_t* self_idx;   /* [atoms, max_nbr] crystal-local centre atom */
+  const int32_t* nbr_idx;    /* [atoms, max_nbr] crystal-local neighbour atom */
+  const int32_t* comp_ptr;   /* [n_graphs+1] */
+  const int32_t* comp_elem;  /* [unique elements] row of `table` */
+  const float* comp_weight;  /* [unique elements] count / n_atoms */
+  const float* y_val;        /* [n_graphs] */
+} cgat_packed_dataset;
+typedef struct cgat_collated {   /* outputs, caller-allocated; dtypes as the reference's tensors */
+  float* x;                  /* [N, fea] */
+  int64_t* edge_index;       /* [2, E], E = N * max_nbr */
+  int64_t* edge_attr;        /* [E] */
+  float* y;                  /* [B] */
+  int64_t* batch;            /* [N] */
+  float* comp_weight;        /* [Nc] (the reference views it as [Nc,1]) */
+  float* comp_fea;           /* [Nc, fea] */
+  int64_t* comp_self;        /* [Ec] */
+  int64_t* comp_nbr;         /* [Ec] */
+  int64_t* comp_crystal;     /* [Nc] */
+} cgat_collated;
+/* ids[B]: crystals of the batch in order; node_off/comp_off/cedge_off[B]: exclusive prefix sums of their atom
+ * counts, unique-element counts and u*(u-1) composition edges (all device pointers). */
+int cgat_collate_batch(const cgat_packed_dataset* ds, const int32_t* ids, const int32_t* node_off,
+                       const int32_t* comp_off, const int32_t* cedge_off, int32_t B, int64_t E_total, int64_t Ec_total,
+                       const cgat_collated* out, void* stream);
+
 /* ---- GATConvNodes message + softmax + aggregate (scalar attention) ----------------------
  * replaces CGAT/CGAT.py:319-329: m=cat[x_i,edge_attr,x_j]; alpha=softmax_dst(MH_A(m));
  * aggr = scatter_add(MH_M(m)*alpha).mean(heads), with MH_* = MultiHeadNetwork (CGAT.py:65-112).
