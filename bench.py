@@ -73,6 +73,77 @@ def cpu_baseline(n_graphs=100, reps=3):
                       "batch-size independent (SURVEY §8d)"}
 
 
+def bench_collate(args, rank, world, device):
+    """Informational: device-side collation of the BASELINE batch (4167 crystals x 20 atoms x 12
+    neighbours -> the tensors the layer consumes) from a packed HBM-resident dataset; one step = one batch.  The
+    CPU baseline is the oracle's restatement of the reference's per-crystal Python loops on a bounded sample."""
+    import numpy as np
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    from cgat_amd.graph import synthetic_dataset_dict, ELEMENT_SYMBOLS
+    data, emb = synthetic_dataset_dict(args.graphs, ATOMS, 24, seed=rank)
+    ds = P.PackedDataset.from_dict(data, emb, max_neighbor_number=K_NBR, device=device)
+    rs = np.random.RandomState(rank)
+    batches = [rs.permutation(args.graphs) for _ in range(args.warmup + args.steps)]
+    for i in range(args.warmup):
+        ds.collate(batches[i])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gb, _ = ds.collate(batches[args.warmup + i])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        N, E = gb.num_nodes, gb.edge_index.shape[1]
+        n_l, ms_l = ops.prof_get("collate")
+        # algorithmic HBM bytes per batch: embedding rows written (800 B per atom; the 82-KB table itself stays in
+        # L2; the composition rows are ~1/6 of the atom rows), three int32 tables read and three int64 arrays
+        # written per edge, batch vector
+        alg = N * 800 * (1 + 1 / 6) + E * (12 + 24) + N * 8
+        roof = None
+        if n_l:
+            avg_ms = ms_l / n_l
+            roof = {"bound": "hbm", "kernel": "collate_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg)}
+        out = {"metric": "batch-edges/sec collated on the device (dataset -> layer inputs) [informational, SURVEY 8 f1]",
+               "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "int32/int64 indices, f32 rows", "data": "synthetic",
+               "config": {"workload": f"collate {args.graphs} crystals x {ATOMS} atoms x {K_NBR} of 24 stored neighbours "
+                                      f"per rank from a packed HBM-resident dataset: N={N}, E={E}",
+                          "edges_per_rank": E, "parallelism": f"dp{world} (every rank collates its own crystals)"},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import collate_oracle as O
+            elem_id = {el: k for k, el in enumerate(ELEMENT_SYMBOLS)}
+            table = np.asarray([emb[el] for el in ELEMENT_SYMBOLS], dtype=np.float32)
+            n_s, reps = args.graphs, 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ref = O.collate(data, list(range(n_s)), table, elem_id, K_NBR, "e_above_hull")
+            dt = (time.perf_counter() - t0) / reps
+            out["cpu_baseline"] = {"value": ref["edge_attr"].shape[0] / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same {n_s}-crystal batch through the oracle's restatement of "
+                                             f"CompositionData.__getitem__ + collate_batch (numpy, mean of {reps}, {dt:.2f} s "
+                                             "per batch; without the host-to-device copy the reference adds)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=GRAPHS, help="crystals per rank (default: the 1M-edge batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["layer", "stack"], default="layer",
+    ap.add_argument("--workload", choices=["layer", "stack", "collate"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -96,6 +167,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
+    if args.workload == "collate":
+        return bench_collate(args, rank, world, device)
     torch.manual_seed(1)                                   # identical parameters on every rank
     if args.workload == "layer":
         layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)

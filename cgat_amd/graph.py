@@ -93,3 +93,35 @@ def shard_graphs(num_graphs, rank, world_size):
     base, rem = divmod(num_graphs, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# element symbols in the order of the reference's embeddings/matscholar-embedding.json (Z = 1 .. 103)
+ELEMENT_SYMBOLS = ("H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb "
+                   "Sr Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf "
+                   "Ta W Re Os Ir Pt Au Hg Tl Pb Bi Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr").split()
+
+
+def synthetic_dataset_dict(num_graphs, atoms_per_graph=20, stored_nbrs=24, seed=0):
+    """A dataset in the reference's on-disk dictionary layout 0 (prepare_data.py:92-98; data.py:47-50):
+    {'input': object array [3, n] of per-crystal [n_atoms, 24] tables (shell id, centre, neighbour), 'comps': per-atom
+    element symbols, 'batch_comp': formula strings, 'target': {name: array}} and the embedding dict symbol -> vector.
+    Used by bench.py --workload collate and the collation tests."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    G, A, K = int(num_graphs), int(atoms_per_graph), int(stored_nbrs)
+    z = rs.randint(0, N_ELEMENTS, size=(G, 1)) + rs.randint(0, 4, size=(G, A)) * 17
+    z %= N_ELEMENTS
+    shell = (1 + np.cumsum(rs.rand(G, A, K) < 0.4, axis=2)).astype(np.int64)
+    centre = np.broadcast_to(np.arange(A)[None, :, None], (G, A, K)).astype(np.int64)
+    nbr = rs.randint(0, A, size=(G, A, K)).astype(np.int64)
+    inp = np.empty((3, G), dtype=object)
+    comps, formulas = [], []
+    for g in range(G):
+        inp[0][g], inp[1][g], inp[2][g] = shell[g], centre[g], nbr[g]
+        syms = [ELEMENT_SYMBOLS[k] for k in z[g]]
+        comps.append(syms)
+        formulas.append("".join(f"{el}{syms.count(el)}" for el in dict.fromkeys(syms)))
+    table = element_table().numpy()
+    emb = {el: table[k].astype("float64").tolist() for k, el in enumerate(ELEMENT_SYMBOLS)}
+    return {"input": inp, "comps": comps, "batch_comp": formulas,
+            "target": {"e_above_hull": rs.randn(G).round(4)}}, emb
