@@ -73,6 +73,24 @@ def cpu_baseline(n_graphs=100, reps=3):
                       "batch-size independent (SURVEY §8d)"}
 
 
+def cpu_baseline_collate(data, emb, n_graphs, reps=5):
+    """The oracle's restatement of the reference's host-side collation (CompositionData.__getitem__ for every crystal
+    + Batch.from_data_list + collate_batch) on the same batch."""
+    import numpy as np
+    from oracle import collate_oracle as O
+    from cgat_amd.graph import ELEMENT_SYMBOLS
+    elem_id = {el: k for k, el in enumerate(ELEMENT_SYMBOLS)}
+    table = np.asarray([emb[el] for el in ELEMENT_SYMBOLS], dtype=np.float32)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref = O.collate(data, list(range(n_graphs)), table, elem_id, K_NBR, "e_above_hull")
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": ref["edge_attr"].shape[0] / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"the same {n_graphs}-crystal batch through the oracle's restatement of CompositionData.__getitem__ "
+                      f"+ collate_batch (numpy, mean of {reps}, {dt:.2f} s per batch; without the host-to-device copy the "
+                      "reference adds)"}
+
+
 def bench_collate(args, rank, world, device):
     """Informational: device-side collation of the BASELINE batch (4167 crystals x 20 atoms x 12
     neighbours -> the tensors the layer consumes) from a packed HBM-resident dataset; one step = one batch.  The
@@ -81,7 +99,7 @@ def bench_collate(args, rank, world, device):
     import torch.distributed as dist
     import cgat_amd as P
     from cgat_amd import ops
-    from cgat_amd.graph import synthetic_dataset_dict, ELEMENT_SYMBOLS
+    from cgat_amd.graph import synthetic_dataset_dict
     data, emb = synthetic_dataset_dict(args.graphs, ATOMS, 24, seed=rank)
     ds = P.PackedDataset.from_dict(data, emb, max_neighbor_number=K_NBR, device=device)
     rs = np.random.RandomState(rank)
@@ -126,18 +144,76 @@ def bench_collate(args, rank, world, device):
                           "edges_per_rank": E, "parallelism": f"dp{world} (every rank collates its own crystals)"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import collate_oracle as O
-            elem_id = {el: k for k, el in enumerate(ELEMENT_SYMBOLS)}
-            table = np.asarray([emb[el] for el in ELEMENT_SYMBOLS], dtype=np.float32)
-            n_s, reps = args.graphs, 5
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                ref = O.collate(data, list(range(n_s)), table, elem_id, K_NBR, "e_above_hull")
-            dt = (time.perf_counter() - t0) / reps
-            out["cpu_baseline"] = {"value": ref["edge_attr"].shape[0] / dt, "unit": "edges/s", "cores": 1, "kind": "port",
-                                   "sample": f"the same {n_s}-crystal batch through the oracle's restatement of "
-                                             f"CompositionData.__getitem__ + collate_batch (numpy, mean of {reps}, {dt:.2f} s "
-                                             "per batch; without the host-to-device copy the reference adds)"}
+            out["cpu_baseline"] = cpu_baseline_collate(data, emb, args.graphs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_optim(shapes, lr, wd):
+    """The oracle's AdamW update (torch fp32 on the host cores) over the same tensors."""
+    from oracle import optim_oracle as O
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.randn(sh, generator=g) for sh in shapes]
+    gs = [torch.randn(sh, generator=g) for sh in shapes]
+    ms, vs = [torch.zeros(sh) for sh in shapes], [torch.zeros(sh) for sh in shapes]
+    times = []
+    for step in range(1, 5):
+        t0 = time.perf_counter()
+        for i in range(len(ps)):
+            ps[i], ms[i], vs[i] = O.adamw_step(ps[i], gs[i], ms[i], vs[i], step, lr=lr, weight_decay=wd)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[1]
+    n = sum(p.numel() for p in ps)
+    return {"value": n / dt, "unit": "parameters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"all {len(ps)} tensors ({n} parameters), median of 3 steps after 1 warm-up ({dt:.3f} s per step)"}
+
+
+def bench_optim(args, rank, world, device):
+    """Informational: one fused AdamW step over all 44.6 M parameters of CGAtNet(200,128,4,msg_heads=3)."""
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    from cgat_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
+    params = list(net.parameters())
+    g = torch.Generator().manual_seed(2)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(device)
+    opt = FusedAdamW(params, lr=1e-3, weight_decay=1e-2)
+    for _ in range(args.warmup):
+        opt.step()
+    torch.cuda.synchronize()
+    ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        opt.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n = sum(p.numel() for p in params)
+        n_l, ms_l = ops.prof_get("adamw")
+        alg = 28.0 * n                                     # read p, g, m, v; write p, m, v
+        avg_ms = ms_l / max(n_l, 1)
+        out = {"metric": "parameters/sec through one fused AdamW step [informational, SURVEY 8 f4]",
+               "value": world * n * args.steps / elapsed, "unit": "parameters/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"FusedAdamW over the {len(params)} tensors / {n} parameters of "
+                                      "CGAtNet(200,128,4,msg_heads=3,update_edges=True), one launch per step",
+                          "parallelism": f"dp{world} (replicated optimiser state)"},
+               "roofline": {"bound": "hbm", "kernel": "adamw_mt_kernel", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1),
+                            "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (avg_ms * 1e-3) / 1e9 / 8000.0, 4),
+                            "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg)}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_optim([tuple(p.shape) for p in params], 1e-3, 1e-2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -151,7 +227,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=GRAPHS, help="crystals per rank (default: the 1M-edge batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["layer", "stack", "collate"], default="layer",
+    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -169,6 +245,8 @@ def main():
 
     if args.workload == "collate":
         return bench_collate(args, rank, world, device)
+    if args.workload == "optim":
+        return bench_optim(args, rank, world, device)
     torch.manual_seed(1)                                   # identical parameters on every rank
     if args.workload == "layer":
         layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)

@@ -12,8 +12,9 @@ from .nets import CGAtNet, GATConvEdges, GATConvNodes, MHAttention, MultiHeadNet
 from .roost import MessageLayer, Roost, WeightedAttention
 from .graph import GraphBatch, synthetic_batch
 from .collate import PackedDataset
+from .optim import FusedAdamW, FusedLamb, RobustL1, RobustL2, cyclical_lr
 from .ops import get_bilinear_mode, set_bilinear_mode
 
 __all__ = ["CGAtNet", "GATConvNodes", "GATConvEdges", "MultiHeadNetwork", "MHAttention", "H_Net", "H_Net_0",
            "HyperFC", "SimpleNetwork", "ResidualNetwork", "Rezero", "Roost", "MessageLayer", "WeightedAttention",
-           "GraphBatch", "synthetic_batch", "PackedDataset", "set_bilinear_mode", "get_bilinear_mode"]
+           "GraphBatch", "synthetic_batch", "PackedDataset", "FusedAdamW", "FusedLamb", "RobustL1", "RobustL2", "cyclical_lr", "set_bilinear_mode", "get_bilinear_mode"]

@@ -94,6 +94,34 @@ int cgat_collate_batch(const cgat_packed_dataset* ds, const int32_t* ids, const 
                        const int32_t* comp_off, const int32_t* cedge_off, int32_t B, int64_t E_total, int64_t Ec_total,
                        const cgat_collated* out, void* stream);
 
+/* ---- fused optimiser steps and robust losses (after the hot path) ------------
+ * One launch over all parameter tensors.  `table[n_tensors]` (device) holds the tensors; the chunk list cuts them
+ * into pieces of cgat_mt_chunk_elems() elements: chunk c covers table[chunk_tensor[c]] from element chunk_off[c];
+ * the chunks of a tensor are consecutive and first_chunk[n_tensors+1] indexes them (LAMB's per-tensor norms).
+ *   cgat_adamw_step : torch.optim.AdamW as the reference constructs it (CGAT/lightning_module.py:328-331):
+ *                     p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;
+ *                     p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ *   cgat_lamb_step  : CGAT/lambs.py:155-181 lamb_kernel (JITLamb.step 226-262): no bias correction, weight norm
+ *                     clamped to [0,10], trust ratio |w|/(|s|+eps) (1 when either norm is 0), p -= lr*ratio*s,
+ *                     s = m/(sqrt(v)+eps) + wd*p.  ws: 2*n_chunks + n_tensors floats.
+ *   cgat_robust_loss: CGAT/utils.py:30-47 RobustL1 (kind 1) / RobustL2 (kind 2): per-row terms and the gradients
+ *                     of the terms wrt output and log_std (the caller takes the mean). */
+typedef struct cgat_mt_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} cgat_mt_tensor;
+int32_t cgat_mt_chunk_elems(void);
+int cgat_adamw_step(const cgat_mt_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_off, int32_t n_chunks,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+int cgat_lamb_step(const cgat_mt_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_off, int32_t n_chunks,
+                   const int32_t* first_chunk, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float* ws, void* stream);
+int cgat_robust_loss(const float* output, const float* log_std, const float* target, int32_t n, int32_t kind,
+                     float* loss_terms, float* g_output, float* g_log_std, void* stream);
+
 /* ---- GATConvNodes message + softmax + aggregate (scalar attention) ----------------------
  * replaces CGAT/CGAT.py:319-329: m=cat[x_i,edge_attr,x_j]; alpha=softmax_dst(MH_A(m));
  * aggr = scatter_add(MH_M(m)*alpha).mean(heads), with MH_* = MultiHeadNetwork (CGAT.py:65-112).
