@@ -1099,6 +1099,12 @@ __global__ void split_rows_bf16_kernel(const float* __restrict__ r, long ldr, in
   dst[((((base + 2 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x3;
 }
 
+// Tried and dropped (round 1): the same kernel on v_mfma_f32_16x16x32_bf16 with the product split of the next k-step
+// interleaved between the MFMAs and the flush through slab tiles -- 1.74 ms vs 1.66 ms for this form.  The kernel is
+// bound by the SIMD's vector ISSUE port, not by the matrix pipe: per 32-row step a wave issues ~170 VALU instructions
+// for the 16 product splits (4 cycles each) and its MFMAs hold the port for 8 cycles apiece; 96 16x16x32 MFMAs
+// (768 cycles of issue) leave less room beside them than 48 32x32x16 ones (384), so here the 32x32x16 shape wins
+// although it clocks lower.  Fewer VALU instructions per split is the remaining lever.
 template <int PASSES>
 __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const float* __restrict__ pT,
                                                                         const float* __restrict__ qT,
