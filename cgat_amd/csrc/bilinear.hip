@@ -247,12 +247,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
       const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
       const float4 t0 = qp[0], t1 = qp[1];
       const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 x1, x2, x3;
-        split3_bf16(v[j], x1, x2, x3);
-        q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
-      }
+      split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
     }
   // acc[2 cb8 + nb][t] = out[row(nb)][16 cb8 + 4 kg + t]
   f32x4 acc[16];
@@ -440,12 +435,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
       const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
       const float4 t0 = qp[0], t1 = qp[1];
       const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 x1, x2, x3;
-        split3_bf16(v[j], x1, x2, x3);
-        q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
-      }
+      split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
     }
   // acc[2 cb + nb][j] = out[row(nb)][64 hf + 16 cb + 4 kg + j];  zr the same elements of zz
   f32x4 acc[8], zr[8];
@@ -652,15 +642,13 @@ __global__ void prepare_T_bf16_rows_kernel(const float* __restrict__ rows, long 
   const long a = i >> 11;
   const long t0 = a * 128 + 32 * s + 8 * kg;
   bf16x8 x1, x2, x3;
+  float vv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const long t = t0 + j;
-    float v = 0.f;
-    if (t < nrows) v = rows[(gather ? (long)gather[t] : t) * ld + c];
-    __bf16 y1, y2, y3;
-    split3_bf16(v, y1, y2, y3);
-    x1[j] = y1; x2[j] = y2; x3[j] = y3;
+    vv[j] = t < nrows ? rows[(gather ? (long)gather[t] : t) * ld + c] : 0.f;
   }
+  split3_x8(vv, x1, x2, x3);
   const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
   const long blk = ((a * 2 + half) * 4 + s) * 3;          // planes of one k-step, each [cb][kg][i] x 16 bytes
   const long in = ((long)cb * 4 + kg) * 16 + i16;
@@ -1120,7 +1108,22 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hi = lane >> 5;
   const int grp = wave >> 2, wb = wave & 3;
-  const int a0 = blockIdx.x * 2, z = blockIdx.y;
+  // XCD-aware placement: workgroups are dealt to the 8 XCDs round-robin by linear id, and every workgroup of a row
+  // split streams the same q^T / r tiles.  With (x, y) = (a pair, split) in natural order each XCD's L2 would serve
+  // all splits' streams at once (27 MB each, 4 MB of L2); remapped, the workgroups sharing an XCD share ONE stream
+  // and run in near lockstep, so the tiles are fetched into that L2 once instead of once per workgroup.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nx = gridDim.x, ny = gridDim.y, total = nx * ny;
+    if (total % 8 == 0 && 8 % ny == 0) {
+      const int lin = by * nx + bx, xcd = lin & 7, w = lin >> 3;   // w-th workgroup of its XCD
+      const int xps = 8 / ny;                                      // XCDs per split
+      by = xcd / xps;
+      bx = (xcd % xps) * (total / 8) + w;                          // a-pair index inside the split
+      if (bx >= nx) { bx = blockIdx.x; by = blockIdx.y; }          // irregular grid: natural order
+    }
+  }
+  const int a0 = bx * 2, z = by;
   const int nbeg = z * rows_per_split;
   const int nend = min(rows_pad, nbeg + rows_per_split);
   const int nchunks = (nend - nbeg) / 32;   // rows_per_split and rows_pad are multiples of 32
@@ -1182,12 +1185,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
       const float av[8] = {pa.x * qa.x, pa.y * qa.y, pa.z * qa.z, pa.w * qa.w,
                            pb.x * qb.x, pb.y * qb.y, pb.z * qb.z, pb.w * qb.w};
       bf16x8 a1, a2v, a3;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 x1, x2, x3;
-        split3_bf16(av[j], x1, x2, x3);
-        a1[j] = x1; a2v[j] = x2; a3[j] = x3;
-      }
+      split3_x8(av, a1, a2v, a3);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];

@@ -62,11 +62,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #define GE_SPLIT(R0_, R1_, Q1_, Q2_, Q3_)                                                                \
   {                                                                                                      \
     const float v[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                         \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-      __bf16 x1, x2, x3;                                                                                 \
-      split3_bf16(v[j], x1, x2, x3);                                                                     \
-      Q1_[j] = x1; Q2_[j] = x2; Q3_[j] = x3;                                                             \
-    }                                                                                                    \
+    split3_x8(v, Q1_, Q2_, Q3_);                                                                         \
   }
   bf16x8 qa1, qa2, qa3, qb1, qb2, qb3;           // current k-step's gZ fragments (rows a, b)
   bf16x8 na1, na2, na3, nb1, nb2, nb3;           // next k-step's
@@ -215,17 +211,12 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     const int idx = gt + 256 * (i_);                                                                     \
     const int row = idx >> 5, c4 = idx & 31;                                                             \
     const int off = 256 * row + 16 * ((c4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (c4 & 1); \
-    const float v[4] = {R_.x * sg_, R_.y * sg_, R_.z * sg_, R_.w * sg_};                                 \
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));                                           \
-    bf16x4 x1, x2, x3;                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-      __bf16 y1, y2, y3;                                                                                 \
-      split3_bf16(v[j], y1, y2, y3);                                                                     \
-      x1[j] = y1; x2[j] = y2; x3[j] = y3;                                                                \
-    }                                                                                                    \
-    *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][0][off]) = x1;                                             \
-    *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][1][off]) = x2;                                             \
-    if (PASSES >= 6) *reinterpret_cast<bf16x4*>(&Gs[buf_][grp][2][off]) = x3;                            \
+    uint2 x1, x2, x3;                                                                                    \
+    split3_pair(R_.x * sg_, R_.y * sg_, x1.x, x2.x, x3.x);                                               \
+    split3_pair(R_.z * sg_, R_.w * sg_, x1.y, x2.y, x3.y);                                               \
+    *reinterpret_cast<uint2*>(&Gs[buf_][grp][0][off]) = x1;                                              \
+    *reinterpret_cast<uint2*>(&Gs[buf_][grp][1][off]) = x2;                                              \
+    if (PASSES >= 6) *reinterpret_cast<uint2*>(&Gs[buf_][grp][2][off]) = x3;                             \
   }
   // transposed fragment of plane pl_, column block nb_ of this wave: k = 8 kg + j  <->  slot 8 kg + j
   const int l16q = n16 >> 2, l16p = n16 & 3;

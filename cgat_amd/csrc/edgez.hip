@@ -60,12 +60,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
         const float4 t0 = qp[0], t1 = qp[1];
         const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          __bf16 x1, x2, x3;
-          split3_bf16(v[j], x1, x2, x3);
-          q1[2 * s + nb][j] = x1; q2[2 * s + nb][j] = x2; q3[2 * s + nb][j] = x3;
-        }
+        split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
       }
   }
   // ADDS: gathered addends Pi[dst], Pj[src] (the edge kernel).  !ADDS: a plain product plus bias, Pi = the bias
