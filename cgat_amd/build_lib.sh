@@ -6,6 +6,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libcgat_hip.so"
 SRCS=(api gemm bilinear edgez edgebwd collate optim rowops segment plan layers)
 OBJS=()
+PIDS=()
 mkdir -p "$HERE/csrc/build"
 for s in "${SRCS[@]}"; do
   src="$HERE/csrc/$s.hip"; obj="$HERE/csrc/build/$s.o"
@@ -13,10 +14,14 @@ for s in "${SRCS[@]}"; do
     extra=""
     # MFMA kernels with VALU epilogues: no SLP packing into v_pk_*_f32 (see the note in csrc/edgez.hip)
     if [ "$s" = edgez ] || [ "$s" = edgebwd ] || [ "$s" = bilinear ]; then extra="-fno-slp-vectorize"; fi
+    rm -f "$obj"     # a failed compile must not leave a stale object behind for the link step
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$src" -o "$obj" ${CGAT_HIPCC_FLAGS} &
+    PIDS+=($!)
   fi
   OBJS+=("$obj")
 done
-wait
+for pid in "${PIDS[@]}"; do
+  wait "$pid" || { echo "build_lib.sh: a compile step failed" >&2; exit 1; }
+done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
 echo "built $OUT"

@@ -1093,7 +1093,7 @@ __global__ void split_rows_bf16_kernel(const float* __restrict__ r, long ldr, in
 // for the 16 product splits (4 cycles each) and its MFMAs hold the port for 8 cycles apiece; 96 16x16x32 MFMAs
 // (768 cycles of issue) leave less room beside them than 48 32x32x16 ones (384), so here the 32x32x16 shape wins
 // although it clocks lower.  Fewer VALU instructions per split is the remaining lever.
-template <int PASSES>
+template <int PASSES, int ABL = 0>   // ABL (timing only, wrong results): 1 no global loads, 2 no split, 4 no barrier
 __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const float* __restrict__ pT,
                                                                         const float* __restrict__ qT,
                                                                         const uint4* __restrict__ Rq,
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nchunks) WG_GLOAD(nbeg + (c + 1) * 32);
+    if constexpr (!(ABL & 1)) { if (c + 1 < nchunks) WG_GLOAD(nbeg + (c + 1) * 32); }
     if ((c & 15) == 0 && c > 0) {   // two-level summation over the long row dimension (512-row partials);
       // groups alternate in sign (see bilinear_rows128_bf16_kernel: cancels the bf16 MFMA's floor bias)
       const float sg = (((c >> 4) - 1) & 1) ? -1.f : 1.f;
@@ -1185,7 +1185,13 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
       const float av[8] = {pa.x * qa.x, pa.y * qa.y, pa.z * qa.z, pa.w * qa.w,
                            pb.x * qb.x, pb.y * qb.y, pb.z * qb.z, pb.w * qb.w};
       bf16x8 a1, a2v, a3;
-      split3_x8(av, a1, a2v, a3);
+      if constexpr (ABL & 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a1[j] = (__bf16)av[j]; }
+        a2v = a1; a3 = a1;
+      } else {
+        split3_x8(av, a1, a2v, a3);
+      }
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
       }
     }
     if (c + 1 < nchunks) WG_LSTORE(cur ^ 1);
-    __syncthreads();
+    if constexpr (!(ABL & 4)) __syncthreads();
   }
 #undef WG_GLOAD
 #undef WG_LSTORE
@@ -1280,7 +1286,12 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     splits = cdiv(np, rps);
     {
       CGAT_PROF("bilinear_wgrad", stream);
-      if (bilinear_mode() == 6)
+      static int abl = -1;
+      if (abl < 0) { const char* e = getenv("CGAT_WGRAD_ABL"); abl = e ? atoi(e) : 0; }
+#define WG_GO(A_) hipLaunchKernelGGL((bilinear_wgrad128_bf16_kernel<6, A_>), dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT, (const uint4*)Rq, slab, np, rps, NA)
+      if (bilinear_mode() == 6 && abl) {
+        switch (abl) { case 1: WG_GO(1); break; case 2: WG_GO(2); break; case 3: WG_GO(3); break; case 4: WG_GO(4); break; default: WG_GO(7); break; }
+      } else if (bilinear_mode() == 6)
         hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<6>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
                            (const uint4*)Rq, slab, np, rps, NA);
       else
