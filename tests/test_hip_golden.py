@@ -215,3 +215,37 @@ def test_million_edge_properties():
     assert torch.isfinite(y).all()
     assert maxnorm_rel(y_perm.cpu().numpy(), y.cpu().numpy()) <= 1e-5
     assert maxnorm_rel(y_sub.cpu().numpy(), y[:n_sub].cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_beyond_int32_element_counts():
+    """7000 crystals -> E = 1 680 000 edges, E x 1536 = 2.58e9 pre-activations (> 2^31 elements): the LAST 50
+    crystals -- where a 32-bit offset would wrap -- give the same outputs and input gradients inside the big batch as
+    evaluated alone (crystals are independent), forward and backward."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    G, A, K = 7000, 20, 12
+    b, _ = P.synthetic_batch(G, A, K, seed=5)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    assert E * 1536 > 2 ** 31
+    torch.manual_seed(1)
+    m = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x, e, x0 = (torch.randn(s, 128, generator=g).to(dev) for s in (N, E, N))
+    ei = b.edge_index.to(dev)
+    n0, e0 = (G - 50) * A, (G - 50) * A * K
+    cot = torch.randn(50 * A, 128, generator=g).to(dev)
+
+    def run(xs, eis, es, x0s, sl):
+        xs, es = xs.clone().requires_grad_(True), es.clone().requires_grad_(True)
+        y = m(xs, eis, es, x0s)
+        gx, ge = torch.autograd.grad((y[sl] * cot).sum(), [xs, es])
+        return y[sl].detach(), gx[sl].detach(), ge
+
+    y_big, gx_big, ge_big = run(x, ei, e, x0, slice(n0, N))
+    y_sub, gx_sub, ge_sub = run(x[n0:].contiguous(), (ei[:, e0:] - n0).contiguous(), e[e0:].contiguous(),
+                                x0[n0:].contiguous(), slice(0, 50 * A))
+    assert torch.isfinite(y_big).all()
+    assert maxnorm_rel(y_big.cpu().numpy(), y_sub.cpu().numpy()) <= 1e-5
+    assert maxnorm_rel(gx_big.cpu().numpy(), gx_sub.cpu().numpy()) <= 1e-5
+    assert maxnorm_rel(ge_big[e0:].cpu().numpy(), ge_sub.cpu().numpy()) <= 1e-5
