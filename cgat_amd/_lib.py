@@ -113,6 +113,12 @@ PROTOTYPES = {
     "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cgat_bilinear_rows": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
+    "cgat_edge_hidden_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32]),
+    "cgat_edge_hidden_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32]),
+    "cgat_edge_hidden_forward": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp,
+                                           C.c_size_t, vp]),
+    "cgat_edge_hidden_backward": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp,
+                                            vp, vp, vp, C.c_size_t, vp]),
     "cgat_mt_chunk_elems": (C.c_int32, []),
     "cgat_adamw_step": (C.c_int, [vp, vp, vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int64, vp]),

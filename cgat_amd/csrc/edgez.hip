@@ -154,6 +154,12 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
         float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
         float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
+        if (act == CGAT_ACT_LEAKY) {   // store the hidden activations instead of the pre-activations (edge_hidden op)
+          va = make_float4(va.x > 0.f ? va.x : 0.01f * va.x, va.y > 0.f ? va.y : 0.01f * va.y,
+                           va.z > 0.f ? va.z : 0.01f * va.z, va.w > 0.f ? va.w : 0.01f * va.w);
+          vb = make_float4(vb.x > 0.f ? vb.x : 0.01f * vb.x, vb.y > 0.f ? vb.y : 0.01f * vb.y,
+                           vb.z > 0.f ? vb.z : 0.01f * vb.z, vb.w > 0.f ? vb.w : 0.01f * vb.w);
+        }
         if (!ADDS) {   // the dense-layer form: out = act(x W^T + b) [+ out]
           if (act == CGAT_ACT_TANH) {
             va = make_float4(tanhf(va.x), tanhf(va.y), tanhf(va.z), tanhf(va.w));
@@ -212,7 +218,7 @@ size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
 // the per-node projections of the operand split.
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
-                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream) {
+                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int act) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
@@ -221,7 +227,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
-                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, 0, 0)
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0)
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 6) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
   else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }

@@ -84,7 +84,8 @@ bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz,
 size_t edge_z_wq_floats(int W2);
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
-                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
+                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
+                  int act = CGAT_ACT_NONE);
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream);
 // dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]

@@ -381,6 +381,68 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   return check_ws(c, "nodes_attention_forward");
 }
 
+// Everything downstream of the pre-activation gradient gZ[t, :] (destination-sorted slots; element (t, 128 a + j) at
+// gZ[t * gz_ld + a * gzb + j]) of the operand-split first layer: gradients wrt edge_attr, x, the stacked weight
+// [W2, D] = [W_i | W_e | W_j] and its bias.  Shared by the scalar-attention backward (gZ from the fused segment
+// kernel, column-blocked, Gi already summed) and the edge_hidden op (gZ row-major from autograd).
+static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* Wcat,
+                                          float* gWcat, float* gbcat, const float* gZ, long gz_ld, long gzb, float* Gi,
+                                          float* Gj, bool have_Gi, const float* x, const float* e, float* g_x, float* g_e,
+                                          float* Wq, float* gw_ws) {
+  const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
+  // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
+  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
+    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, c.s));
+  } else {
+    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
+    g.a_block = xb;
+    g.b_kmajor = 1;
+    g.c_scatter = plan->dst_perm;
+    CGAT_TRY(c.gemm(g));
+  }
+  // grad W_e = gZ^T @ e[perm]
+  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
+    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
+  } else {
+    GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
+    g.a_block = xb;
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.b_kgather = plan->dst_perm;
+    CGAT_TRY(c.gemm(g, true));
+  }
+  // segment sums of gZ: by destination (x_i side) unless the caller already has them, by source (x_j side)
+  if (!have_Gi)
+    RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
+  RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
+                      c.s, xb));
+  // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
+  // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
+  // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
+  if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
+      ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
+    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, c.s));
+    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, c.s));
+    RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s));
+    RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s));
+  } else {
+    GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
+    g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.N, d.C, d.W2, Gj, d.W2, Wcat + d.C + d.Ce, d.D, g_x, d.C);
+    g.b_kmajor = 1;
+    g.beta = 1.f;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.W2, d.C, d.N, Gi, d.W2, x, d.C, gWcat, d.D);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g, true));
+    g = gemm_params(d.W2, d.C, d.N, Gj, d.W2, x, d.C, gWcat + d.C + d.Ce, d.D);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    CGAT_TRY(c.gemm(g, true));
+  }
+  CGAT_TRY(c.colsum(Gi, d.W2, d.N, d.W2, gbcat, 1.f));
+  return CGAT_OK;
+}
+
 static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_params* p, const float* x, const float* e,
                               const float* saved, const float* g_aggr, float* g_x, float* g_e,
                               const cgat_attn_grads* gr) {
@@ -452,59 +514,114 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   }
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
-  // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
-  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
-    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, c.s));
-  } else {
-    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
-    g.a_block = gzb;
-    g.b_kmajor = 1;
-    g.c_scatter = plan->dst_perm;
-    CGAT_TRY(c.gemm(g));
-  }
-  // grad W_e = gZ^T @ e[perm]
-  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
-    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
-  } else {
-    GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
-    g.a_block = gzb;
-    g.a_kmajor = 1; g.b_kmajor = 1;
-    g.b_kgather = plan->dst_perm;
-    CGAT_TRY(c.gemm(g, true));
-  }
-  // segment sum of gZ by source (x_j side); the destination side came out of the fused kernel
-  RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
-                      c.s, gzb));
-  // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
-  // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
-  // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
-  if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
-      ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
-    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, c.s));
-    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, c.s));
-    RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s));
-    RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s));
-  } else {
-    GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
-    g.b_kmajor = 1;
-    CGAT_TRY(c.gemm(g));
-    g = gemm_params(d.N, d.C, d.W2, Gj, d.W2, Wcat + d.C + d.Ce, d.D, g_x, d.C);
-    g.b_kmajor = 1;
-    g.beta = 1.f;
-    CGAT_TRY(c.gemm(g));
-    g = gemm_params(d.W2, d.C, d.N, Gi, d.W2, x, d.C, gWcat, d.D);
-    g.a_kmajor = 1; g.b_kmajor = 1;
-    CGAT_TRY(c.gemm(g, true));
-    g = gemm_params(d.W2, d.C, d.N, Gj, d.W2, x, d.C, gWcat + d.C + d.Ce, d.D);
-    g.a_kmajor = 1; g.b_kmajor = 1;
-    CGAT_TRY(c.gemm(g, true));
-  }
-  CGAT_TRY(c.colsum(Gi, d.W2, d.N, d.W2, gbcat, 1.f));
+  CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, gZ, gz_ld, gzb, Gi, Gj, true, x, e, g_x, g_e, Wq,
+                                          gw_ws));
   RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));
   RUN(copy2d_launch(gbcat + d.HHd, d.HHd, gr->M_in_b, d.HHd, 1, d.HHd, c.s));
   return check_ws(c, "nodes_attention_backward");
+}
+
+// =======================================================================================
+// edge_hidden: H[t, :] = LeakyReLU( W_in [x_i ; edge_attr ; x_j] + b ) for all heads of any number of message networks
+// stacked in W_in [W2, D], rows in destination-sorted slot order t (plan->dst_perm).  The first layer of
+// MultiHeadNetwork (CGAT.py:96,105-108) with the operand split; used by the vector-attention variants, whose second
+// layers / channel-wise softmax then run on H (CGAT.py:286-290, 319-329).
+// =======================================================================================
+static AttnDims hidden_dims(const cgat_plan* plan, int C, int Ce, int W2) {
+  AttnDims d;
+  d.N = plan->N; d.E = plan->E; d.C = C; d.Ce = Ce; d.H = 1; d.Hd = W2 / 2; d.D = 2 * C + Ce; d.HHd = W2 / 2; d.W2 = W2;
+  return d;
+}
+
+static int edge_hidden_forward_impl(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* w_in,
+                                    const float* b_in, const float* x, const float* e, float* Hout) {
+  float* Pi = c.take<float>((size_t)d.N * d.W2);
+  float* Pj = c.take<float>((size_t)d.N * d.W2);
+  float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
+  c.seal();
+  const bool fast = !c.dry && d.N > 0 && d.W2 % 256 == 0 && d.C == 128 &&
+                    edge_z_fast(d.Ce, d.W2, 1, d.W2 / 2, d.Ce, d.W2, d.W2, e, Pi, Pj, Hout, b_in) &&
+                    (((uintptr_t)x) & 15) == 0;
+  if (fast) {
+    RUN(edge_z_launch(x, d.C, nullptr, w_in, d.D, Wq, d.W2, b_in, nullptr, nullptr, nullptr, 0, Pi, d.W2, d.N, nullptr,
+                      nullptr, 1, d.W2 / 2, nullptr, c.s));
+    RUN(edge_z_launch(x, d.C, nullptr, w_in + d.C + d.Ce, d.D, Wq, d.W2, nullptr, nullptr, nullptr, nullptr, 0, Pj, d.W2,
+                      d.N, nullptr, nullptr, 1, d.W2 / 2, nullptr, c.s));
+    RUN(edge_z_launch(e, d.Ce, plan->dst_perm, w_in + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted, d.W2,
+                      Hout, d.W2, d.E, nullptr, nullptr, 1, d.W2 / 2, nullptr, c.s, CGAT_ACT_LEAKY));
+  } else {
+    GemmParams g = gemm_params(d.N, d.W2, d.C, x, d.C, w_in, d.D, Pi, d.W2);
+    g.bias = b_in;
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.N, d.W2, d.C, x, d.C, w_in + d.C + d.Ce, d.D, Pj, d.W2);
+    CGAT_TRY(c.gemm(g));
+    g = gemm_params(d.E, d.W2, d.Ce, e, d.Ce, w_in + d.C, d.D, Hout, d.W2);
+    g.a_rgather = plan->dst_perm;
+    g.add1 = Pi; g.add1_idx = plan->dst_sorted;
+    g.add2 = Pj; g.add2_idx = plan->src_sorted;
+    g.ld_add = d.W2;
+    g.act = CGAT_ACT_LEAKY;
+    CGAT_TRY(c.gemm(g));
+  }
+  return check_ws(c, "edge_hidden_forward");
+}
+
+static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* w_in, const float* x,
+                                     const float* e, const float* Hsaved, const float* g_H, float* g_x, float* g_e,
+                                     float* g_w_in, float* g_b_in) {
+  float* gZ = c.take<float>((size_t)d.E * d.W2);
+  float* Gi = c.take<float>((size_t)d.N * d.W2);
+  float* Gj = c.take<float>((size_t)d.N * d.W2);
+  float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
+  float* gw_ws = c.take<float>(edge_gw_ws_floats(d.E, d.W2));
+  c.seal();
+  RUN(act_bwd_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, CGAT_ACT_LEAKY, c.s));
+  CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, w_in, g_w_in, g_b_in, gZ, d.W2, 128, Gi, Gj, false, x, e, g_x, g_e, Wq,
+                                          gw_ws));
+  return check_ws(c, "edge_hidden_backward");
+}
+
+static int hidden_check(const cgat_plan* plan, int C, int Ce, int W2) {
+  CGAT_CHECK_ARG(plan && plan->N >= 0 && plan->E >= 0, "edge_hidden: bad plan");
+  CGAT_CHECK_ARG(C > 0 && Ce > 0 && W2 > 0, "edge_hidden: bad dims C=%d Ce=%d W2=%d", C, Ce, W2);
+  return CGAT_OK;
+}
+extern "C" size_t cgat_edge_hidden_forward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2) {
+  Ctx c(nullptr, 0, true, nullptr);
+  edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), nullptr, nullptr, nullptr, nullptr, nullptr);
+  return c.total();
+}
+extern "C" size_t cgat_edge_hidden_backward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2) {
+  Ctx c(nullptr, 0, true, nullptr);
+  edge_hidden_backward_impl(c, plan, hidden_dims(plan, C, Ce, W2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr);
+  return c.total();
+}
+extern "C" int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in,
+                                        const float* b_in, const float* x, const float* edge_attr, float* hidden,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  CGAT_TRY(hidden_check(plan, C, Ce, W2));
+  if (ws_bytes < cgat_edge_hidden_forward_workspace_bytes(plan, C, Ce, W2)) {
+    cgat_set_error("edge_hidden_forward: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  return edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), w_in, b_in, x, edge_attr, hidden);
+}
+extern "C" int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in,
+                                         const float* x, const float* edge_attr, const float* hidden,
+                                         const float* g_hidden, float* g_x, float* g_edge_attr, float* g_w_in,
+                                         float* g_b_in, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_TRY(hidden_check(plan, C, Ce, W2));
+  if (ws_bytes < cgat_edge_hidden_backward_workspace_bytes(plan, C, Ce, W2)) {
+    cgat_set_error("edge_hidden_backward: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  return edge_hidden_backward_impl(c, plan, hidden_dims(plan, C, Ce, W2), w_in, x, edge_attr, hidden, g_hidden, g_x,
+                                   g_edge_attr, g_w_in, g_b_in);
 }
 
 static int attn_check(const cgat_plan* plan, const cgat_attn_params* p) {

@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+from .ops import (EdgeHiddenFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
                   segment_softmax, segment_sum)
 from .roost import Roost
 
@@ -174,7 +174,27 @@ class GATConvNodes(nn.Module):
         return NodesAttentionFn.apply(x, edge_attr, plan, self.heads, a.fc_in.weight, a.fc_in.bias, a.fc_out.weight,
                                       a.fc_out.bias, m.fc_in.weight, m.fc_in.bias, m.fc_out.weight, m.fc_out.bias)
 
-    # -- MessagePassing-style surface (vector attention, or subclasses overriding message) --
+    # -- vector attention (CGAT.py:286-290: MH_A emits one logit per head AND channel): the shared first layer of both
+    #    networks runs as one operand-split op in destination-sorted order, so the concatenated message [E, 2C+Ce],
+    #    its K = 2C+Ce products and the two permutations of the generic path disappear --------------------------------
+    def _aggregate_vector(self, x, edge_attr, plan, edge_index):
+        a, m = self.MH_A, self.MH_M
+        H, Hd, Co = self.heads, a.hidden_layer_dim, self.out_channels
+        D = a.input_dim
+        w_in = torch.cat([a.fc_in.weight.reshape(H * Hd, D), m.fc_in.weight.reshape(H * Hd, D)], dim=0)
+        b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
+        hid = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                             # [E, 2*H*Hd], sorted slots
+        E = hid.shape[0]
+
+        def second(net, off):
+            return torch.stack([linear(hid[:, off + h * Hd:off + (h + 1) * Hd], net.fc_out.weight[h * Co:(h + 1) * Co],
+                                       net.fc_out.bias[h * Co:(h + 1) * Co]) for h in range(H)], dim=1)   # [E,H,Co]
+        alpha = SegmentSoftmaxFn.apply(second(a, 0).reshape(E, -1), None, plan.dst_rowptr, 1e-16)
+        msg = second(m, H * Hd).reshape(E, -1) * alpha
+        agg = SegmentSumFn.apply(msg, plan.dst_rowptr, plan.dst_sorted.long())
+        return agg.reshape(plan.N, H, Co).mean(dim=1)
+
+    # -- MessagePassing-style surface (subclasses overriding message) --
     def message(self, x_i, x_j, edge_attr, edge_index_i, plan=None):
         m = torch.cat([x_i, edge_attr, x_j], dim=-1)
         alpha = self.MH_A(m)
@@ -189,6 +209,8 @@ class GATConvNodes(nn.Module):
         plan = get_plan(edge_index, x.shape[0])
         if not self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
             aggr = self._aggregate_fused(x, edge_attr, plan)
+        elif self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
+            aggr = self._aggregate_vector(x, edge_attr, plan, edge_index)
         else:
             if self.dropout:
                 raise NotImplementedError("attention dropout is always 0 in the reference stack")

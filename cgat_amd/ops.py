@@ -172,6 +172,47 @@ class NodesAttentionFn(torch.autograd.Function):
         return (g_x, g_e, None, None, *grads)
 
 
+class EdgeHiddenFn(torch.autograd.Function):
+    """hidden[t] = LeakyReLU(w_in [x_i ; edge_attr ; x_j] + b_in) in destination-sorted slot order t (plan.dst_perm):
+    the first layer of both message networks (reference CGAT.py:96,105-108 on the concatenated message of 316-318)
+    with the operand split, for the vector-attention variants whose second layers need every hidden row."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, plan, w_in, b_in):
+        _require_gpu(x, edge_attr, w_in, b_in)
+        x, edge_attr, w_in, b_in = _f32c(x), _f32c(edge_attr), _f32c(w_in.detach()), _f32c(b_in.detach())
+        N, E = plan.N, plan.E
+        Cn, Ce, W2 = x.shape[1], edge_attr.shape[1], w_in.shape[0]
+        if x.shape[0] != N or edge_attr.shape[0] != E or w_in.shape[1] != 2 * Cn + Ce or b_in.numel() != W2:
+            raise ValueError("EdgeHiddenFn: shapes do not match the plan / the stacked first-layer weight")
+        dev = x.device
+        hidden = torch.empty(E, W2, dtype=torch.float32, device=dev)
+        ws = workspace(lib.cgat_edge_hidden_forward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_edge_hidden_forward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(b_in), _ptr(x),
+                                               _ptr(edge_attr), _ptr(hidden), _ptr(ws), ws.numel(), _stream()),
+                  "cgat_edge_hidden_forward")
+        ctx.plan = plan
+        ctx.save_for_backward(x, edge_attr, w_in, hidden)
+        return hidden
+
+    @staticmethod
+    def backward(ctx, g_hidden):
+        x, edge_attr, w_in, hidden = ctx.saved_tensors
+        plan = ctx.plan
+        g_hidden = _f32c(g_hidden)
+        Cn, Ce, W2 = x.shape[1], edge_attr.shape[1], w_in.shape[0]
+        dev = x.device
+        g_x, g_e = torch.empty_like(x), torch.empty_like(edge_attr)
+        g_w, g_b = torch.empty_like(w_in), torch.empty(W2, dtype=torch.float32, device=dev)
+        ws = workspace(lib.cgat_edge_hidden_backward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_edge_hidden_backward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(x), _ptr(edge_attr),
+                                                _ptr(hidden), _ptr(g_hidden), _ptr(g_x), _ptr(g_e), _ptr(g_w), _ptr(g_b),
+                                                _ptr(ws), ws.numel(), _stream()), "cgat_edge_hidden_backward")
+        return g_x, g_e, None, g_w, g_b
+
+
 # ----------------------------------------------------------------------------------------
 # hypernetwork Pooling_NN
 # ----------------------------------------------------------------------------------------

@@ -154,6 +154,21 @@ int cgat_nodes_attention_backward(const cgat_plan* plan, const cgat_attn_params*
                                   float* g_x /* [N,C] */, float* g_edge_attr /* [E,Ce] */, const cgat_attn_grads* g,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---- first layer of the message networks alone (vector-attention variants) ---------------
+ * hidden[t, :] = LeakyReLU(w_in [x_i ; edge_attr ; x_j] + b_in), t = destination-sorted edge slot (plan.dst_perm),
+ * for the stacked first-layer weights w_in [W2, 2C+Ce] of any number of heads / networks: MultiHeadNetwork's
+ * repeat + grouped Conv1d + LeakyReLU (CGAT/CGAT.py:96,105-108) on m = cat[x_i, edge_attr, x_j] (CGAT.py:316-318),
+ * computed with the operand split and never materialising m.  The channel-wise attention of
+ * vector_attention=True (CGAT.py:286-290) applies the second layers and the softmax to `hidden`. */
+size_t cgat_edge_hidden_forward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2);
+size_t cgat_edge_hidden_backward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2);
+int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in /* [W2,2C+Ce] */,
+                             const float* b_in /* [W2] */, const float* x /* [N,C] */, const float* edge_attr /* [E,Ce] */,
+                             float* hidden /* [E,W2] */, void* ws, size_t ws_bytes, void* stream);
+int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in, const float* x,
+                              const float* edge_attr, const float* hidden, const float* g_hidden, float* g_x,
+                              float* g_edge_attr, float* g_w_in, float* g_b_in, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- H_Net_0 / H_Net: hypernetwork Pooling_NN -------------------------------------------
  * replaces CGAT/Hypernetworksmp.py:257-313 (HyperFC of n_hyper predicted layers, each with its
  * own FCBlock trunk of n_fc Linear+Tanh and a Linear(W -> W*W+W) head; LayerNorm(no affine,

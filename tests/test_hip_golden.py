@@ -139,6 +139,22 @@ def test_nodes_layer_vs_oracle_random_init(first):
                          lambda: O.GATConvNodes(128, 128, 128, 3, concat=True, first=first), inputs, call)
 
 
+@pytest.mark.gpu
+def test_vector_attention_layer_vs_oracle_random_init():
+    """vector_attention=True (the reference harness' shipped default) at the BASELINE widths: the
+    operand-split first layer (edge_hidden op on the split-bf16 kernels) + channel-wise softmax against the oracle."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = P.synthetic_batch(60, 20, 12, seed=3)
+    g = torch.Generator().manual_seed(4)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True, vector_attention=True),
+                         lambda: O.GATConvNodes(128, 128, 128, 3, concat=True, vector_attention=True), inputs, call)
+
+
 def test_ragged_graphs_vs_oracle():
     """Ragged crystals (2..40 atoms), K=24 neighbours, H=5: the DCGAT-like shape of config 4."""
     import cgat_amd as P
