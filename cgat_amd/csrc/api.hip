@@ -90,20 +90,48 @@ extern "C" int cgat_csr_from_keys(const int32_t* keys, int32_t n, int32_t S, int
 }
 
 // ---- dense layer ----
+// split-bf16 routes of the dense layer (default arithmetic mode): K == 128 -> any multiple of 128 outputs on the
+// edge_z kernel (rows split once, weights through the LDS-DMA ring); K a multiple of 128 -> 128 outputs on the edge_ge
+// kernel (rows split in the loop).  Everything else, and the f32 mode, runs on the generic f32 GEMM engine.
+static bool linear_route_z(int K, int N, int act, long ldx, long ldy, const void* x, const void* y) {
+  return (act == CGAT_ACT_NONE || act == CGAT_ACT_TANH || act == CGAT_ACT_LEAKY) && linear128_fast(K, N, ldx, ldy, x, y);
+}
+static bool linear_route_ge(int K, int N, int act, long ldx, long ldy, const void* x, const void* y) {
+  return act == CGAT_ACT_NONE && N == 128 && K > 128 && edge_ge_fast(128, K, ldx, 128, ldy, x, y);
+}
+extern "C" size_t cgat_linear_forward_workspace_bytes(int32_t M, int32_t K, int32_t N) {
+  (void)M;
+  const size_t a = (K == 128 && N % 128 == 0) ? linear128_ws_bytes(N) : 0;
+  const size_t b = (N == 128 && K % 128 == 0) ? edge_z_wq_floats(K) * sizeof(float) : 0;
+  return (a > b ? a : b) + 256;
+}
 extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
-                                   float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* stream) {
+                                   float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* ws,
+                                   size_t ws_bytes, void* stream) {
   CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0, "linear_forward: negative size");
+  hipStream_t s = (hipStream_t)stream;
+  const bool have_ws = ws && ws_bytes >= cgat_linear_forward_workspace_bytes(M, K, N);
+  if (have_ws && (!bias || (((uintptr_t)bias) & 15) == 0)) {
+    if (linear_route_z(K, N, act, ldx, ldy, x, y))
+      return linear128_launch(x, ldx, w, ldw, 1, bias, act, 0, y, ldy, M, ws, s, N);
+    if (linear_route_ge(K, N, act, ldx, ldy, x, y))
+      return edge_ge_launch(x, ldx, 128, w, 1, ldw, (float*)ws, K, y, ldy, nullptr, M, 0, bias, s);
+  }
   GemmParams g = gemm_params(M, N, K, x, ldx, w, ldw, y, ldy);
   g.bias = bias;
   g.act = act;
-  return gemm_launch(g, nullptr, 0, (hipStream_t)stream);
+  return gemm_launch(g, nullptr, 0, s);
 }
-
 extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N) {
   int splits = gemm_pick_splits(N, K, M);
   size_t a = splits > 1 ? ws_round((size_t)splits * N * K, 4) : 0;
   size_t b = colsum_ws_bytes(M, N);
-  return (a > b ? a : b) + 256;
+  // g_x = gpre W on the split-bf16 kernels: N == 128 inputs -> K outputs (edge_z route) or N > 128 -> 128 outputs
+  size_t c = (N == 128 && K % 128 == 0) ? linear128_ws_bytes(K) : 0;
+  if (K == 128 && N % 128 == 0 && edge_z_wq_floats(N) * sizeof(float) > c) c = edge_z_wq_floats(N) * sizeof(float);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return a + 256;
 }
 
 extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
@@ -121,11 +149,20 @@ extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w,
     gp = gpre;
     ldgp = N;
   }
-  if (g_x) {  // g_x = gpre @ W
-    GemmParams g = gemm_params(M, K, N, gp, ldgp, w, ldw, g_x, ldgx);
-    g.b_kmajor = 1;
-    g.beta = accumulate_gx ? 1.f : 0.f;
-    CGAT_TRY(gemm_launch(g, nullptr, 0, s));
+  if (g_x) {  // g_x = gpre @ W   (W [N, K]: "inputs" are the N columns of gpre, "outputs" the K columns of g_x)
+    const bool have_ws = ws && ws_bytes >= cgat_linear_backward_workspace_bytes(M, K, N);
+    if (have_ws && N == 128 && linear128_fast(N, K, ldgp, ldgx, gp, g_x)) {
+      // weight seen as out(o = k) x in(n): element W[n * ldw + k]  ->  so = 1, sk = ldw
+      CGAT_TRY(linear128_launch(gp, ldgp, w, 1, ldw, nullptr, CGAT_ACT_NONE, accumulate_gx, g_x, ldgx, M, ws, s, K));
+    } else if (have_ws && K == 128 && N > 128 && edge_ge_fast(128, N, ldgp, 128, ldgx, gp, g_x)) {
+      // inputs n (N of them) -> 128 outputs k: element (col = n, out = k) at W[n * ldw + k]
+      CGAT_TRY(edge_ge_launch(gp, ldgp, 128, w, ldw, 1, (float*)ws, N, g_x, ldgx, nullptr, M, accumulate_gx, nullptr, s));
+    } else {
+      GemmParams g = gemm_params(M, K, N, gp, ldgp, w, ldw, g_x, ldgx);
+      g.b_kmajor = 1;
+      g.beta = accumulate_gx ? 1.f : 0.f;
+      CGAT_TRY(gemm_launch(g, nullptr, 0, s));
+    }
   }
   if (g_w) {  // g_W = gpre^T @ x
     GemmParams g = gemm_params(N, K, M, gp, ldgp, x, ldx, g_w, ldgw);

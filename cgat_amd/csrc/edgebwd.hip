@@ -16,7 +16,8 @@ template <int PASSES>
 __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Wq, int ncb,
                                                          float* __restrict__ out, long ldo,
-                                                         const int* __restrict__ scatter, int E, int accumulate) {
+                                                         const int* __restrict__ scatter, int E, int accumulate,
+                                                         const float* __restrict__ bias) {
   __shared__ uint4 Bs[2][1536];                  // [buffer][half][plane][cb][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
@@ -122,17 +123,19 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   const long oa = scatter ? (long)scatter[rca] : rca, ob = scatter ? (long)scatter[rcb] : rcb;
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + 16 * g + 4 * kg);
     if (row_a < E) {
       const f32x4 v = acc[2 * g + 0];
       float4* o = reinterpret_cast<float4*>(out + oa * ldo + 16 * g + 4 * kg);
-      float4 w = make_float4(v[0], v[1], v[2], v[3]);
+      float4 w = make_float4(v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w);
       if (accumulate) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }
       *o = w;
     }
     if (row_b < E) {
       const f32x4 v = acc[2 * g + 1];
       float4* o = reinterpret_cast<float4*>(out + ob * ldo + 16 * g + 4 * kg);
-      float4 w = make_float4(v[0], v[1], v[2], v[3]);
+      float4 w = make_float4(v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w);
       if (accumulate) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }
       *o = w;
     }
@@ -328,21 +331,23 @@ bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, 
          (ldo % 4) == 0 && ((((uintptr_t)gZ) | ((uintptr_t)out)) & 15) == 0;
 }
 
-// We: element (col, k) at We[col * ldw + k] (col < W2, k < 128).  Wq: edge_z_wq_floats(W2) floats of workspace.
-int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long ldw, float* Wq, int W2, float* out,
-                   long ldo, const int* scatter, int E, int accumulate, hipStream_t stream) {
+// We: element (col, k) at We[col * s_col + k * s_out] (col < W2 inputs, k < 128 outputs).  Wq: edge_z_wq_floats(W2)
+// floats of workspace.  bias [128] or null (added to the product, before any accumulation into `out`).
+int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
+                   float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
+                   hipStream_t stream) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
-  // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * ldw + c]
-  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, ldw, 1, 0, stream));
+  // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * s_col + c * s_out]
+  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));
   CGAT_PROF("edge_ge", stream);
   const int grid = cdiv(E, 256);
   if (bilinear_mode() == 6)
     hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate);
+                       scatter, E, accumulate, bias);
   else
     hipLaunchKernelGGL(edge_ge_kernel<3>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate);
+                       scatter, E, accumulate, bias);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -242,20 +242,21 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
 // Here they run as the one-column-block case of the kernel above (rows split once into registers, 96 KB of weight
 // planes through the LDS-DMA ring).
 bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out) {
-  return bilinear_mode() != 0 && K == 128 && N == 128 && (ldi % 4) == 0 && (ldo % 4) == 0 &&
+  return bilinear_mode() != 0 && K == 128 && N >= 128 && N % 128 == 0 && (ldi % 4) == 0 && (ldo % 4) == 0 &&
          ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
 }
-size_t linear128_ws_bytes() { return ws_round((size_t)128 * 128 * 3 / 2 + 4, 4); }
+size_t linear128_ws_bytes(int n_out) { return ws_round((size_t)n_out * 128 * 3 / 2 + 4, 4); }
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
-                     float* out, long ldo, int rows, void* ws, hipStream_t stream) {
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out) {
   if (rows <= 0) return CGAT_OK;
-  // operand (a = 0, b = k, c = output) = W[c * so + b * sk]
-  CGAT_TRY(prepare_T_bf16_launch(W, ws, 1, 0, sk, so, 0, stream));
+  const int ncb = n_out / 128;
+  // operand (a = output block, b = k, c = output in block) = W[(128 a + c) * so + b * sk]
+  CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
   CGAT_PROF("linear128", stream);
   const int grid = cdiv(rows, 128);
 #define L128_GO(P_)                                                                                                   \
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
-                     (const uint4*)ws, 1, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l,  \
+                     (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate)
   if (bilinear_mode() == 6) L128_GO(6); else L128_GO(3);
 #undef L128_GO

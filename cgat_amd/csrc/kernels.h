@@ -90,9 +90,9 @@ int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, in
                                hipStream_t stream);
 // dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]
 bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out);
-size_t linear128_ws_bytes();
+size_t linear128_ws_bytes(int n_out = 128);
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
-                     float* out, long ldo, int rows, void* ws, hipStream_t stream);
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out = 128);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
 // operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);
@@ -100,8 +100,9 @@ size_t edge_gw_ws_floats(int E, int W2);
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
                    float* ws, float* out, long ldo, hipStream_t stream);
 bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
-int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long ldw, float* Wq, int W2, float* out,
-                   long ldo, const int* scatter, int E, int accumulate, hipStream_t stream);
+int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
+                   float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
+                   hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

@@ -392,7 +392,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
   // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
   if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
-    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, c.s));
+    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s));
   } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = xb;
@@ -420,8 +420,8 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
   if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
       ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
-    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, c.s));
-    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, c.s));
+    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, nullptr, c.s));
+    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, nullptr, c.s));
     RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s));
     RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s));
   } else {

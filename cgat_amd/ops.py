@@ -292,7 +292,10 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
         _require_gpu(x, w, b)
-        x = _f32c(x)
+        # a column slice of a wider matrix (one head's hidden block) is passed with its row stride, not copied
+        if not (x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and
+                x.data_ptr() % 16 == 0):
+            x = _f32c(x)
         w2 = w.detach().reshape(w.shape[0], -1)
         if w2.stride(1) != 1:
             w2 = w2.contiguous()
@@ -302,9 +305,10 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = w2.shape[0]
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.cgat_linear_forward_workspace_bytes(M, K, N), x.device)
         with torch.cuda.device(x.device):
-            check(lib.cgat_linear_forward(_ptr(x), K, _ptr(w2), w2.stride(0), _ptr(bb), _ptr(y), N, M, K, N, act,
-                                          _stream()), "cgat_linear_forward")
+            check(lib.cgat_linear_forward(_ptr(x), x.stride(0), _ptr(w2), w2.stride(0), _ptr(bb), _ptr(y), N, M, K, N, act,
+                                          _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
         ctx.act, ctx.has_b, ctx.wshape = act, b is not None, w.shape
         ctx.save_for_backward(x, w2, y)
         return y
@@ -317,12 +321,12 @@ class LinearFn(torch.autograd.Function):
         N = w2.shape[0]
         dev = x.device
         gpre = torch.empty_like(y) if ctx.act != _lib.ACT_NONE else None
-        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_x = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         g_w = torch.empty(N, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         g_b = torch.empty(N, dtype=torch.float32, device=dev) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         ws = workspace(lib.cgat_linear_backward_workspace_bytes(M, K, N), dev)
         with torch.cuda.device(dev):
-            check(lib.cgat_linear_backward(_ptr(x), K, _ptr(w2), w2.stride(0), _ptr(y), N, _ptr(g_y), N, _ptr(gpre),
+            check(lib.cgat_linear_backward(_ptr(x), x.stride(0), _ptr(w2), w2.stride(0), _ptr(y), N, _ptr(g_y), N, _ptr(gpre),
                                            _ptr(g_x), K, 0, _ptr(g_w), K, _ptr(g_b), M, K, N, ctx.act, _ptr(ws),
                                            ws.numel(), _stream()), "cgat_linear_backward")
         return g_x, (None if g_w is None else g_w.reshape(ctx.wshape)), g_b, None

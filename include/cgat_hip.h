@@ -211,9 +211,12 @@ int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0,
  * replaces the Linear/LeakyReLU/ReLU/Tanh pairs of CGAT/message_changed.py:58-63,124-130,
  * CGAT/roost_message.py:348-352 and one head of MultiHeadNetwork (CGAT/CGAT.py:103-109).
  * act: 0 none, 1 tanh, 2 LeakyReLU(0.01), 3 ReLU.  ldx/ldw/ldy are row strides in floats. */
+size_t cgat_linear_forward_workspace_bytes(int32_t M, int32_t K, int32_t N);
 size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N);
+/* ws may be NULL (then the generic f32 GEMM engine is used for every shape) */
 int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                        int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* stream);
+                        int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
+                        void* stream);
 /* gpre = g_y * act'(y) is written to `gpre` [M,N] (caller buffer); g_x += or = per accumulate_gx */
 int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
                          const float* g_y, int64_t ldgy, float* gpre /* [M,N] dense */, float* g_x, int64_t ldgx,

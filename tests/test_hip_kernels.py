@@ -296,3 +296,31 @@ def test_segment_softmax(env, F, with_mult):
     assert rel(al.detach(), ref.detach()) <= TOL
     for got, want in zip(grads, rg):
         assert rel(got, want) <= 5e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 128), (513, 128, 256), (300, 384, 128), (64, 96, 40)])
+@pytest.mark.parametrize("act", ["none", "leaky", "tanh"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_linear_routes(env, M, K, N, act, mode):
+    """cgat_linear_forward/backward through ops.LinearFn: the split-bf16 routes (K == 128, or 128 outputs) and the
+    generic engine, with a strided input slice (one head's block of a wider hidden matrix), vs fp64."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode(mode)
+    g = torch.Generator().manual_seed(M + K + N)
+    wide = torch.randn(M, K + 128, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    cot = torch.randn(M, N, generator=g).to(dev)
+    code = {"none": _lib.ACT_NONE, "leaky": _lib.ACT_LEAKY, "tanh": _lib.ACT_TANH}[act]
+    x = wide[:, 128:]                                    # row stride K + 128, 16-byte aligned
+    y = ops.linear(x, w, b, code)
+    gw_, gww, gb = torch.autograd.grad((y * cot).sum(), [wide, w, b])
+    ops.set_bilinear_mode("bf16x6")
+    xd, wd, bd = wide.detach().double()[:, 128:].requires_grad_(True), w.detach().double().requires_grad_(True), \
+        b.detach().double().requires_grad_(True)
+    pre = xd @ wd.t() + bd
+    ref = {"none": pre, "leaky": torch.nn.functional.leaky_relu(pre, 0.01), "tanh": torch.tanh(pre)}[act]
+    rx, rw, rb = torch.autograd.grad((ref * cot.double()).sum(), [xd, wd, bd])
+    assert rel(y, ref.detach()) <= TOL
+    assert rel(gw_[:, 128:], rx) <= TOL and float(gw_[:, :128].abs().max()) == 0.0
+    assert rel(gww, rw) <= TOL and rel(gb, rb) <= TOL
