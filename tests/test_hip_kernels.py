@@ -324,3 +324,36 @@ def test_linear_routes(env, M, K, N, act, mode):
     assert rel(y, ref.detach()) <= TOL
     assert rel(gw_[:, 128:], rx) <= TOL and float(gw_[:, :128].abs().max()) == 0.0
     assert rel(gww, rw) <= TOL and rel(gb, rb) <= TOL
+
+
+@pytest.mark.parametrize("rows", [255, 257, 4099, 83340])
+def test_ring_kernels_race_screen(env, rows):
+    """The LDS-DMA ring kernels order their loads with counted vmcnt waits and raw barriers (no compiler help): screen
+    them for races by repeating each launch 12 times on the same inputs -- every repetition must be bit-identical --
+    at sizes around the tile boundaries and at the BASELINE row count."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode("bf16x6")
+    W = 128
+    g = torch.Generator().manual_seed(rows)
+    p, q, z = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))
+    T = (torch.randn(W, W, W, generator=g) / W).to(dev)
+    init = torch.randn(rows, W, generator=g).to(dev)
+    ws = torch.empty(max(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), _lib.lib.cgat_bilinear_rows_workspace_bytes(rows, W, W, W)),
+                     dtype=torch.uint8, device=dev)
+    first = None
+    for rep in range(12):
+        o0 = torch.empty(rows, W, device=dev)
+        o1, o2 = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
+        _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, q.data_ptr(), W, T.data_ptr(), init.data_ptr(), W,
+                                               o0.data_ptr(), W, rows, W, W, W, ws.data_ptr(), ws.numel(), None), "rows")
+        _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, q.data_ptr(), W, z.data_ptr(), W, T.data_ptr(),
+                                               init.data_ptr(), W, o1.data_ptr(), W, None, W, o2.data_ptr(), W, rows,
+                                               ws.data_ptr(), ws.numel(), None), "dual")
+        y = ops.linear(p, T[0], None, _lib.ACT_TANH)          # edge_z ring, dense-layer form
+        torch.cuda.synchronize()
+        cur = (o0.clone(), o1.clone(), o2.clone(), y.clone())
+        if first is None:
+            first = cur
+        else:
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b), rep
