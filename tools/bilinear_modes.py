@@ -30,7 +30,6 @@ for rnd in range(5):
         e1.record(); torch.cuda.synchronize()
         res.setdefault(mode, []).append(e0.elapsed_time(e1) / 4)
 fl = 2.0 * rows * W ** 3
-print("CGAT_BF16_VARIANT =", os.environ.get("CGAT_BF16_VARIANT", "(default)"))
 for mode, t in res.items():
     t = sorted(t); med = t[len(t) // 2]
     print(f"mode {mode}: median {med:.3f} ms incl. T preparation + slab sum -> {fl / med / 1e9:.1f} TFLOP/s (fp32-equivalent)")
