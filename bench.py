@@ -347,9 +347,24 @@ def main():
             roof["other_contraction_kernels"] = {t: {k: v[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
                                                                         "ms_per_step", "traffic")}
                                                  for t, v in per_kernel.items() if t != dom}
+        # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
+        # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
+        W2b = 2 * HEADS * 256 * 4
+        hbm_alg = {"edge_z": E * (2 * W2b + C_FEA * 4) + N * W2b,            # Z written, Pj gathered, e read, Pi rows once
+                   "edge_seg_bwd": E * 2 * W2b + N * (W2b + W2b // 2),       # Z read, gZ written, Gi written, gS read
+                   "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
+                   "edge_gw": E * (W2b + C_FEA * 6)}                         # gZ read, bf16x3 planes of e read
+        hbm = {}
+        for tag, nbytes in hbm_alg.items():
+            n_t, ms_t = ops.prof_get(tag)
+            if n_t:
+                gbs = nbytes / (ms_t / n_t * 1e-3) / 1e9
+                hbm[tag] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms_t / n_t, 4),
+                            "algorithmic_bytes_per_launch": int(nbytes)}
         shares = {}
-        for tag in ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_seg_bwd", "edge_ge", "edge_gw", "linear128",
-                    "gemm_f32"):
+        for tag in ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
+                    "edge_gw", "rows_ge", "rows_gw", "linear128", "gemm_f32"):
             n_t, ms_t = ops.prof_get(tag)
             if n_t:
                 shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
@@ -366,7 +381,8 @@ def main():
                        (f"CGAtNet(200,128,4,msg_heads=3,update_edges=True) fwd+bwd of L1 loss, {args.graphs} crystals: "
                         f"N={N}, E={E}"),
                        "edges_per_rank": E, "parallelism": f"dp{world} (graphs sharded, gradient all-reduce)"},
-            "roofline": roof, "kernel_ms_per_step": shares,
+            "roofline": roof, "hbm_bound_kernels": hbm if args.workload == "layer" else None,
+            "kernel_ms_per_step": shares,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
             out["cpu_baseline"] = cpu_baseline()

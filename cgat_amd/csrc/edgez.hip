@@ -223,7 +223,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int ncb = W2 / 128;
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
   CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
-  CGAT_PROF("edge_z", stream);
+  CGAT_PROF(Pj ? "edge_z" : "edge_proj", stream);   // the per-edge launch / the per-node projections
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
