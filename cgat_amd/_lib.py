@@ -97,6 +97,9 @@ PROTOTYPES = {
     "cgat_hnet_forward": (C.c_int, [C.c_int32, C.POINTER(HnetParams), vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "cgat_hnet_backward": (C.c_int, [C.c_int32, C.POINTER(HnetParams), vp, vp, vp, vp, vp, vp, C.POINTER(HnetGrads),
                                      vp, C.c_size_t, vp]),
+    "cgat_hnet_backward_side_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(HnetParams)]),
+    "cgat_hnet_backward_overlapped": (C.c_int, [C.c_int32, C.POINTER(HnetParams), vp, vp, vp, vp, vp, vp,
+                                                C.POINTER(HnetGrads), vp, C.c_size_t, vp, vp, C.c_size_t, vp]),
     "cgat_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "cgat_linear_forward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "cgat_linear_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int32, C.c_int32,

@@ -1261,8 +1261,11 @@ size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
   return 0;
 }
 
+// force_splits > 0: number of row splits = workgroups per `a` pair (default: enough for one workgroup per CU; 2 gives
+// 128 workgroups, i.e. half the chip, for running beside an HBM-bound kernel on another stream)
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
-                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream) {
+                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream,
+                          int force_splits) {
   if (wgrad_fast(q, ldq, r, ldr, NB, NC) && bilinear_mode() != 0 && nrows > 0) {
     size_t o_pT, o_qT, o_Rq, o_slab;
     const size_t need = wgrad_bf16_ws(nrows, NA, &o_pT, &o_qT, &o_Rq, &o_slab);
@@ -1282,6 +1285,7 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     hipLaunchKernelGGL(split_rows_bf16_kernel, dim3(cdiv((long)np * 128, 256)), dim3(256), 0, stream, r, ldr, nrows, np, Rq);
     CGAT_LAUNCH_CHECK();
     int splits = wgrad_bf16_splits(NA);
+    if (force_splits > 0 && force_splits < splits) splits = force_splits;
     int rps = cdiv(np / 32, splits) * 32;
     splits = cdiv(np, rps);
     {

@@ -74,7 +74,8 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
 // out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c]      (workspace: slabs)
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
-                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream);
+                          int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream,
+                          int force_splits = 0);
 // three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
 int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
                           hipStream_t stream);

@@ -748,9 +748,24 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
   return check_ws(c, "hnet_forward");
 }
 
+// `side`: optional second stream + workspace.  The four dT contractions (the weight-gradient kernel and its operand
+// preparation) feed nothing else in the backward pass, and they are matrix-core bound while what follows them (the
+// attention backward of the layer) is HBM bound: issued on the side stream they run beside it (measured in isolation:
+// 7.3 ms of contractions + 7.7 ms of streaming take 10.8 ms on two streams instead of 15.0).  Their inputs must then
+// outlive this call's main-stream buffers: every layer's g_u gets its own buffer in the side workspace.
+struct HnetSide {
+  hipStream_t s;
+  void* ws;
+  size_t bytes;
+  int wgrad_splits;   // 0 = default grid (one workgroup per CU)
+};
+static size_t hnet_side_ws_bytes(int rows, const cgat_hnet_params* p) {
+  const size_t rw = (size_t)rows * p->W;
+  return ws_round((size_t)p->n_hyper * rw, 4) + bilinear_wgrad_ws_bytes(rows, p->W, p->W, p->W) + 256;
+}
 static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const float* h0, const float* v,
                               const float* saved, const float* g_y, float* g_h0, float* g_v,
-                              const cgat_hnet_grads* gr) {
+                              const cgat_hnet_grads* gr, const HnetSide* side = nullptr) {
   const int W = p->W;
   const size_t WW = (size_t)W * W;
   const size_t rw = (size_t)rows * W;
@@ -764,20 +779,27 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   HnetSaved sv = hnet_saved(const_cast<float*>(saved), rows, p);
   const float* hin = p->damping ? sv.hin() : h0;
   RUN(fill_launch(g_hin, 0.f, (long)rw, c.s));
+  struct { const float *gu, *vin, *z; float* out; } deferred[CGAT_MAX_HYPER];
+  int n_deferred = 0;
   const float* gout = g_y;  // gradient wrt the output of predicted layer l (post norm for l < last)
   for (int l = p->n_hyper - 1; l >= 0; --l) {
     const cgat_hyperlinear_params& L = p->layer[l];
     const cgat_hyperlinear_grads& G = gr->layer[l];
     const float* gu = gout;  // gradient wrt the pre-norm output u_l
     if (l < p->n_hyper - 1) {
-      RUN(layernorm_tanh_bwd_launch(sv.u(l), sv.vin(l + 1), gout, g_u, rows, W, 1e-5f, c.s));
-      gu = g_u;
+      float* gu_buf = (side && !c.dry) ? (float*)side->ws + (size_t)l * rw : g_u;
+      RUN(layernorm_tanh_bwd_launch(sv.u(l), sv.vin(l + 1), gout, gu_buf, rows, W, 1e-5f, c.s));
+      gu = gu_buf;
     }
     float* g_vin = (l == 0) ? g_v : gvin_buf[l & 1];  // gradient wrt this layer's input
     const float* vin = (l == 0) ? v : sv.vin(l);
     const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
     // ---- head parameter gradients ----
-    CGAT_TRY(c.wgrad(gu, W, vin, W, z, W, G.head_w, rows, W, W, W));  // [o][i][k]
+    if (side && !c.dry) {   // dT[o][i][k]: deferred to the side stream, see the end of this function
+      deferred[n_deferred++] = {gu, vin, z, G.head_w};
+    } else {
+      CGAT_TRY(c.wgrad(gu, W, vin, W, z, W, G.head_w, rows, W, W, W));  // [o][i][k]
+    }
     {
       GemmParams g = gemm_params(W, W, rows, gu, W, vin, W, G.head_b, W);  // Bm grad [o][i]
       g.a_kmajor = 1; g.b_kmajor = 1;
@@ -830,6 +852,20 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   } else {
     RUN(copy2d_launch(g_hin, W, g_h0, W, rows, W, c.s));
   }
+  if (n_deferred > 0) {
+    // The dT contractions start when everything above has been issued on the main stream, i.e. together with
+    // whatever the caller enqueues next (the HBM-bound attention backward); started earlier they would only
+    // time-slice the matrix cores with the other contractions of this pass.
+    hipEvent_t ev;
+    CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CGAT_HIP(hipEventRecord(ev, c.s));
+    CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
+    CGAT_HIP(hipEventDestroy(ev));
+    const size_t off = ws_round((size_t)p->n_hyper * rw, 4);
+    for (int i = 0; i < n_deferred; ++i)
+      CGAT_TRY(bilinear_wgrad_launch(deferred[i].gu, W, deferred[i].vin, W, deferred[i].z, W, deferred[i].out, rows, W, W,
+                                     W, (char*)side->ws + off, side->bytes - off, side->s, side->wgrad_splits));
+  }
   return check_ws(c, "hnet_backward");
 }
 
@@ -856,6 +892,33 @@ extern "C" int cgat_hnet_forward(int32_t rows, const cgat_hnet_params* p, const 
   Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
   c.scratch_need = dry.scratch_need;
   return hnet_forward_impl(c, rows, p, h0, v, y, saved);
+}
+extern "C" size_t cgat_hnet_backward_side_workspace_bytes(int32_t rows, const cgat_hnet_params* p) {
+  return hnet_side_ws_bytes(rows, p);
+}
+extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,
+                                             const float* saved, const float* g_y, float* g_h0, float* g_v,
+                                             const cgat_hnet_grads* g, void* ws, size_t ws_bytes, void* stream,
+                                             void* side_ws, size_t side_ws_bytes, void* side_stream) {
+  CGAT_TRY(hnet_check(rows, p));
+  CGAT_CHECK_ARG(g, "hnet_backward: null grads");
+  CGAT_CHECK_ARG(side_stream && side_ws && side_ws_bytes >= hnet_side_ws_bytes(rows, p),
+                 "hnet_backward_overlapped: side stream / workspace missing or too small");
+  Ctx dry(nullptr, 0, true, nullptr);
+  hnet_backward_impl(dry, rows, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g);
+  if (ws_bytes < dry.total()) {
+    cgat_set_error("hnet_backward: workspace too small (%zu < %zu)", ws_bytes, dry.total());
+    return CGAT_ERR_WORKSPACE;
+  }
+  Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
+  c.scratch_need = dry.scratch_need;
+  static int side_splits = -1;   // CGAT_SIDE_WGRAD_SPLITS: 2 (default) = 128 workgroups, the other half of the chip stays
+  if (side_splits < 0) {         // free for the main stream's HBM-bound kernels; 0 = full grid
+    const char* e = getenv("CGAT_SIDE_WGRAD_SPLITS");
+    side_splits = e ? atoi(e) : 2;
+  }
+  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_splits};
+  return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);
 }
 extern "C" int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,
                                   const float* saved, const float* g_y, float* g_h0, float* g_v,

@@ -17,8 +17,9 @@ import torch.nn as nn
 from . import _lib
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (EdgeHiddenFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+from .ops import (EdgeHiddenFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
                   segment_softmax, segment_sum)
+from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
 
 
@@ -205,8 +206,31 @@ class GATConvNodes(nn.Module):
         alpha = torch.empty_like(al).index_copy(0, perm, al).reshape(alpha.shape)
         return m * alpha
 
+    # -- whole layer as one autograd node (scalar attention + H_Net update): lets the backward overlap the
+    #    hypernetwork's weight-gradient contractions with the attention backward (ops.NodeLayerFn) -----------------
+    def _layer_fused(self, x, edge_attr, x_0, plan):
+        a, m, pool = self.MH_A, self.MH_M, self.Pooling_NN
+        hyper = pool.Hyper
+        flat = []
+        for layer in hyper.layers:
+            hl = layer.hyper_linear if hasattr(layer, "hyper_linear") else layer
+            flat += hl.flat_params()
+        if self.first:
+            h0, damping = x, None
+        else:
+            with torch.no_grad():
+                pool.damping.data = pool.damping.data.clamp(0.0, 1.0)      # Hypernetworksmp.py:307, as H_Net.forward
+            h0, damping = x_0, pool.damping
+        return NodeLayerFn.apply(x, edge_attr, h0, plan, self.heads, damping, hyper.n_fc, len(hyper.layers),
+                                 a.fc_in.weight, a.fc_in.bias, a.fc_out.weight, a.fc_out.bias,
+                                 m.fc_in.weight, m.fc_in.bias, m.fc_out.weight, m.fc_out.bias, *flat)
+
     def propagate(self, edge_index, x, edge_attr, x_0):
         plan = get_plan(edge_index, x.shape[0])
+        if (ops_overlap_enabled() and not self.vector_attention and not self.final and not self.dropout and
+                type(self).message is GATConvNodes.message and type(self).update is GATConvNodes.update and
+                type(self.Pooling_NN) in (H_Net, H_Net_0)):
+            return self._layer_fused(x, edge_attr, x_0, plan)
         if not self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
             aggr = self._aggregate_fused(x, edge_attr, plan)
         elif self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:

@@ -3,6 +3,8 @@ stream and the autograd tape; all arithmetic of the path runs in libcgat_hip ker
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -232,6 +234,30 @@ def _hnet_struct(cls, W, n_fc, n_hyper, flat, damping):
     return s
 
 
+# Side stream for the hypernetwork's weight-gradient contractions (cgat_hnet_backward_overlapped, used by NodeLayerFn):
+# they are off the critical path of the backward pass and matrix-core bound, the attention backward is HBM bound.
+_side_streams = {}
+_overlap_wgrad = os.environ.get("CGAT_OVERLAP_WGRAD", "1") != "0"
+
+
+def set_overlap_wgrad(flag):
+    global _overlap_wgrad
+    _overlap_wgrad = bool(flag)
+
+
+def overlap_enabled():
+    return _overlap_wgrad
+
+
+def side_stream(device, create=True):
+    """The per-device side stream (None if it has never been used and create is False)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side_streams and create:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams.get(key)
+
+
 class HNetFn(torch.autograd.Function):
     """y = HyperFC(hyper_input)(v)  with hyper_input = h0 (H_Net_0) or d*h0 + (1-d)*v (H_Net);
     reference Hypernetworksmp.py:257-313.  `flat` = per predicted layer: n_fc trunk weights,
@@ -281,6 +307,80 @@ class HNetFn(torch.autograd.Function):
             check(lib.cgat_hnet_backward(rows, C.byref(p), _ptr(h0), _ptr(v), _ptr(saved), _ptr(g_y), _ptr(g_h0),
                                          _ptr(g_v), C.byref(g), _ptr(ws), ws.numel(), _stream()), "cgat_hnet_backward")
         return (g_h0, g_v, g_d, None, None, *grads)
+
+
+class NodeLayerFn(torch.autograd.Function):
+    """One whole GATConvNodes layer: aggr = attention(x, edge_attr) (NodesAttentionFn), y = HyperFC(h0)(aggr) (HNetFn) --
+    reference CGAT.py:307-340 -- as ONE autograd node, so that its backward can run the hypernetwork's four
+    weight-gradient contractions (matrix-core bound, feeding nothing else) on a side stream BESIDE the attention
+    backward (HBM bound) and join the two streams before returning.  Same kernels, same results as the two separate
+    nodes; only the schedule differs."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, h0, plan, H, damping, n_fc, n_hyper, *params):
+        attn_w, flat = list(params[:8]), list(params[8:])
+        _require_gpu(x, edge_attr, h0, *attn_w, *flat)
+        x, edge_attr, h0 = _f32c(x), _f32c(edge_attr), _f32c(h0)
+        attn_w = [_f32c(w.detach()) for w in attn_w]
+        flat = [_f32c(t.detach()) for t in flat]
+        d = None if damping is None else _f32c(damping.detach())
+        N, E = plan.N, plan.E
+        if x.shape[0] != N or edge_attr.shape[0] != E or h0.shape != x.shape:
+            raise ValueError("NodeLayerFn: shapes do not match the plan")
+        dev = x.device
+        pa, Hd = _attn_params(x, edge_attr, H, attn_w)
+        W = x.shape[1]
+        ph = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
+        saved_a = torch.empty(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), dtype=torch.float32, device=dev)
+        saved_h = torch.empty(lib.cgat_hnet_saved_floats(N, C.byref(ph)), dtype=torch.float32, device=dev)
+        aggr, y = torch.empty(N, W, dtype=torch.float32, device=dev), torch.empty(N, W, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = workspace(lib.cgat_nodes_attention_forward_workspace_bytes(C.byref(plan.c), C.byref(pa)), dev)
+            check(lib.cgat_nodes_attention_forward(C.byref(plan.c), C.byref(pa), _ptr(x), _ptr(edge_attr), _ptr(aggr),
+                                                   _ptr(saved_a), _ptr(ws), ws.numel(), _stream()),
+                  "cgat_nodes_attention_forward")
+            ws = workspace(lib.cgat_hnet_forward_workspace_bytes(N, C.byref(ph)), dev)
+            check(lib.cgat_hnet_forward(N, C.byref(ph), _ptr(h0), _ptr(aggr), _ptr(y), _ptr(saved_h), _ptr(ws), ws.numel(),
+                                        _stream()), "cgat_hnet_forward")
+        ctx.plan, ctx.H, ctx.n_fc, ctx.n_hyper, ctx.has_d = plan, H, n_fc, n_hyper, d is not None
+        ctx.save_for_backward(x, edge_attr, h0, aggr, saved_a, saved_h, *([d] if d is not None else []), *attn_w, *flat)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, edge_attr, h0, aggr, saved_a, saved_h, *rest = ctx.saved_tensors
+        d = rest.pop(0) if ctx.has_d else None
+        attn_w, flat = rest[:8], rest[8:]
+        plan, H, n_fc, n_hyper = ctx.plan, ctx.H, ctx.n_fc, ctx.n_hyper
+        N, W = x.shape
+        dev = x.device
+        g_y = _f32c(g_y)
+        ph = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
+        g_flat = [torch.empty_like(t) for t in flat]
+        g_d = torch.empty_like(d) if d is not None else None
+        gh = _hnet_struct(_lib.HnetGrads, W, n_fc, n_hyper, g_flat, g_d)
+        g_h0, g_aggr = torch.empty_like(h0), torch.empty_like(aggr)
+        pa, Hd = _attn_params(x, edge_attr, H, attn_w)
+        g_x, g_e = torch.empty_like(x), torch.empty_like(edge_attr)
+        g_attn = [torch.empty_like(w) for w in attn_w]
+        ga = _lib.AttnGrads(*[t.data_ptr() for t in g_attn])
+        main = torch.cuda.current_stream(dev)
+        s2 = side_stream(dev)
+        with torch.cuda.device(dev):
+            # side_ws (the side stream's inputs and scratch) is its own allocation: the attention backward reuses the
+            # cached main workspace while the side stream is still running
+            ws_h = workspace(lib.cgat_hnet_backward_workspace_bytes(N, C.byref(ph)), dev)
+            side_ws = torch.empty(lib.cgat_hnet_backward_side_workspace_bytes(N, C.byref(ph)), dtype=torch.uint8, device=dev)
+            check(lib.cgat_hnet_backward_overlapped(N, C.byref(ph), _ptr(h0), _ptr(aggr), _ptr(saved_h), _ptr(g_y),
+                                                    _ptr(g_h0), _ptr(g_aggr), C.byref(gh), _ptr(ws_h), ws_h.numel(),
+                                                    main.cuda_stream, _ptr(side_ws), side_ws.numel(), s2.cuda_stream),
+                  "cgat_hnet_backward_overlapped")
+            ws_a = workspace(lib.cgat_nodes_attention_backward_workspace_bytes(C.byref(plan.c), C.byref(pa)), dev)
+            check(lib.cgat_nodes_attention_backward(C.byref(plan.c), C.byref(pa), _ptr(x), _ptr(edge_attr), _ptr(saved_a),
+                                                    _ptr(g_aggr), _ptr(g_x), _ptr(g_e), C.byref(ga), _ptr(ws_a),
+                                                    ws_a.numel(), main.cuda_stream), "cgat_nodes_attention_backward")
+            main.wait_stream(s2)     # every gradient is complete, in stream order, when this node returns
+        return (g_x, g_e, g_h0, None, None, g_d, None, None, *g_attn, *g_flat)
 
 
 # ----------------------------------------------------------------------------------------

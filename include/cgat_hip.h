@@ -207,6 +207,16 @@ int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0,
                        const float* g_y, float* g_h0, float* g_v, const cgat_hnet_grads* g, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* Same backward with the four weight-gradient contractions (grad of head_w[0 : W*W]) issued on `side_stream`: they
+ * feed nothing else in the pass and are matrix-core bound, so they can run beside the HBM-bound kernels that follow
+ * on `stream`.  The caller owns `side_ws` (cgat_hnet_backward_side_workspace_bytes) and must keep it, `saved`, `v`,
+ * `g_y` and the head_w gradient buffers alive -- and must not read those gradients -- until `side_stream` has drained. */
+size_t cgat_hnet_backward_side_workspace_bytes(int32_t rows, const cgat_hnet_params* p);
+int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,
+                                  const float* saved, const float* g_y, float* g_h0, float* g_v, const cgat_hnet_grads* g,
+                                  void* ws, size_t ws_bytes, void* stream, void* side_ws, size_t side_ws_bytes,
+                                  void* side_stream);
+
 /* ---- dense layer  y = act(x W^T + b)  (nn.Linear / 1x1 Conv1d group + activation) --------
  * replaces the Linear/LeakyReLU/ReLU/Tanh pairs of CGAT/message_changed.py:58-63,124-130,
  * CGAT/roost_message.py:348-352 and one head of MultiHeadNetwork (CGAT/CGAT.py:103-109).
