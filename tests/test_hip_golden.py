@@ -186,9 +186,49 @@ def test_full_stack_vs_oracle_random_init():
     _compare_with_oracle(mk(P), mk(O), inputs, call)
 
 
-def test_determinism_bitwise():
-    """No atomics on the data path: two runs give bit-identical outputs and gradients."""
+@pytest.mark.parametrize("overlap", [True, False])
+def test_determinism_bitwise(overlap):
+    """No atomics on the data path: two runs give bit-identical outputs and gradients, with the
+    weight-gradient contractions on the side stream (default) and in serial order."""
     import cgat_amd as P
+    from cgat_amd import ops
+    was = ops.overlap_enabled()
+    ops.set_overlap_wgrad(overlap)
+    try:
+        _determinism_body(P)
+    finally:
+        ops.set_overlap_wgrad(was)
+
+
+def test_side_stream_equals_serial():
+    """The overlapped backward computes the same gradients as the serial one (only the row split of the
+    weight-gradient sums differs): 1e-5 max-norm relative on every gradient."""
+    import cgat_amd as P
+    from cgat_amd import ops
+    b, _ = P.synthetic_batch(300, 20, 12, seed=4)
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    m = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    g = torch.Generator().manual_seed(9)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0 = (torch.randn(s, 128, generator=g).to(dev) for s in (N, E, N))
+    ei = b.edge_index.to(dev)
+    was = ops.overlap_enabled()
+    res = {}
+    try:
+        for mode in (True, False):
+            ops.set_overlap_wgrad(mode)
+            xx, ee = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+            y = m(xx, ei, ee, x0)
+            gr = torch.autograd.grad(y.square().sum(), [xx, ee] + list(m.parameters()))
+            res[mode] = [y.detach().cpu().numpy()] + [t.detach().cpu().numpy() for t in gr]
+    finally:
+        ops.set_overlap_wgrad(was)
+    for a, bb in zip(res[True], res[False]):
+        assert maxnorm_rel(a, bb) <= 1e-5
+
+
+def _determinism_body(P):
     b, _ = P.synthetic_batch(200, 20, 12, seed=2)
     dev = "cuda:0"
     torch.manual_seed(1)
