@@ -211,8 +211,10 @@ template <int PASSES, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const uint4* __restrict__ Tq,
     const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo, int nrows, int NA, int tiles, int asplit,
-    long slab_stride, int vec_io) {
-  constexpr int CH16 = 2 * 3 * 4 * 64;          // 16-byte pieces per chunk = 24 KB
+    long slab_stride, int vec_io, const float* __restrict__ tmax) {
+  constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h); tmax = max |T|
+  constexpr int NP = F16 ? 2 : 3;               // planes per operand
+  constexpr int CH16 = 2 * NP * 4 * 64;         // 16-byte pieces per chunk = 24 KB (16 KB)
   constexpr int PST = 8 * 64;
   __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,17 +240,51 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
   const unsigned t_off = (unsigned)tid * 16;
   const long last_chunk = (long)a_end * 4 - 1;
 
-  // q[row, 32 s + 8 kg + j] for both row blocks as three bf16 planes: qf[plane][2 s + nb]
-  bf16x8 q1[8], q2[8], q3[8];
+  // q[row, 32 s + 8 kg + j] for both row blocks as three bf16 (two fp16) planes: qf[plane][2 s + nb]
+  bf16x8 q1[8], q2[8], q3[F16 ? 1 : 8];
+  float rs_a = 1.f, rs_b = 1.f;                 // F16: 1 / (scale of the lane's q row * scale of T)
+  if constexpr (F16) {
+    float qv[2][32];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+    float st, it;
+    pow2_scale(tmax[0], st, it);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
-      const float4 t0 = qp[0], t1 = qp[1];
-      const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-      split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));          // the row's 128 values live in the four lanes n16 + 16 kg
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      (nb ? rs_b : rs_a) = iq * it;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+      }
     }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+      }
+  }
   // acc[2 cb8 + nb][t] = out[row(nb)][16 cb8 + 4 kg + t]
   f32x4 acc[16];
 #pragma unroll
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
     glds_b128(tb, t_off, dst);                                                                 \
     glds_b128(tb + 512, t_off, dst + 8192);                                                    \
-    glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
+    if (NP == 3) glds_b128(tb + 1024, t_off, dst + 16384);                                     \
   }
 #define RG_PLOAD(a_)                                                                           \
   {                                                                                            \
@@ -293,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
   // group (s2, cb): the three planes of one 16-column block at one k-step
 #define RG_READ(F1_, F2_, F3_, slot_, s2_, cb_)                                                \
   {                                                                                            \
-    const bf16x8* fp = ring + (slot_) * (CH16) + (((s2_) * 3) * 4 + (cb_)) * 64;               \
+    const bf16x8* fp = ring + (slot_) * (CH16) + (((s2_) * NP) * 4 + (cb_)) * 64;              \
     F1_ = fp[0];                                                                               \
     F2_ = fp[4 * 64];                                                                          \
     if (PASSES >= 6) F3_ = fp[8 * 64];                                                         \
@@ -301,13 +337,13 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
 #define RG_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
   {                                                                                            \
     if (PASSES >= 6) {                                                                         \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+      P_ = mma16<F16>(F3_, q1[qi_], P_);                                                       \
+      P_ = mma16<F16>(F1_, q3[qi_], P_);                                                       \
+      P_ = mma16<F16>(F2_, q2[qi_], P_);                                                       \
     }                                                                                          \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = mma16<F16>(F2_, q1[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q2[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q1[qi_], P_);                                                         \
   }
 #define RG_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
   {                                                                                            \
@@ -345,7 +381,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
         }
       }
       if (c2 == 1) {
-        const float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
+        float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
+        if constexpr (F16) { pva *= rs_a; pvb *= rs_b; }
         const float pas_a = (a & 1) ? -pva : pva, pas_b = (a & 1) ? -pvb : pvb;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -355,7 +392,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
             acc[2 * (4 * half + cb) + 1][t] = fmaf(pas_b, part[2 * cb + 1][t], acc[2 * (4 * half + cb) + 1][t]);
           }
       }
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
@@ -396,8 +434,12 @@ template <int PASSES>
 __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const float* __restrict__ zz, long ldz,
     const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
-    float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io) {
-  constexpr int CH16 = 2 * 3 * 4 * 64;          // 16-byte pieces per ring slot = 24 KB: [half][plane][cb][lane]
+    float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io,
+    const float* __restrict__ tmax) {
+  constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes; tmax = max |T|
+  constexpr int NP = F16 ? 2 : 3;
+  constexpr int HP = NP * 256;                  // 16-byte pieces of one (a, half, k-step) block of the prepared T
+  constexpr int CH16 = 2 * HP;                  // per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
   constexpr int PST = 8 * 64;
   __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   }
   const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
-  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + hf * 768 + lane;
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + hf * HP + lane;
   const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
   p += (long)tile * 128 * ldp;
   const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 128) * ldp * 4);
@@ -427,16 +469,50 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   const int P0 = 64 * wave_u, P1 = 64 * wave_u + 512, P2 = 64 * wave_u + 1024;
   const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + (unsigned)P0 * 16);
 
-  bf16x8 q1[8], q2[8], q3[8];
+  bf16x8 q1[8], q2[8], q3[F16 ? 1 : 8];
+  float rs_a = 1.f, rs_b = 1.f;                 // F16: 1 / (scale of the lane's q row * scale of T)
+  if constexpr (F16) {
+    float qv[2][32];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+    float st, it;
+    pow2_scale(tmax[0], st, it);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
-      const float4 t0 = qp[0], t1 = qp[1];
-      const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-      split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      (nb ? rs_b : rs_a) = iq * it;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+      }
     }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+      }
+  }
   // acc[2 cb + nb][j] = out[row(nb)][64 hf + 16 cb + 4 kg + j];  zr the same elements of zz
   f32x4 acc[8], zr[8];
 #pragma unroll
@@ -462,12 +538,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   {                                                                                            \
     const long gi = (gi_) < last_step ? (gi_) : last_step;                                     \
     const long a_ = gi >> 2, s_ = gi & 3;                                                      \
-    const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * 768;                                      \
-    const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * 768;                                      \
+    const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                       \
+    const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                       \
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
     glds_b128(h0 + P0, l_off, dst);                                                            \
-    glds_b128(P1 < 768 ? h0 + P1 : h1 + (P1 - 768), l_off, dst + 8192);                        \
-    glds_b128(h1 + (P2 - 768), l_off, dst + 16384);                                            \
+    glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                          \
+    if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                                \
   }
 #define DU_PLOAD(a_)                                                                           \
   {                                                                                            \
@@ -494,13 +570,13 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
 #define DU_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
   {                                                                                            \
     if (PASSES >= 6) {                                                                         \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+      P_ = mma16<F16>(F3_, q1[qi_], P_);                                                       \
+      P_ = mma16<F16>(F1_, q3[qi_], P_);                                                       \
+      P_ = mma16<F16>(F2_, q2[qi_], P_);                                                       \
     }                                                                                          \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = mma16<F16>(F2_, q1[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q2[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q1[qi_], P_);                                                         \
   }
 #define DU_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
   {                                                                                            \
@@ -534,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
         // part = (-1)^a M[n,a,:] (the prepared T alternates in sign): scale-after flush and the second gradient
         const float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
         const float sg = (a & 1) ? -1.f : 1.f;
-        const float pas_a = sg * pva, pas_b = sg * pvb;
+        const float sga = F16 ? sg * rs_a : sg, sgb = F16 ? sg * rs_b : sg;   // F16: part carries the operand scales
+        const float pas_a = sga * pva, pas_b = sgb * pvb;
         float da = 0.f, db = 0.f;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -550,11 +627,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
         da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
         db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
         if (kg == 0) {
-          dvp[dv_a + a * dv_ld] = sg * da;         // dv_ld >= the tile-padded row count: no bounds check needed
-          dvp[dv_b + a * dv_ld] = sg * db;
+          dvp[dv_a + a * dv_ld] = sga * da;        // dv_ld >= the tile-padded row count: no bounds check needed
+          dvp[dv_b + a * dv_ld] = sgb * db;
         }
       }
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
@@ -609,8 +687,10 @@ __global__ __launch_bounds__(256) void dual_finish_kernel(const float* __restric
 
 // sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
 // (layout in the header above); element (a, b, c) of the [NA,128,128] operand is src[a*sa + b*sb + c*sc].
+// F16: two fp16 planes of 2^k sgn(a) T[a], 2^k from tmax[0] = max |T| (pow2_scale), same order with 2 planes per k-step
+template <bool F16>
 __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int NA, long sa, long sb,
-                                      long sc, int alternate) {
+                                      long sc, int alternate, const float* __restrict__ tmax) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)NA * 128 * 128) return;
   // thread order follows the fastest source stride so that reads coalesce
@@ -619,15 +699,51 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
   else { c = (int)((i >> 7) & 127); b = (int)(i & 127); }
   float v = src[a * sa + b * sb + c * sc];
   if (alternate && (a & 1)) v = -v;
-  __bf16 x1, x2, x3;
-  split3_bf16(v, x1, x2, x3);
   const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
   const int kh = b >> 6, s2 = (b >> 5) & 1, kg = (b & 31) >> 3, j = b & 7;
-  const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * 3;   // planes of one k-step, each [cb][kg][i][j]
+  constexpr int NP = F16 ? 2 : 3;
+  const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * NP;  // planes of one k-step, each [cb][kg][i][j]
   const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
-  dst[(blk + 0) * 2048 + in] = x1;
-  dst[(blk + 1) * 2048 + in] = x2;
-  dst[(blk + 2) * 2048 + in] = x3;
+  if constexpr (F16) {
+    float st, it;
+    pow2_scale(tmax[0], st, it);
+    v *= st;
+    const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+    _Float16* d16 = reinterpret_cast<_Float16*>(dst);
+    d16[(blk + 0) * 2048 + in] = h;
+    d16[(blk + 1) * 2048 + in] = l;
+  } else {
+    __bf16 x1, x2, x3;
+    split3_bf16(v, x1, x2, x3);
+    dst[(blk + 0) * 2048 + in] = x1;
+    dst[(blk + 1) * 2048 + in] = x2;
+    dst[(blk + 2) * 2048 + in] = x3;
+  }
+}
+
+// out[0] = max |src[i]| (out[0] zeroed before; non-negative floats order like their bit patterns, and a maximum does
+// not depend on the order it is taken in: deterministic)
+__global__ void absmax_kernel(const float* __restrict__ src, long n, float* __restrict__ out) {
+  float m = 0.f;
+  const long n4 = n >> 2;
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = s4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(src[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
+}
+int absmax_launch(const float* src, long n, float* out, hipStream_t stream) {
+  if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
+  if (n <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG((((uintptr_t)src) & 15) == 0, "absmax: source must be 16-byte aligned");
+  const int blocks = (int)(cdiv(n, 4 * 256) < 1024 ? cdiv(n, 4 * 256) : 1024);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, src, n, out);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
 }
 
 // Row-gathered variant for operands whose k index is a row number: element (a, b, c) = rows[gather[128 a + b]][c]
@@ -671,8 +787,20 @@ int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb,
                           hipStream_t stream) {
   long total = (long)NA * 128 * 128;
   if (total <= 0) return CGAT_OK;
-  hipLaunchKernelGGL(prepare_T_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA, sa, sb,
-                     sc, alternate);
+  hipLaunchKernelGGL(prepare_T_bf16_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
+                     sa, sb, sc, alternate, (const float*)nullptr);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+// fp16 form: the whole [NA,128,128] source is contiguous (any index order); max |T| goes behind the planes
+int prepare_T_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
+                         hipStream_t stream) {
+  long total = (long)NA * 128 * 128;
+  if (total <= 0) return CGAT_OK;
+  float* tmax = (float*)dst + total;
+  CGAT_TRY(absmax_launch(src, total, tmax, stream));
+  hipLaunchKernelGGL(prepare_T_bf16_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
+                     sa, sb, sc, alternate, (const float*)tmax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -741,22 +869,25 @@ static int rows_per_wg() { return bilinear_mode() == 0 ? 128 : 256; }
 
 bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
 
-// 0 = f32-input MFMA (exact fp32), 6 = 3-way bf16 split with 6 MFMA passes (fp32-equivalent), 3 = 3 passes
+// 0 = f32-input MFMA (exact fp32), 6 = 3-way bf16 split with 6 MFMA passes (fp32-equivalent), 3 = 3 passes,
+// 2 = 2-way fp16 split with 3 passes (22-bit operands, scaled per row / per tensor)
 static int g_bilinear_mode = -1;
 int bilinear_mode() {
   if (g_bilinear_mode < 0) {
-    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 (default) | bf16x3
+    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 (default) | bf16x3 | f16x3
     g_bilinear_mode = 6;
     if (e && !strcmp(e, "f32")) g_bilinear_mode = 0;
     if (e && !strcmp(e, "bf16x3")) g_bilinear_mode = 3;
+    if (e && !strcmp(e, "f16x3")) g_bilinear_mode = 2;
   }
   return g_bilinear_mode;
 }
-void bilinear_set_mode(int m) { g_bilinear_mode = (m == 6 || m == 3) ? m : 0; }
-// floats of workspace the prepared T occupies (the bf16 form stores three 2-byte planes)
+void bilinear_set_mode(int m) { g_bilinear_mode = (m == 6 || m == 3 || m == 2) ? m : 0; }
+// floats of workspace the prepared T occupies (the bf16 form stores three 2-byte planes, the fp16 form two and its scale)
 size_t bilinear_T_floats(int NA, int NB, int NC) {
   size_t n = (size_t)NA * NB * NC;
-  return (bilinear_T_interleaved(NB, NC) && bilinear_mode() != 0) ? (n * 3 + 1) / 2 : n;
+  if (!bilinear_T_interleaved(NB, NC) || bilinear_mode() == 0) return n;
+  return bilinear_mode() == 2 ? n + 4 : (n * 3 + 1) / 2;
 }
 
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
@@ -798,12 +929,16 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
                       (!init1 || ((ldi1 % 4) == 0 && (((uintptr_t)init1) & 15) == 0))) ? 1 : 0;
   {
     CGAT_PROF("bilinear_dual", stream);
+    const float* tmax = T + (size_t)128 * 128 * 128;   // f16x3 only
     if (bilinear_mode() == 6)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<6>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
-                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io);
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
+    else if (bilinear_mode() == 2)
+      hipLaunchKernelGGL((bilinear_rows128_dual_kernel<2>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
     else
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<3>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
-                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io);
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
     CGAT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv(nrows, 32)), dim3(256), 0, stream, slab, sp, stride, nrows, out1, ldo1,
@@ -844,12 +979,16 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
         cgat_set_error("bilinear_rows: ldp %ld too large", ldp);
         return CGAT_ERR_ARG;
       }
+      const float* tmax = T + (size_t)NA * 128 * 128;   // f16x3 only: max |T| behind the two planes
       if (bilinear_mode() == 6)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<6>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
-                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io);
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
+      else if (bilinear_mode() == 2)
+        hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
       else
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<3>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
-                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io);
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
     } else {
       CGAT_PROF("bilinear_rows", stream);
       static int variant = -1;  // dev knob: CGAT_BIL_VARIANT = <JS><FLUSH>, e.g. 161, 162, 322, 324
@@ -1293,9 +1432,9 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
       static int abl = -1;
       if (abl < 0) { const char* e = getenv("CGAT_WGRAD_ABL"); abl = e ? atoi(e) : 0; }
 #define WG_GO(A_) hipLaunchKernelGGL((bilinear_wgrad128_bf16_kernel<6, A_>), dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT, (const uint4*)Rq, slab, np, rps, NA)
-      if (bilinear_mode() == 6 && abl) {
+      if (bilinear_mode() != 3 && abl) {
         switch (abl) { case 1: WG_GO(1); break; case 2: WG_GO(2); break; case 3: WG_GO(3); break; case 4: WG_GO(4); break; default: WG_GO(7); break; }
-      } else if (bilinear_mode() == 6)
+      } else if (bilinear_mode() != 3)
         hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<6>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
                            (const uint4*)Rq, slab, np, rps, NA);
       else
@@ -1372,6 +1511,7 @@ int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int
   int dims[3] = {n0, n1, n2};
   if (bilinear_T_interleaved(dims[perm1], dims[perm2]) && bilinear_mode() != 0) {
     long st[3] = {(long)n1 * n2, (long)n2, 1};   // source strides of dims 0, 1, 2
+    if (bilinear_mode() == 2) return prepare_T_f16_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
     return prepare_T_bf16_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
   }
   return permute3_launch(src, dst, n0, n1, n2, perm0, perm1, perm2,

@@ -342,7 +342,7 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);   // the per-edge launch / node-side and dense-layer uses
   const int grid = cdiv(E, 256);
-  if (bilinear_mode() == 6)
+  if (bilinear_mode() != 3)
     hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
                        scatter, E, accumulate, bias);
   else
@@ -382,7 +382,7 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
   {
     CGAT_PROF(perm ? "edge_gw" : "rows_gw", stream);
     const int nsteps = cdiv(E, 32);
-    if (bilinear_mode() == 6)
+    if (bilinear_mode() != 3)
       hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
                          slab, E, ncb, nsteps, S);
     else

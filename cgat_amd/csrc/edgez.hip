@@ -229,7 +229,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
                      Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0)
   const bool adds = Pj != nullptr;
-  if (bilinear_mode() == 6) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
+  if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
   else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }
 #undef EZ_GO
   CGAT_LAUNCH_CHECK();
@@ -258,7 +258,7 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
                      (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate)
-  if (bilinear_mode() == 6) L128_GO(6); else L128_GO(3);
+  if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;

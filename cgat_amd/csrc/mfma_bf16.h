@@ -41,6 +41,48 @@ __device__ __forceinline__ void split3_x8(const float (&v)[8], bf16x8& q1, bf16x
   q3 = __builtin_bit_cast(bf16x8, w3);
 }
 
+// ---- two-plane fp16 split ("f16x3": x*2^k = h + l with fp16 pieces, 22 significant bits; a product is
+// a1b2 + a2b1 + a1b1 = three fp16 MFMA passes, all partial products exact in fp32, dropped term <= 2^-22).
+// fp16 has 5 exponent bits, so every operand is scaled by a power of two that puts its largest magnitude (per row,
+// or per tensor for operands indexed by the reduction index) into [2^13, 2^14): the low plane of any element within
+// 2^-16 of that maximum is still a normal fp16 number, and what is lost on smaller elements is below 2^-37 of the
+// maximum.  The inverse scales are folded into the fp32 multiplier the kernels already apply to the sums.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// power-of-two scale for a block whose largest magnitude is m (m >= 0): s = 2^(140 - E(m)), inv = 1/s (both exact)
+__device__ __forceinline__ void pow2_scale(float m, float& s, float& inv) {
+  int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xff);
+  e = e < 30 ? 30 : (e > 230 ? 230 : e);   // all-zero / denormal / huge blocks: any finite scale will do
+  s = __builtin_bit_cast(float, (unsigned)(267 - e) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(e - 13) << 23);
+}
+__device__ __forceinline__ void split2_pair_f16(float a, float b, unsigned& w1, unsigned& w2) {
+  const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  const f16x2 l = __builtin_convertvector((f32x2){ra, rb}, f16x2);
+  w1 = __builtin_bit_cast(unsigned, h);
+  w2 = __builtin_bit_cast(unsigned, l);
+}
+// eight (already scaled) values -> the two fragment planes (stored in the 16-byte bf16x8 carrier type)
+__device__ __forceinline__ void split2_x8_f16(const float (&v)[8], bf16x8& q1, bf16x8& q2) {
+  uint4 w1, w2;
+  split2_pair_f16(v[0], v[1], w1.x, w2.x);
+  split2_pair_f16(v[2], v[3], w1.y, w2.y);
+  split2_pair_f16(v[4], v[5], w1.z, w2.z);
+  split2_pair_f16(v[6], v[7], w1.w, w2.w);
+  q1 = __builtin_bit_cast(bf16x8, w1);
+  q2 = __builtin_bit_cast(bf16x8, w2);
+}
+// one 16x16x32 matrix-core pass on 16-byte fragments held in the bf16x8 carrier type
+template <bool F16>
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // global address = scalar base + per-lane 32-bit byte offset; LDS address = lds_addr + 16 (4) * lane
 __device__ __forceinline__ void glds_b128(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;

@@ -534,7 +534,7 @@ def segment_sum(x, index_plan, index):
     return SegmentSumFn.apply(x.index_select(0, perm), index_plan.rowptr, index.index_select(0, perm))
 
 
-_MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3}
+_MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "f16x3": 2}
 
 
 def set_bilinear_mode(mode):

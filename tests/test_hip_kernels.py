@@ -132,7 +132,7 @@ def test_gemm_blocked_A(env, kmajor):
 
 @pytest.mark.parametrize("W,rows", [(128, 128), (128, 300), (128, 1), (16, 45), (128, 1000), (128, 83340)])
 @pytest.mark.parametrize("with_init", [False, True])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
 def test_bilinear_rows(env, W, rows, with_init, mode):
     """All three arithmetic modes of the width-128 kernel; the 6-pass bf16 split and the f32-input MFMA are
     held to the same 2e-5, the 3-pass form to 2e-5 as well (measured ~3e-6)."""
@@ -162,7 +162,7 @@ def test_bilinear_rows(env, W, rows, with_init, mode):
 
 @pytest.mark.parametrize("rows", [1, 127, 128, 300, 1000, 83340])
 @pytest.mark.parametrize("with_init", [False, True])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
 def test_bilinear_dual(env, rows, with_init, mode):
     """The fused pair of hypernetwork gradients (one contraction, two outputs) against fp64 einsums; the f32 mode
     runs the same entry point as two contractions."""
@@ -196,7 +196,7 @@ def test_bilinear_dual(env, rows, with_init, mode):
 
 
 @pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45), (128, 33), (128, 20001)])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
 def test_bilinear_wgrad(env, W, rows, mode):
     _, _lib, ops, dev = env
     ops.set_bilinear_mode(mode)

@@ -18,7 +18,7 @@ def call():
                                            W, rows, W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
 res = {}
 for rnd in range(5):
-    for mode in (0, 6, 3):
+    for mode in (0, 6, 3, 2):
         _lib.lib.cgat_set_bilinear_mode(mode)
         call(); torch.cuda.synchronize()
         if rnd == 0:
@@ -33,3 +33,36 @@ fl = 2.0 * rows * W ** 3
 for mode, t in res.items():
     t = sorted(t); med = t[len(t) // 2]
     print(f"mode {mode}: median {med:.3f} ms incl. T preparation + slab sum -> {fl / med / 1e9:.1f} TFLOP/s (fp32-equivalent)")
+
+# the fused pair of gradients (bilinear_dual) in the same modes, plus a row-scale stress for the fp16 form
+z = torch.randn(rows, W, generator=g).to(dev)
+o1, o2 = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
+ws2 = torch.empty(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), dtype=torch.uint8, device=dev)
+M = torch.einsum("nb,abc->nac", q[sel].double().cpu(), T.double().cpu())
+r1 = torch.einsum("na,nac->nc", p[sel].double().cpu(), M); r2 = torch.einsum("nc,nac->na", z[sel].double().cpu(), M)
+def dual():
+    _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, q.data_ptr(), W, z.data_ptr(), W, T.data_ptr(), None, W, o1.data_ptr(), W,
+                                           None, W, o2.data_ptr(), W, rows, ws2.data_ptr(), ws2.numel(), None), "dual")
+for mode in (6, 3, 2):
+    _lib.lib.cgat_set_bilinear_mode(mode)
+    dual(); torch.cuda.synchronize()
+    e1_ = float((o1[sel].double().cpu() - r1).abs().max() / r1.abs().max()); e2_ = float((o2[sel].double().cpu() - r2).abs().max() / r2.abs().max())
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4): dual()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 4)
+    print(f"dual mode {mode}: err {e1_:.3e} / {e2_:.3e}   median {sorted(ts)[2]:.3f} ms")
+# rows whose magnitudes span 1e-6 .. 1e4 and a T of magnitude 1e-3: relative error PER ROW
+scale = torch.logspace(-6, 4, rows).to(dev)[:, None]
+qs = q * scale
+Ts = T * 1e-3
+refs = torch.einsum("na,nb,abc->nc", p[sel].double().cpu(), qs[sel].double().cpu(), Ts.double().cpu())
+for mode in (6, 2):
+    _lib.lib.cgat_set_bilinear_mode(mode)
+    _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, qs.data_ptr(), W, Ts.data_ptr(), None, W, out.data_ptr(),
+                                           W, rows, W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
+    torch.cuda.synchronize()
+    d = (out[sel].double().cpu() - refs).abs().amax(1) / refs.abs().amax(1)
+    print(f"row-scaled q, mode {mode}: worst per-row max-norm rel err {float(d.max()):.3e}")
