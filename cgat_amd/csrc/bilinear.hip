@@ -721,6 +721,21 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
   }
 }
 
+// at most one atomic per workgroup (thousands of same-address atomics cost more than the pass itself)
+__device__ __forceinline__ void block_absmax_commit(float m, float* out) {
+  __shared__ float wm[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
+    // the slot only grows, so a (possibly stale) plain read that is already >= m makes the atomic unnecessary
+    if (m > *reinterpret_cast<volatile float*>(out))
+      atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
+  }
+}
+
 // out[0] = max |src[i]| (out[0] zeroed before; non-negative floats order like their bit patterns, and a maximum does
 // not depend on the order it is taken in: deterministic)
 __global__ void absmax_kernel(const float* __restrict__ src, long n, float* __restrict__ out) {
@@ -732,15 +747,13 @@ __global__ void absmax_kernel(const float* __restrict__ src, long n, float* __re
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(src[(n4 << 2) + threadIdx.x]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
+  block_absmax_commit(m, out);
 }
 int absmax_launch(const float* src, long n, float* out, hipStream_t stream) {
   if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
   if (n <= 0) return CGAT_OK;
   CGAT_CHECK_ARG((((uintptr_t)src) & 15) == 0, "absmax: source must be 16-byte aligned");
-  const int blocks = (int)(cdiv(n, 4 * 256) < 1024 ? cdiv(n, 4 * 256) : 1024);
+  const int blocks = (int)(cdiv(n, 4 * 256) < 512 ? cdiv(n, 4 * 256) : 512);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, src, n, out);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
@@ -874,11 +887,11 @@ bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !
 static int g_bilinear_mode = -1;
 int bilinear_mode() {
   if (g_bilinear_mode < 0) {
-    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 (default) | bf16x3 | f16x3
-    g_bilinear_mode = 6;
+    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 | bf16x3 | f16x3 (default)
+    g_bilinear_mode = 2;
     if (e && !strcmp(e, "f32")) g_bilinear_mode = 0;
     if (e && !strcmp(e, "bf16x3")) g_bilinear_mode = 3;
-    if (e && !strcmp(e, "f16x3")) g_bilinear_mode = 2;
+    if (e && !strcmp(e, "bf16x6")) g_bilinear_mode = 6;
   }
   return g_bilinear_mode;
 }
@@ -1195,15 +1208,20 @@ __global__ void bilinear_wgrad_generic_kernel(const float* __restrict__ p, long 
 // Workgroup = 8 waves = two `a` values (waves 0-3 / 4-7) x 128 b x 128 c; wave = 32 b x 128 c.
 // The A fragment (p*q, 8 values per lane) is split on the fly; six MFMA passes, smallest first.
 // ---------------------------------------------------------------------------------------
+// mx (optional): max |in| is folded into it (zeroed before; f16x3 mode)
 __global__ void transpose_pad_kernel(const float* __restrict__ in, long ld, int rows, int cols, int rows_pad,
-                                     float* __restrict__ out) {  // out[c][n] = in[n][c], n < rows_pad (zeros beyond rows)
+                                     float* __restrict__ out, float* __restrict__ mx) {  // out[c][n] = in[n][c], n < rows_pad (zeros beyond rows)
   __shared__ float t[32][33];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  float m = 0.f;
   for (int i = ty; i < 32; i += 8) {
     int n = n0 + i, c = c0 + tx;
-    t[i][tx] = (n < rows && c < cols) ? in[(long)n * ld + c] : 0.f;
+    const float v = (n < rows && c < cols) ? in[(long)n * ld + c] : 0.f;
+    t[i][tx] = v;
+    m = fmaxf(m, fabsf(v));
   }
+  if (mx) block_absmax_commit(m, mx);
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     int c = c0 + i, n = n0 + tx;
@@ -1211,19 +1229,43 @@ __global__ void transpose_pad_kernel(const float* __restrict__ in, long ld, int 
   }
 }
 
+// F16: two fp16 planes of 2^k r, 2^k from mx[2] = max |r| (f16x3 mode; mx = {max|p|, max|q|, max|r|})
+template <bool F16>
 __global__ void split_rows_bf16_kernel(const float* __restrict__ r, long ldr, int rows, int rows_pad,
-                                       __bf16* __restrict__ dst) {
+                                       __bf16* __restrict__ dst, const float* __restrict__ mx) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows_pad * 128) return;
   const int n = (int)(i >> 7), c = (int)(i & 127);
-  const float v = n < rows ? r[(long)n * ldr + c] : 0.f;
-  __bf16 x1, x2, x3;
-  split3_bf16(v, x1, x2, x3);
+  float v = n < rows ? r[(long)n * ldr + c] : 0.f;
   const int s = n >> 4, h = (n >> 3) & 1, j = n & 7, cb = c >> 5, rr = c & 31;
-  const long base = (long)s * 3 * 4;
-  dst[((((base + 0 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x1;
-  dst[((((base + 1 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x2;
-  dst[((((base + 2 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x3;
+  constexpr int NP = F16 ? 2 : 3;
+  const long base = (long)s * NP * 4;
+  if constexpr (F16) {
+    float sr, ir;
+    pow2_scale(mx[2], sr, ir);
+    v *= sr;
+    const _Float16 x1 = (_Float16)v, x2 = (_Float16)(v - (float)x1);
+    _Float16* d16 = reinterpret_cast<_Float16*>(dst);
+    d16[((((base + 0 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x1;
+    d16[((((base + 1 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x2;
+  } else {
+    __bf16 x1, x2, x3;
+    split3_bf16(v, x1, x2, x3);
+    dst[((((base + 0 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x1;
+    dst[((((base + 1 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x2;
+    dst[((((base + 2 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x3;
+  }
+}
+
+// out[0] = max |t[n, c]| over a [rows, 128] view with row stride ld (16-byte aligned rows; out zeroed before)
+__global__ void absmax_rows128_kernel(const float* __restrict__ t, long ld, int rows, float* __restrict__ out) {
+  const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;      // 8 rows of 32 float4 per workgroup pass
+  float m = 0.f;
+  for (long n = (long)blockIdx.x * 8 + r0; n < rows; n += (long)gridDim.x * 8) {
+    const float4 v = *reinterpret_cast<const float4*>(t + n * ld + 4 * c4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  block_absmax_commit(m, out);
 }
 
 // Tried and dropped (round 1): the same kernel on v_mfma_f32_16x16x32_bf16 with the product split of the next k-step
@@ -1237,9 +1279,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
                                                                         const float* __restrict__ qT,
                                                                         const uint4* __restrict__ Rq,
                                                                         float* __restrict__ slab, int rows_pad,
-                                                                        int rows_per_split, int NA) {
+                                                                        int rows_per_split, int NA,
+                                                                        const float* __restrict__ mx) {
+  constexpr bool F16 = PASSES == 2;        // two fp16 planes, three passes; mx = {max|p|, max|q|, max|r|}
+  constexpr int NP = F16 ? 2 : 3;
   constexpr int KS = 2;                    // k-steps (16 rows each) per chunk
-  constexpr int RCH = KS * 768;            // 16-byte pieces of Rq per chunk
+  constexpr int RCH = KS * NP * 256;       // 16-byte pieces of Rq per chunk
   constexpr int QP = 36;                   // pitch (floats) of the q^T tile: conflict-free 16-byte reads
   __shared__ uint4 Rs[2][RCH];
   __shared__ __attribute__((aligned(16))) float Qs[2][128 * QP];
@@ -1273,26 +1318,38 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
 #pragma unroll
     for (int t = 0; t < 16; ++t) { acc[cb][t] = 0.f; tot[cb][t] = 0.f; }
 
+  // F16: the products p*q are brought into fp16 range by 2^k from max|p| max|q| (folded into the staged p); the sums
+  // come out scaled by that and by r's scale
+  float spq = 1.f, inv_all = 1.f;
+  if constexpr (F16) {
+    float ipq, sr, ir;
+    pow2_scale(mx[0] * mx[1], spq, ipq);
+    pow2_scale(mx[2], sr, ir);
+    inv_all = ipq * ir;
+  }
   uint4 pr0, pr1, pr2;
   float4 pq0, pq1;
   float pp = 0.f;
   const int qb0 = tid >> 3, qn4 = tid & 7;                 // q^T pieces: rows qb0 and qb0 + 64
 #define WG_GLOAD(n0_)                                                                   \
   {                                                                                     \
-    const uint4* rb = Rq + (long)((n0_) >> 4) * 768 + tid;                              \
-    pr0 = rb[0]; pr1 = rb[512]; pr2 = rb[1024];                                         \
+    const uint4* rb = Rq + (long)((n0_) >> 4) * (NP * 256) + tid;                       \
+    pr0 = rb[0]; pr1 = rb[512];                                                         \
+    if (NP == 3) pr2 = rb[1024];                                                        \
     pq0 = *reinterpret_cast<const float4*>(qT + (long)qb0 * rows_pad + (n0_) + 4 * qn4);        \
     pq1 = *reinterpret_cast<const float4*>(qT + (long)(qb0 + 64) * rows_pad + (n0_) + 4 * qn4); \
     if (tid < 64) {                                                                     \
       const int aa = a0 + (tid >> 5);                                                   \
       pp = aa < NA ? pT[(long)aa * rows_pad + (n0_) + (tid & 31)] : 0.f;                \
+      if (F16) pp *= spq;                                                               \
       if (((((n0_) - nbeg) >> 5) >> 4) & 1) pp = -pp; /* odd flush groups accumulate -p*q*r */ \
     }                                                                                   \
   }
 #define WG_LSTORE(buf_)                                                                 \
   {                                                                                     \
     uint4* lb = &Rs[buf_][tid];                                                         \
-    lb[0] = pr0; lb[512] = pr1; lb[1024] = pr2;                                         \
+    lb[0] = pr0; lb[512] = pr1;                                                         \
+    if (NP == 3) lb[1024] = pr2;                                                        \
     *reinterpret_cast<float4*>(&Qs[buf_][qb0 * QP + 4 * qn4]) = pq0;                    \
     *reinterpret_cast<float4*>(&Qs[buf_][(qb0 + 64) * QP + 4 * qn4]) = pq1;             \
     if (tid < 64) Ps[buf_][tid] = pp;                                                   \
@@ -1328,22 +1385,30 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a1[j] = (__bf16)av[j]; }
         a2v = a1; a3 = a1;
+      } else if constexpr (F16) {
+        split2_x8_f16(av, a1, a2v);
       } else {
         split3_x8(av, a1, a2v, a3);
       }
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        const bf16x8 b1 = bs[((ks * 3 + 0) * 4 + cb) * 64];
-        const bf16x8 b2 = bs[((ks * 3 + 1) * 4 + cb) * 64];
-        if (PASSES >= 6) {
-          const bf16x8 b3 = bs[((ks * 3 + 2) * 4 + cb) * 64];
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b2, acc[cb], 0, 0, 0);
+        const bf16x8 b1 = bs[((ks * NP + 0) * 4 + cb) * 64];
+        const bf16x8 b2 = bs[((ks * NP + 1) * 4 + cb) * 64];
+        if constexpr (F16) {
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2v), __builtin_bit_cast(f16x8, b1), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b2), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b1), acc[cb], 0, 0, 0);
+        } else {
+          if (PASSES >= 6) {
+            const bf16x8 b3 = bs[((ks * 3 + 2) * 4 + cb) * 64];
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b2, acc[cb], 0, 0, 0);
+          }
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b1, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[cb], 0, 0, 0);
         }
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v, b1, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[cb], 0, 0, 0);
       }
     }
     if (c + 1 < nchunks) WG_LSTORE(cur ^ 1);
@@ -1358,6 +1423,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     acc[cb] = acc[cb] * sg_last + tot[cb];
+    if constexpr (F16) acc[cb] = acc[cb] * inv_all;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int b = wb * 32 + (t & 3) + 8 * (t >> 2) + 4 * hi;
@@ -1387,6 +1453,7 @@ static size_t wgrad_bf16_ws(int nrows, int NA, size_t* o_pT, size_t* o_qT, size_
   *o_qT = off; off += ws_round(np * 128, 4);
   *o_Rq = off; off += ws_round(np * 128 * 3, 2);
   *o_slab = off; off += ws_round((size_t)wgrad_bf16_splits(NA) * NA * 128 * 128, 4);
+  off += 16;                              // f16x3: {max|p|, max|q|, max|r|} behind the slabs
   return off;
 }
 
@@ -1417,11 +1484,22 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     float* qT = (float*)((char*)ws + o_qT);
     __bf16* Rq = (__bf16*)((char*)ws + o_Rq);
     float* slab = (float*)((char*)ws + o_slab);
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, cdiv(NA, 32)), dim3(256), 0, stream, p, ldp, nrows, NA, np, pT);
+    float* mx = (float*)((char*)ws + need - 16);
+    const bool f16 = bilinear_mode() == 2;
+    if (f16 && hipMemsetAsync(mx, 0, 16, stream) != hipSuccess) return CGAT_ERR_HIP;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, cdiv(NA, 32)), dim3(256), 0, stream, p, ldp, nrows, NA, np, pT,
+                       f16 ? mx : (float*)nullptr);
     CGAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, 4), dim3(256), 0, stream, q, ldq, nrows, 128, np, qT);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, 4), dim3(256), 0, stream, q, ldq, nrows, 128, np, qT,
+                       f16 ? mx + 1 : (float*)nullptr);
     CGAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(split_rows_bf16_kernel, dim3(cdiv((long)np * 128, 256)), dim3(256), 0, stream, r, ldr, nrows, np, Rq);
+    if (f16) {
+      hipLaunchKernelGGL(absmax_rows128_kernel, dim3(512), dim3(256), 0, stream, r, ldr, nrows, mx + 2);
+      CGAT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(split_rows_bf16_kernel<true>, dim3(cdiv((long)np * 128, 256)), dim3(256), 0, stream, r, ldr, nrows, np, Rq, (const float*)mx);
+    } else {
+      hipLaunchKernelGGL(split_rows_bf16_kernel<false>, dim3(cdiv((long)np * 128, 256)), dim3(256), 0, stream, r, ldr, nrows, np, Rq, (const float*)mx);
+    }
     CGAT_LAUNCH_CHECK();
     int splits = wgrad_bf16_splits(NA);
     if (force_splits > 0 && force_splits < splits) splits = force_splits;
@@ -1431,15 +1509,18 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
       CGAT_PROF("bilinear_wgrad", stream);
       static int abl = -1;
       if (abl < 0) { const char* e = getenv("CGAT_WGRAD_ABL"); abl = e ? atoi(e) : 0; }
-#define WG_GO(A_) hipLaunchKernelGGL((bilinear_wgrad128_bf16_kernel<6, A_>), dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT, (const uint4*)Rq, slab, np, rps, NA)
-      if (bilinear_mode() != 3 && abl) {
+#define WG_GO(A_) hipLaunchKernelGGL((bilinear_wgrad128_bf16_kernel<6, A_>), dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT, (const uint4*)Rq, slab, np, rps, NA, (const float*)mx)
+      if (f16)
+        hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<2>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
+                           (const uint4*)Rq, slab, np, rps, NA, (const float*)mx);
+      else if (bilinear_mode() != 3 && abl) {
         switch (abl) { case 1: WG_GO(1); break; case 2: WG_GO(2); break; case 3: WG_GO(3); break; case 4: WG_GO(4); break; default: WG_GO(7); break; }
       } else if (bilinear_mode() != 3)
         hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<6>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
-                           (const uint4*)Rq, slab, np, rps, NA);
+                           (const uint4*)Rq, slab, np, rps, NA, (const float*)mx);
       else
         hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<3>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,
-                           (const uint4*)Rq, slab, np, rps, NA);
+                           (const uint4*)Rq, slab, np, rps, NA, (const float*)mx);
     }
     CGAT_LAUNCH_CHECK();
     long n = (long)NA * NB * NC;

@@ -535,12 +535,17 @@ def segment_sum(x, index_plan, index):
 
 
 _MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "f16x3": 2}
+# the mode a fresh process starts in (env CGAT_BILINEAR_MODE overrides the built-in default)
+DEFAULT_MODE = os.environ.get("CGAT_BILINEAR_MODE", "f16x3")
+if DEFAULT_MODE not in _MODES:
+    DEFAULT_MODE = "f16x3"
 
 
 def set_bilinear_mode(mode):
-    """Arithmetic of the width-128 hypernetwork contractions: "bf16x6" (default; operands split into
-    three bf16 pieces, six bf16-MFMA passes, fp32 accumulate -- measured fp32-equivalent), "f32"
-    (f32-input MFMA, exact fp32 fmaf chains) or "bf16x3" (three passes, ~4e-6 relative)."""
+    """Arithmetic of the width-128 matrix-core kernels: "f16x3" (default; every fp32 operand scaled by a power
+    of two and split into two fp16 pieces = 22 bits, three fp16-MFMA passes, fp32 accumulate -- measured at the
+    error of an fp32 product chain), "bf16x6" (three bf16 pieces, six passes, same accuracy), "f32" (f32-input
+    MFMA, exact fp32 fmaf chains) or "bf16x3" (three bf16 passes, ~4e-6 relative; fails the parity tests)."""
     lib.cgat_set_bilinear_mode(_MODES[mode])
 
 

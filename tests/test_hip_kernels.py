@@ -155,7 +155,7 @@ def test_bilinear_rows(env, W, rows, with_init, mode):
                                            None if init is None else init.data_ptr(), W, out.data_ptr(), W, rows, W, W,
                                            W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
     torch.cuda.synchronize()
-    ops.set_bilinear_mode("bf16x6")
+    ops.set_bilinear_mode(ops.DEFAULT_MODE)
     assert torch.isfinite(out).all()
     assert rel(out[sel], ref) <= TOL
 
@@ -189,7 +189,7 @@ def test_bilinear_dual(env, rows, with_init, mode):
                                            None if i2 is None else i2.data_ptr(), W, o2.data_ptr(), W, rows,
                                            ws.data_ptr(), ws.numel(), None), "bilinear_dual")
     torch.cuda.synchronize()
-    ops.set_bilinear_mode("bf16x6")
+    ops.set_bilinear_mode(ops.DEFAULT_MODE)
     assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
     assert rel(o1[sel], r1) <= TOL
     assert rel(o2[sel], r2) <= TOL
@@ -209,7 +209,7 @@ def test_bilinear_wgrad(env, W, rows, mode):
     _lib.check(_lib.lib.cgat_bilinear_wgrad(p.data_ptr(), W, q.data_ptr(), W, r.data_ptr(), W, out.data_ptr(), rows, W,
                                             W, W, ws.data_ptr(), ws.numel(), None), "bilinear_wgrad")
     torch.cuda.synchronize()
-    ops.set_bilinear_mode("bf16x6")
+    ops.set_bilinear_mode(ops.DEFAULT_MODE)
     assert rel(out, ref) <= TOL
 
 
@@ -315,7 +315,7 @@ def test_linear_routes(env, M, K, N, act, mode):
     x = wide[:, 128:]                                    # row stride K + 128, 16-byte aligned
     y = ops.linear(x, w, b, code)
     gw_, gww, gb = torch.autograd.grad((y * cot).sum(), [wide, w, b])
-    ops.set_bilinear_mode("bf16x6")
+    ops.set_bilinear_mode(ops.DEFAULT_MODE)
     xd, wd, bd = wide.detach().double()[:, 128:].requires_grad_(True), w.detach().double().requires_grad_(True), \
         b.detach().double().requires_grad_(True)
     pre = xd @ wd.t() + bd
@@ -332,7 +332,7 @@ def test_ring_kernels_race_screen(env, rows):
     them for races by repeating each launch 12 times on the same inputs -- every repetition must be bit-identical --
     at sizes around the tile boundaries and at the BASELINE row count."""
     _, _lib, ops, dev = env
-    ops.set_bilinear_mode("bf16x6")
+    ops.set_bilinear_mode(ops.DEFAULT_MODE)
     W = 128
     g = torch.Generator().manual_seed(rows)
     p, q, z = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))

@@ -66,3 +66,23 @@ for mode in (6, 2):
     torch.cuda.synchronize()
     d = (out[sel].double().cpu() - refs).abs().amax(1) / refs.abs().amax(1)
     print(f"row-scaled q, mode {mode}: worst per-row max-norm rel err {float(d.max()):.3e}")
+# weight gradient in the same modes (+ operands of very different magnitudes)
+wout = torch.empty(W, W, W, device=dev)
+ws3 = torch.empty(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W), dtype=torch.uint8, device=dev)
+for tag, (pp, qq, rr) in {"unit": (p, q, z), "scaled": (p * 3e-4, q * 2e3, z * 1e-5)}.items():
+    refw = torch.einsum("na,nb,nc->abc", pp[:20000].double(), qq[:20000].double(), rr[:20000].double()).cpu()
+    for mode in (6, 3, 2):
+        _lib.lib.cgat_set_bilinear_mode(mode)
+        def wg(n=rows):
+            _lib.check(_lib.lib.cgat_bilinear_wgrad(pp.data_ptr(), W, qq.data_ptr(), W, rr.data_ptr(), W, wout.data_ptr(), n, W, W, W,
+                                                    ws3.data_ptr(), ws3.numel(), None), "wgrad")
+        wg(20000); torch.cuda.synchronize()
+        err = float((wout.double().cpu() - refw).abs().max() / refw.abs().max())
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4): wg()
+            e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 4)
+        print(f"wgrad {tag} mode {mode}: err(20000 rows) {err:.3e}   median {sorted(ts)[2]:.3f} ms (83340 rows, incl. pre-passes)")
+_lib.lib.cgat_set_bilinear_mode(6)

@@ -54,7 +54,7 @@ print("fused vs f32 path: Z max diff %.3e, alpha max diff %.3e, out max diff %.3
     float((Zf - Zb).abs().max()), float((af - ab).abs().max()), float((res[0] - keep[0]).abs().max())))
 
 # which logits are wrong?  recompute alpha from the saved Z with torch and compare row by row
-P.set_bilinear_mode("bf16x6")
+P.set_bilinear_mode(P.ops.DEFAULT_MODE)
 y, saved, _ = run()
 Z, al = parts(saved)
 wA = W[2].reshape(3, 256); bA = W[3].reshape(3)
