@@ -4,7 +4,7 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libcgat_hip.so"
-SRCS=(api gemm bilinear edgez edgebwd collate optim rowops segment plan layers)
+SRCS=(api gemm bilinear edgez edgebwd rowsdw collate optim rowops segment plan layers)
 OBJS=()
 PIDS=()
 mkdir -p "$HERE/csrc/build"

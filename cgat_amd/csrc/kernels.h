@@ -108,6 +108,13 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);
 
+// ---- width-128 weight gradients over rows, rowsdw.hip: out_k[o][i] = sum_n G[n,o] X_k[n,i], bsum[o] = sum_n G[n,o] ----
+bool rows_dw128_fast(const float* G, long ldg, const float* X1, long ldx1, const float* X2, long ldx2);
+size_t rows_dw128_ws_bytes(int rows, int nx);
+int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, float* out1, long ldo1, const float* X2,
+                      long ldx2, float* out2, long ldo2, float* bsum, int rows, void* ws, size_t ws_bytes,
+                      hipStream_t stream);
+
 // ---- elementwise / row kernels, rowops.hip ----
 int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float eps, hipStream_t s);
 int layernorm_tanh_bwd_launch(const float* u, const float* y, const float* gy, float* gu, int rows, int W, float eps,

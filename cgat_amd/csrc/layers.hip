@@ -46,6 +46,15 @@ struct Ctx {
                               p.beta == 1.f, p.C, p.ldc, p.M, scratch, s);
     return gemm_launch(p, scratch, scratch_bytes, s);
   }
+  // weight (and bias) gradients of width-128 dense layers: out_k = G^T X_k, bsum = column sums of G (rowsdw.hip);
+  // returns -1 if the shape/alignment is not the fast one (caller falls back to gemm + colsum)
+  int dw128(const float* G, long ldg, const float* X1, long ldx1, float* out1, long ldo1, const float* X2, long ldx2,
+            float* out2, long ldo2, float* bsum, int rows) {
+    need(rows_dw128_ws_bytes(rows, X2 ? 2 : 1));
+    if (dry) return CGAT_OK;
+    if (!rows_dw128_fast(G, ldg, X1, ldx1, X2, ldx2) || scratch_bytes < rows_dw128_ws_bytes(rows, X2 ? 2 : 1)) return -1;
+    return rows_dw128_launch(G, ldg, X1, ldx1, out1, ldo1, X2, ldx2, out2, ldo2, bsum, rows, scratch, scratch_bytes, s);
+  }
   int colsum(const float* x, long ldx, int rows, int cols, float* out, float alpha) {
     need(colsum_ws_bytes(rows, cols));
     if (dry) return CGAT_OK;
@@ -800,15 +809,18 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     } else {
       CGAT_TRY(c.wgrad(gu, W, vin, W, z, W, G.head_w, rows, W, W, W));  // [o][i][k]
     }
-    {
+    // Bm grad [o][i] = gu^T vin, U grad [o][k] = gu^T z, bias grad = column sums of gu: one pass over the three operands
+    int fused = W == 128 ? c.dw128(gu, W, vin, W, G.head_b, W, z, W, G.head_w + WW * W, W, G.head_b + WW, rows) : -1;
+    if (fused > 0) return fused;
+    if (fused < 0) {
       GemmParams g = gemm_params(W, W, rows, gu, W, vin, W, G.head_b, W);  // Bm grad [o][i]
       g.a_kmajor = 1; g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g, true));
       g = gemm_params(W, W, rows, gu, W, z, W, G.head_w + WW * W, W);  // U grad [o][k]
       g.a_kmajor = 1; g.b_kmajor = 1;
       CGAT_TRY(c.gemm(g, true));
+      CGAT_TRY(c.colsum(gu, W, rows, W, G.head_b + WW, 1.f));
     }
-    CGAT_TRY(c.colsum(gu, W, rows, W, G.head_b + WW, 1.f));
     // ---- g_z = gu @ U + sum_{o,i} gu[o] vin[i] T[o,i,k]  ----
     {
       GemmParams g = gemm_params(rows, W, W, gu, W, L.head_w + WW * W, W, g_t, W);
@@ -837,9 +849,13 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       const float* tin = (s == 0) ? hin : (c.dry ? nullptr : sv.act(l, s - 1));
       RUN(act_bwd_launch(tout, g_t, g_pre, (long)rw, CGAT_ACT_TANH, c.s));
       GemmParams g = gemm_params(W, W, rows, g_pre, W, tin, W, G.fc_w[s], W);
-      g.a_kmajor = 1; g.b_kmajor = 1;
-      CGAT_TRY(c.gemm(g, true));
-      CGAT_TRY(c.colsum(g_pre, W, rows, W, G.fc_b[s], 1.f));
+      fused = W == 128 ? c.dw128(g_pre, W, tin, W, G.fc_w[s], W, nullptr, 0, nullptr, 0, G.fc_b[s], rows) : -1;
+      if (fused > 0) return fused;
+      if (fused < 0) {
+        g.a_kmajor = 1; g.b_kmajor = 1;
+        CGAT_TRY(c.gemm(g, true));
+        CGAT_TRY(c.colsum(g_pre, W, rows, W, G.fc_b[s], 1.f));
+      }
       g = gemm_params(rows, W, W, g_pre, W, L.fc_w[s], W, s == 0 ? g_hin : g_t, W);
       g.b_kmajor = 1;
       g.beta = (s == 0) ? 1.f : 0.f;  // every predicted layer's trunk reads the same hyper input
