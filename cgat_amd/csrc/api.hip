@@ -131,6 +131,7 @@ extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int
   if (K == 128 && N % 128 == 0 && edge_z_wq_floats(N) * sizeof(float) > c) c = edge_z_wq_floats(N) * sizeof(float);
   if (b > a) a = b;
   if (c > a) a = c;
+  if (K == 128 && N == 128 && rows_dw128_ws_bytes(M, 1) > a) a = rows_dw128_ws_bytes(M, 1);
   return a + 256;
 }
 
@@ -163,6 +164,11 @@ extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w,
       g.beta = accumulate_gx ? 1.f : 0.f;
       CGAT_TRY(gemm_launch(g, nullptr, 0, s));
     }
+  }
+  if (g_w && K == 128 && N == 128 && M > 0 && ws && ws_bytes >= rows_dw128_ws_bytes(M, 1) &&
+      rows_dw128_fast(gp, ldgp, x, ldx, nullptr, 0)) {
+    // g_W = gpre^T @ x and g_b = column sums of gpre in one pass over both operands (rowsdw.hip)
+    return rows_dw128_launch(gp, ldgp, x, ldx, g_w, ldgw, nullptr, 0, nullptr, 0, g_b, M, ws, ws_bytes, s);
   }
   if (g_w) {  // g_W = gpre^T @ x
     GemmParams g = gemm_params(N, K, M, gp, ldgp, x, ldx, g_w, ldgw);

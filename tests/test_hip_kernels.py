@@ -298,12 +298,14 @@ def test_segment_softmax(env, F, with_mult):
         assert rel(got, want) <= 5e-5
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 128), (513, 128, 256), (300, 384, 128), (64, 96, 40)])
+@pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 128), (513, 128, 256), (300, 384, 128), (64, 96, 40),
+                                   (1, 128, 128), (17, 128, 128), (83340, 128, 128)])
 @pytest.mark.parametrize("act", ["none", "leaky", "tanh"])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
 def test_linear_routes(env, M, K, N, act, mode):
-    """cgat_linear_forward/backward through ops.LinearFn: the split-bf16 routes (K == 128, or 128 outputs) and the
-    generic engine, with a strided input slice (one head's block of a wider hidden matrix), vs fp64."""
+    """cgat_linear_forward/backward through ops.LinearFn: the split routes (K == 128, or 128 outputs), the one-pass
+    weight+bias gradient kernel (K == N == 128, from a single row to the BASELINE row count) and the generic engine,
+    with a strided input slice (one head's block of a wider hidden matrix), vs fp64."""
     _, _lib, ops, dev = env
     ops.set_bilinear_mode(mode)
     g = torch.Generator().manual_seed(M + K + N)
