@@ -736,6 +736,57 @@ __device__ __forceinline__ void block_absmax_commit(float m, float* out) {
   }
 }
 
+// Weight operands of the edge / dense kernels in the fp16 form: one workgroup per 128 x 128 block `a` keeps the block
+// in registers, takes its largest magnitude, and writes the two planes of 2^k(a) W[a] in the bf16 kernel's order with
+// two planes per k-step; max |W[a]| goes to wmax[a] behind the planes (the consumer undoes 2^k(a) per column block).
+// No atomics, no second pass, one launch.
+__global__ __launch_bounds__(256) void prepare_W_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
+                                                            long sa, long sb, long sc, float* __restrict__ wmax) {
+  __shared__ float wm[4];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  float v[64];
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int i = r * 256 + tid;                 // thread order follows the fastest source stride
+    int b, c;
+    if (sc == 1) { b = i >> 7; c = i & 127; }
+    else { c = i >> 7; b = i & 127; }
+    v[r] = src[a * sa + b * sb + c * sc];
+    m = fmaxf(m, fabsf(v[r]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) wm[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  if (tid == 0) wmax[a] = m;
+  float st, it;
+  pow2_scale(m, st, it);
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int i = r * 256 + tid;
+    int b, c;
+    if (sc == 1) { b = i >> 7; c = i & 127; }
+    else { c = i >> 7; b = i & 127; }
+    const float x = v[r] * st;
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+    const int kh = b >> 6, s2 = (b >> 5) & 1, kg = (b & 31) >> 3, j = b & 7;
+    const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * 2;
+    const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+    dst[(blk + 0) * 2048 + in] = h;
+    dst[(blk + 1) * 2048 + in] = l;
+  }
+}
+int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream) {
+  if (NA <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_W_f16_kernel, dim3(NA), dim3(256), 0, stream, src, (_Float16*)dst, sa, sb, sc,
+                     (float*)dst + (size_t)NA * 16384);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // out[0] = max |src[i]| (out[0] zeroed before; non-negative floats order like their bit patterns, and a maximum does
 // not depend on the order it is taken in: deterministic)
 __global__ void absmax_kernel(const float* __restrict__ src, long n, float* __restrict__ out) {

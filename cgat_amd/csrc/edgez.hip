@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
                                                         const float* __restrict__ wA, const float* __restrict__ bA,
                                                         int H, int cb_per_head, float* __restrict__ a_out, int act,
                                                         int accumulate) {
-  constexpr int CH16 = 3 * 4 * 64;              // 16-byte pieces per chunk = 12 KB
+  constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
+  constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
+  constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
   __shared__ uint4 smem[4 * CH16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
@@ -50,18 +52,51 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   const long last_chunk = (long)ncb * 8 - 1;
 
   // the lane's two edge rows, split once: q[plane][2 s + nb] holds e[row(nb), 32 s + 8 kg + 0..7]
-  bf16x8 q1[8], q2[8], q3[8];
+  bf16x8 q1[8], q2[8], q3[F16 ? 1 : 8];
+  float rs_a = 1.f, rs_b = 1.f;                 // F16: 1 / scale of the lane's two rows
+  const float* wmax = reinterpret_cast<const float*>(Wq + (long)ncb * 8 * CH16);   // F16: max |W| per column block
   {
     const long ea = perm ? perm[rca] : rca, eb = perm ? perm[rcb] : rcb;
+    if constexpr (F16) {
+      float qv[2][32];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
+          const float4 t0 = qp[0], t1 = qp[1];
+          qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+          qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+        }
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
-        const float4 t0 = qp[0], t1 = qp[1];
-        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+        m = fmaxf(m, __shfl_xor(m, 16));        // the row's 128 values live in the four lanes n16 + 16 kg
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sq, iq;
+        pow2_scale(m, sq, iq);
+        (nb ? rs_b : rs_a) = iq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
+          split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+        }
       }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
+          const float4 t0 = qp[0], t1 = qp[1];
+          const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+        }
+    }
   }
   // ADDS: gathered addends Pi[dst], Pj[src] (the edge kernel).  !ADDS: a plain product plus bias, Pi = the bias
   // vector or null (the per-node projections x W_i^T + b and x W_j^T, same kernel with e = x)
@@ -80,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
     glds_b128(tb, t_off, dst);                                                                 \
     glds_b128(tb + 256, t_off, dst + 4096);                                                    \
-    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+    if (NP == 3) glds_b128(tb + 512, t_off, dst + 8192);                                       \
   }
   EZ_TLOAD(0l);
   EZ_TLOAD(1l);
@@ -101,13 +136,13 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 #define EZ_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
   {                                                                                            \
     if (PASSES >= 6) {                                                                         \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, q1[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q3[qi_], P_, 0, 0, 0);                 \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q2[qi_], P_, 0, 0, 0);                 \
+      P_ = mma16<F16>(F3_, q1[qi_], P_);                                                       \
+      P_ = mma16<F16>(F1_, q3[qi_], P_);                                                       \
+      P_ = mma16<F16>(F2_, q2[qi_], P_);                                                       \
     }                                                                                          \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, q1[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q2[qi_], P_, 0, 0, 0);                   \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, q1[qi_], P_, 0, 0, 0);                   \
+    P_ = mma16<F16>(F2_, q1[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q2[qi_], P_);                                                         \
+    P_ = mma16<F16>(F1_, q1[qi_], P_);                                                         \
   }
 #define EZ_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
   {                                                                                            \
@@ -136,9 +171,17 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
           __builtin_amdgcn_sched_barrier(0);
           EZ_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
         }
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+      }
+      if constexpr (F16) {                           // undo the row and column-block scales
+        float sw, iw;
+        pow2_scale(wmax[cb], sw, iw);
+        const float ma = rs_a * iw, mb = rs_b * iw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { part[2 * i + 0] = part[2 * i + 0] * ma; part[2 * i + 1] = part[2 * i + 1] * mb; }
       }
       // ---- epilogue of the 64-column slice: z = part + Pi[dst] + Pj[src]; store; logits ----
       const int col0 = cb * 128 + half * 64 + 4 * kg;
@@ -222,14 +265,16 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
-  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
+  if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, stream));
+  else CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
   CGAT_PROF(Pj ? "edge_z" : "edge_proj", stream);   // the per-edge launch / the per-node projections
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
                      Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0)
   const bool adds = Pj != nullptr;
-  if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
+  if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
+  else if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
   else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }
 #undef EZ_GO
   CGAT_LAUNCH_CHECK();
@@ -251,14 +296,15 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   if (rows <= 0) return CGAT_OK;
   const int ncb = n_out / 128;
   // operand (a = output block, b = k, c = output in block) = W[(128 a + c) * so + b * sk]
-  CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
+  if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(W, ws, ncb, 128 * so, sk, so, stream));
+  else CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
   CGAT_PROF("linear128", stream);
   const int grid = cdiv(rows, 128);
 #define L128_GO(P_)                                                                                                   \
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
                      (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate)
-  if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
+  if (bilinear_mode() == 2) L128_GO(2); else if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
