@@ -25,7 +25,9 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restr
                                                             const float* __restrict__ X1, long ldx1,
                                                             const float* __restrict__ X2, long ldx2,
                                                             float* __restrict__ slab, int rows, int rows_per_wg) {
-  constexpr int U = 4;                                 // k-steps (2 rows each) per register batch, double-buffered
+  constexpr int U = 4;                                 // k-steps (2 rows each) per register batch; three batches
+                                                       // rotate so that two are in flight while one is consumed (one
+                                                       // ahead left the waves waiting on HBM latency: 50 us vs 18 us of MFMA)
   constexpr int SLAB = NX * 128 * 128 + 128;           // floats per workgroup: out_1, (out_2,) bsum
   extern __shared__ float red[];                       // [NX][128][128] + [128]: the second row half's partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restr
       for (int t = 0; t < 16; ++t) acc[k][j][t] = 0.f;
   float cs = 0.f;
 
-  float ga[2][U];
-  float4 xa[2][U], xb[2][NX > 1 ? U : 1];
+  float ga[3][U];
+  float4 xa[3][U], xb[3][NX > 1 ? U : 1];
 #define DW_LOAD(buf_, b_)                                                                     \
   {                                                                                           \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                           \
@@ -77,13 +79,19 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restr
       }                                                                                       \
     }                                                                                         \
   }
-  if (nbatch > 0) DW_LOAD(0, 0);
-  for (int b = 0; b < nbatch; b += 2) {
-    if (b + 1 < nbatch) DW_LOAD(1, b + 1);
+  // batches past the end load a valid row with a zeroed G value (see DW_LOAD): no guards needed on the loads
+  DW_LOAD(0, 0);
+  DW_LOAD(1, 1);
+  for (int b = 0; b < nbatch; b += 3) {
+    DW_LOAD(2, b + 2);
     DW_MFMA(0);
     if (b + 1 < nbatch) {
-      if (b + 2 < nbatch) DW_LOAD(0, b + 2);
+      DW_LOAD(0, b + 3);
       DW_MFMA(1);
+    }
+    if (b + 2 < nbatch) {
+      DW_LOAD(1, b + 4);
+      DW_MFMA(2);
     }
   }
 #undef DW_LOAD
