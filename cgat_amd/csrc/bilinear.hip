@@ -779,6 +779,56 @@ __global__ __launch_bounds__(256) void prepare_W_f16_kernel(const float* __restr
     dst[(blk + 1) * 2048 + in] = l;
   }
 }
+// Many 128 x 128 weights in ONE launch (a dense layer's own prepare is a single workgroup: 11 us of latency per layer,
+// 48 layers per hypernetwork step): item i = (src, sb, sc) goes to dst + i * WPREP_IMAGE_FLOATS, wmax behind its planes.
+__global__ __launch_bounds__(256) void prepare_W_f16_batch_kernel(WPrepBatch b, float* __restrict__ dst) {
+  __shared__ float wm[4];
+  const int it = blockIdx.x, tid = threadIdx.x;
+  const float* src = b.src[it];
+  const long sb = b.sb[it], sc = b.sc[it];
+  float* img = dst + (size_t)it * WPREP_IMAGE_FLOATS;
+  float v[64];
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int i = r * 256 + tid;
+    int bb, c;
+    if (sc == 1) { bb = i >> 7; c = i & 127; }
+    else { c = i >> 7; bb = i & 127; }
+    v[r] = src[bb * sb + c * sc];
+    m = fmaxf(m, fabsf(v[r]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) wm[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  if (tid == 0) img[16384] = m;
+  float st, iv;
+  pow2_scale(m, st, iv);
+  _Float16* d16 = reinterpret_cast<_Float16*>(img);
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int i = r * 256 + tid;
+    int bb, c;
+    if (sc == 1) { bb = i >> 7; c = i & 127; }
+    else { c = i >> 7; bb = i & 127; }
+    const float x = v[r] * st;
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+    const int kh = bb >> 6, s2 = (bb >> 5) & 1, kg = (bb & 31) >> 3, j = bb & 7;
+    const long blk = (((long)half * 2 + kh) * 2 + s2) * 2;
+    const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+    d16[(blk + 0) * 2048 + in] = h;
+    d16[(blk + 1) * 2048 + in] = l;
+  }
+}
+int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream) {
+  if (b.n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_W_f16_batch_kernel, dim3(b.n), dim3(256), 0, stream, b, dst);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream) {
   if (NA <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_W_f16_kernel, dim3(NA), dim3(256), 0, stream, src, (_Float16*)dst, sa, sb, sc,

@@ -292,11 +292,12 @@ bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void
 }
 size_t linear128_ws_bytes(int n_out) { return ws_round((size_t)n_out * 128 * 3 / 2 + 4, 4); }
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
-                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out) {
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out, const void* prepared) {
   if (rows <= 0) return CGAT_OK;
   const int ncb = n_out / 128;
   // operand (a = output block, b = k, c = output in block) = W[(128 a + c) * so + b * sk]
-  if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(W, ws, ncb, 128 * so, sk, so, stream));
+  if (prepared && bilinear_mode() == 2 && n_out == 128) ws = const_cast<void*>(prepared);
+  else if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(W, ws, ncb, 128 * so, sk, so, stream));
   else CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
   CGAT_PROF("linear128", stream);
   const int grid = cdiv(rows, 128);

@@ -89,13 +89,23 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
                   int act = CGAT_ACT_NONE);
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream);
+// batched form for 128 x 128 dense-layer weights W(o, k) = src[o * so + k * sk]: image i at dst + i * WPREP_IMAGE_FLOATS
+#define WPREP_MAX 48
+#define WPREP_IMAGE_FLOATS (16384 + 4)
+struct WPrepBatch {
+  const float* src[WPREP_MAX];
+  long sb[WPREP_MAX], sc[WPREP_MAX];   // strides of the k index and of the output index
+  int n;
+};
+int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream);
 // dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]
 bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out);
 size_t linear128_ws_bytes(int n_out = 128);
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
-                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out = 128);
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out = 128,
+                     const void* prepared = nullptr);   // prepared: image from prepare_W_f16_batch_launch (f16x3, n_out 128)
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
 // operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);

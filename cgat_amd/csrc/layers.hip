@@ -18,9 +18,27 @@ struct Ctx {
   size_t scratch_need;
   char* scratch;
   size_t scratch_bytes;
+  // 128 x 128 dense-layer weights prepared ahead in one launch (f16x3 mode): looked up by (pointer, strides) in gemm()
+  WPrepBatch wprep;
+  float* wprep_images;
   Ctx(void* ws, size_t bytes, bool dry_, hipStream_t st)
       : w(dry_ ? nullptr : ws, dry_ ? (size_t)-1 / 2 : bytes), dry(dry_), s(st), scratch_need(0), scratch(nullptr),
-        scratch_bytes(0) {}
+        scratch_bytes(0), wprep_images(nullptr) { wprep.n = 0; }
+  // call before seal(): reserves the image space; add items, then wprep_run() once
+  void wprep_reserve(int max_items) { wprep_images = take<float>((size_t)max_items * WPREP_IMAGE_FLOATS); }
+  void wprep_add(const float* W, long so, long sk) {
+    if (wprep.n < WPREP_MAX) { wprep.src[wprep.n] = W; wprep.sb[wprep.n] = sk; wprep.sc[wprep.n] = so; ++wprep.n; }
+  }
+  int wprep_run() {
+    if (dry || bilinear_mode() != 2 || wprep.n == 0) { if (bilinear_mode() != 2) wprep.n = 0; return CGAT_OK; }
+    return prepare_W_f16_batch_launch(wprep, wprep_images, s);
+  }
+  const void* wprep_find(const float* W, long so, long sk) const {
+    if (dry || bilinear_mode() != 2) return nullptr;
+    for (int i = 0; i < wprep.n; ++i)
+      if (wprep.src[i] == W && wprep.sb[i] == sk && wprep.sc[i] == so) return wprep_images + (size_t)i * WPREP_IMAGE_FLOATS;
+    return nullptr;
+  }
   template <typename T>
   T* take(size_t n) { return w.take<T>(n); }
   void seal() {  // everything after the persistent carve-outs is scratch
@@ -41,9 +59,11 @@ struct Ctx {
                           (p.beta == 0.f || p.beta == 1.f) && (p.act == CGAT_ACT_NONE || p.act == CGAT_ACT_TANH);
     if (dense128) need(linear128_ws_bytes());
     if (dry) return CGAT_OK;
-    if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes())
-      return linear128_launch(p.A, p.lda, p.B, p.b_kmajor ? 1 : p.ldb, p.b_kmajor ? p.ldb : 1, p.bias, p.act,
-                              p.beta == 1.f, p.C, p.ldc, p.M, scratch, s);
+    if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes()) {
+      const long so = p.b_kmajor ? 1 : p.ldb, sk = p.b_kmajor ? p.ldb : 1;
+      return linear128_launch(p.A, p.lda, p.B, so, sk, p.bias, p.act, p.beta == 1.f, p.C, p.ldc, p.M, scratch, s, 128,
+                              wprep_find(p.B, so, sk));
+    }
     return gemm_launch(p, scratch, scratch_bytes, s);
   }
   // weight (and bias) gradients of width-128 dense layers: out_k = G^T X_k, bsum = column sums of G (rowsdw.hip);
@@ -717,7 +737,17 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
   const int W = p->W;
   const size_t WW = (size_t)W * W;
   float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
+  const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
+  if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
   c.seal();
+  if (batch_w) {   // every dense-layer weight of the pass, prepared in one launch (forward orientation [out][in])
+    for (int l = 0; l < p->n_hyper; ++l) {
+      for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], W, 1);
+      c.wprep_add(p->layer[l].head_b, W, 1);
+      c.wprep_add(p->layer[l].head_w + WW * W, W, 1);
+    }
+    CGAT_TRY(c.wprep_run());
+  }
   HnetSaved sv = hnet_saved(saved, rows, p);
   const float* hin = h0;
   if (p->damping) {
@@ -784,7 +814,17 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
   float* g_t = c.take<float>(rw);
   float* g_pre = c.take<float>(rw);
+  const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
+  if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
   c.seal();
+  if (batch_w) {   // the same weights in the transposed orientation (g_in = g_out W)
+    for (int l = 0; l < p->n_hyper; ++l) {
+      for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], 1, W);
+      c.wprep_add(p->layer[l].head_b, 1, W);
+      c.wprep_add(p->layer[l].head_w + WW * W, 1, W);
+    }
+    CGAT_TRY(c.wprep_run());
+  }
   HnetSaved sv = hnet_saved(const_cast<float*>(saved), rows, p);
   const float* hin = p->damping ? sv.hin() : h0;
   RUN(fill_launch(g_hin, 0.f, (long)rw, c.s));

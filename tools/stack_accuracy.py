@@ -28,7 +28,7 @@ y64, g64 = run(om64, "cpu", torch.float64)
 y32, g32 = run(om, "cpu", torch.float32)
 scale = max(float(v.abs().max()) for v in g64.values() if v is not None)
 res = {}
-for mode in ("f32", "bf16x6", "bf16x3"):
+for mode in ("f32", "bf16x6", "bf16x3", "f16x3"):
     P.set_bilinear_mode(mode)
     pm = P.CGAtNet(200, 128, 4, msg_heads=3, neighbor_number=12, update_edges=True)
     pm.load_state_dict(om.state_dict())
@@ -37,16 +37,16 @@ for mode in ("f32", "bf16x6", "bf16x3"):
     res[mode] = (yp, gp)
     print(f"mode {mode}: out max-norm rel err {float((yp - y64).abs().max() / y64.abs().max()):.2e}  (oracle fp32: {float((y32 - y64).abs().max() / y64.abs().max()):.2e})")
 print(f"largest gradient of the case: {scale:.3e}")
-print(f"{'tensor':74s} {'|ref|':>9s} {'orac32':>9s} {'f32':>9s} {'bf16x6':>9s} {'bf16x3':>9s}   (abs err vs fp64 / largest gradient)")
+print(f"{'tensor':74s} {'|ref|':>9s} {'orac32':>9s} {'f32':>9s} {'bf16x6':>9s} {'bf16x3':>9s} {'f16x3':>9s}   (abs err vs fp64 / largest gradient)")
 rows = []
 for k, v in g64.items():
     if v is None:
         continue
     e = lambda g: float((g[k] - v).abs().max()) / scale
-    rows.append((max(e(res["bf16x6"][1]), e(res["f32"][1])), k, float(v.abs().max()) / scale, e(g32), e(res["f32"][1]), e(res["bf16x6"][1]),
-                 e(res["bf16x3"][1])))
+    rows.append((max(e(res["bf16x6"][1]), e(res["f32"][1]), e(res["f16x3"][1])), k, float(v.abs().max()) / scale, e(g32), e(res["f32"][1]), e(res["bf16x6"][1]),
+                 e(res["bf16x3"][1]), e(res["f16x3"][1])))
 for r in sorted(rows, reverse=True)[:14]:
-    print(f"{r[1]:74s} {r[2]:9.2e} {r[3]:9.2e} {r[4]:9.2e} {r[5]:9.2e} {r[6]:9.2e}")
+    print(f"{r[1]:74s} {r[2]:9.2e} {r[3]:9.2e} {r[4]:9.2e} {r[5]:9.2e} {r[6]:9.2e} {r[7]:9.2e}")
 rel = lambda g, k: float((g[k] - g64[k]).abs().max() / g64[k].abs().max())
 worst = {m: max((rel(res[m][1], k), k) for k in g64 if g64[k] is not None and float(g64[k].abs().max()) > 1e-4 * scale) for m in res}
 for m, (e, k) in worst.items():
