@@ -295,10 +295,11 @@ size_t cgat_bilinear_dual_workspace_bytes(int32_t rows);
 int cgat_bilinear_dual(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* zz, int64_t ldz,
                        const float* T, const float* init1, int64_t ldi1, float* out1, int64_t ldo1, const float* init2,
                        int64_t ldi2, float* out2, int64_t ldo2, int32_t rows, void* ws, size_t ws_bytes, void* stream);
-/* Arithmetic of the width-128 trilinear contractions: 0 = f32-input MFMA (exact fp32 fmaf chains),
- * 6 (default) = operands split into three bf16 pieces, six bf16-MFMA passes with fp32 accumulation (measured
- * fp32-equivalent accuracy, 2.67x higher matrix-core ceiling), 3 = three passes (~4e-6 relative).  The mode also
- * selects the split-bf16 edge kernels (edgez.hip, edgebwd.hip) over the f32 GEMM engine. */
+/* Arithmetic of the width-128 matrix-core kernels: 2 (default, "f16x3") = operands scaled by a power of two and
+ * split into two fp16 pieces, three fp16-MFMA passes with fp32 accumulation (measured at the error of an fp32 product
+ * chain); 6 ("bf16x6") = three bf16 pieces, six bf16-MFMA passes (same accuracy, twice the matrix work); 3 = three bf16
+ * passes (~4e-6 relative, fails the parity tests: diagnostic only); 0 = f32-input MFMA (exact fp32 fmaf chains) and the
+ * f32 GEMM engine for the edge products.  Env CGAT_BILINEAR_MODE = f16x3 | bf16x6 | bf16x3 | f32 sets the start value. */
 void cgat_set_bilinear_mode(int32_t mode);
 int32_t cgat_get_bilinear_mode(void);
 /* out[(a*NB+b)*NC + c] = sum_n p[n,a] q[n,b] r[n,c] */
