@@ -207,6 +207,13 @@ __global__ __launch_bounds__(256, 1) void bilinear_rows128_kernel(const float* _
 //   Tq[a][half = c/64][kh = b/64][s2 = (b/32)%2][piece][cb = (c%64)/16][kg = (b%32)/8][i = c%16][j = b%8]
 // one chunk = (a, half, kh) = 2 k-steps x 3 planes x 4 column blocks x 1 KB; a fragment is one ds_read_b128.
 
+// Timing-only ablations of the fp16 form at 83 340 rows (tools/ring_ablation.py; ABL bits: 1 no barrier, 2 no global
+// loads, 4 no fragment reads, 8 no flush -- the last two let the compiler drop MFMAs and are not usable as skeleton
+// times): 754 us as is, 729 without the barrier, 682 without the LDS-DMA loads, 673 without both, against 520 us of
+// pure MFMA issue at the 1.9 GHz the chip holds here.  Tried and dropped (round 1): 4 waves x 64 rows per workgroup
+// (one wave per SIMD on the 512-register budget, every T fragment feeding four row blocks instead of two, i.e. half
+// the LDS fragment traffic): 777 us -- what it saves in LDS reads it loses by having no second wave to cover the
+// flush, the barrier wait and the accumulator-register copies.
 template <int PASSES, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const uint4* __restrict__ Tq,
@@ -330,9 +337,11 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
 #define RG_READ(F1_, F2_, F3_, slot_, s2_, cb_)                                                \
   {                                                                                            \
     const bf16x8* fp = ring + (slot_) * (CH16) + (((s2_) * NP) * 4 + (cb_)) * 64;              \
-    F1_ = fp[0];                                                                               \
-    F2_ = fp[4 * 64];                                                                          \
-    if (PASSES >= 6) F3_ = fp[8 * 64];                                                         \
+    if (!(ABL & 4) || (slot_) + (s2_) + (cb_) == 0) {                                          \
+      F1_ = fp[0];                                                                             \
+      F2_ = fp[4 * 64];                                                                        \
+      if (PASSES >= 6) F3_ = fp[8 * 64];                                                       \
+    }                                                                                          \
   }
 #define RG_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
   {                                                                                            \
@@ -351,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     RG_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
   }
   RG_READ(fa1, fa2, fa3, 0, 0, 0);
+  if constexpr ((ABL & 4) != 0) { fb1 = fa1; fb2 = fa2; fb3 = fa3; }
   f32x4 part[8];
   for (int a = a_beg; a < a_end; ++a) {
 #pragma unroll
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
           RG_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
         }
       }
-      if (c2 == 1) {
+      if (c2 == 1 && !(ABL & 8)) {
         float pva = pst[(a & 3) * PST], pvb = pst[(a & 3) * PST + 16];
         if constexpr (F16) { pva *= rs_a; pvb *= rs_b; }
         const float pas_a = (a & 1) ? -pva : pva, pas_b = (a & 1) ? -pvb : pvb;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
       }
       if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
   }
@@ -1097,7 +1107,14 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
       if (bilinear_mode() == 6)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<6>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
                            (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
-      else if (bilinear_mode() == 2)
+      else if (bilinear_mode() == 2 && getenv("CGAT_RING_ABL")) {   // timing-only ablations (wrong results): dev knob
+#define RG_ABL(A_) hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2, A_>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax)
+        switch (atoi(getenv("CGAT_RING_ABL"))) {
+          case 1: RG_ABL(1); break; case 2: RG_ABL(2); break; case 3: RG_ABL(3); break; case 4: RG_ABL(4); break;
+          case 7: RG_ABL(7); break; case 8: RG_ABL(8); break; case 15: RG_ABL(15); break; default: RG_ABL(0); break;
+        }
+#undef RG_ABL
+      } else if (bilinear_mode() == 2)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
                            (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
       else
