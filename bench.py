@@ -395,7 +395,7 @@ def main():
         hbm_alg = {"edge_z": E * (2 * W2b + C_FEA * 4) + N * W2b,            # Z written, Pj gathered, e read, Pi rows once
                    "edge_seg_bwd": E * 2 * W2b + N * (W2b + W2b // 2),       # Z read, gZ written, Gi written, gS read
                    "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
-                   "edge_gw": E * (W2b + C_FEA * 6)}                         # gZ read, bf16x3 planes of e read
+                   "edge_gw": E * (W2b + C_FEA * (4 if mode == "f16x3" else 6))}   # gZ read, fp16x2 / bf16x3 planes of e read
         hbm = {}
         for tag, nbytes in hbm_alg.items():
             n_t, ms_t = prof[tag]

@@ -731,21 +731,6 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
   }
 }
 
-// at most one atomic per workgroup (thousands of same-address atomics cost more than the pass itself)
-__device__ __forceinline__ void block_absmax_commit(float m, float* out) {
-  __shared__ float wm[16];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
-    // the slot only grows, so a (possibly stale) plain read that is already >= m makes the atomic unnecessary
-    if (m > *reinterpret_cast<volatile float*>(out))
-      atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
-  }
-}
-
 // Weight operands of the edge / dense kernels in the fp16 form: one workgroup per 128 x 128 block `a` keeps the block
 // in registers, takes its largest magnitude, and writes the two planes of 2^k(a) W[a] in the bf16 kernel's order with
 // two planes per k-step; max |W[a]| goes to wmax[a] behind the planes (the consumer undoes 2^k(a) per column block).
@@ -872,8 +857,10 @@ int absmax_launch(const float* src, long n, float* out, hipStream_t stream) {
 
 // Row-gathered variant for operands whose k index is a row number: element (a, b, c) = rows[gather[128 a + b]][c]
 // for 128 a + b < nrows, zero beyond (the last block is padded).
+// F16: two fp16 planes of 2^k rows, 2^k from emax[0] = max |rows|
+template <bool F16>
 __global__ void prepare_T_bf16_rows_kernel(const float* __restrict__ rows, long ld, const int* __restrict__ gather,
-                                           int nrows, uint4* __restrict__ dst, int NA) {
+                                           int nrows, uint4* __restrict__ dst, int NA, const float* __restrict__ emax) {
   // one thread per 16-byte fragment piece: (a, k-step s, kg, column c) -> the 8 rows t = 128 a + 32 s + 8 kg + j of
   // column c; lanes run over c, so the eight row reads are coalesced and the three stores are 16 B at 16-B pitch
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -888,21 +875,35 @@ __global__ void prepare_T_bf16_rows_kernel(const float* __restrict__ rows, long 
     const long t = t0 + j;
     vv[j] = t < nrows ? rows[(gather ? (long)gather[t] : t) * ld + c] : 0.f;
   }
-  split3_x8(vv, x1, x2, x3);
+  if constexpr (F16) {
+    float se, ie;
+    pow2_scale(emax[0], se, ie);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] *= se;
+    split2_x8_f16(vv, x1, x2);
+  } else {
+    split3_x8(vv, x1, x2, x3);
+  }
+  constexpr int NP = F16 ? 2 : 3;
   const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
-  const long blk = ((a * 2 + half) * 4 + s) * 3;          // planes of one k-step, each [cb][kg][i] x 16 bytes
+  const long blk = ((a * 2 + half) * 4 + s) * NP;         // planes of one k-step, each [cb][kg][i] x 16 bytes
   const long in = ((long)cb * 4 + kg) * 16 + i16;
   dst[(blk + 0) * 256 + in] = __builtin_bit_cast(uint4, x1);
   dst[(blk + 1) * 256 + in] = __builtin_bit_cast(uint4, x2);
-  dst[(blk + 2) * 256 + in] = __builtin_bit_cast(uint4, x3);
+  if constexpr (!F16) dst[(blk + 2) * 256 + in] = __builtin_bit_cast(uint4, x3);
 }
 
+// emax != null: the fp16 form (two planes of 2^k rows, 2^k from emax[0])
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
-                               hipStream_t stream) {
+                               hipStream_t stream, const float* emax) {
   long total = (long)NA * 16 * 128;
   if (total <= 0) return CGAT_OK;
-  hipLaunchKernelGGL(prepare_T_bf16_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, rows, ld, gather, nrows,
-                     (uint4*)dst, NA);
+  if (emax)
+    hipLaunchKernelGGL(prepare_T_bf16_rows_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, stream, rows, ld, gather,
+                       nrows, (uint4*)dst, NA, emax);
+  else
+    hipLaunchKernelGGL(prepare_T_bf16_rows_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, stream, rows, ld, gather, nrows,
+                     (uint4*)dst, NA, emax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -913,6 +914,16 @@ int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb,
   if (total <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_T_bf16_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
                      sa, sb, sc, alternate, (const float*)nullptr);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+// fp16 form with the maximum already known (tmax[0], device memory): strided sources
+int prepare_T_f16_scaled_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, const float* tmax,
+                                hipStream_t stream) {
+  long total = (long)NA * 128 * 128;
+  if (total <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_T_bf16_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
+                     sa, sb, sc, 0, tmax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -1384,6 +1395,14 @@ __global__ void absmax_rows128_kernel(const float* __restrict__ t, long ld, int 
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   block_absmax_commit(m, out);
+}
+// max |t[n, 0..127]| over rows of stride ld folded into out[0] (NOT zeroed here)
+int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream) {
+  if (rows <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG((ld % 4) == 0 && (((uintptr_t)t) & 15) == 0, "absmax_rows128: rows must be 16-byte aligned");
+  hipLaunchKernelGGL(absmax_rows128_kernel, dim3(rows < 8192 ? (rows + 7) / 8 : 1024), dim3(256), 0, stream, t, ld, rows, out);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
 }
 
 // Tried and dropped (round 1): the same kernel on v_mfma_f32_16x16x32_bf16 with the product split of the next k-step

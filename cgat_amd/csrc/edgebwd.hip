@@ -17,8 +17,14 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
                                                          const uint4* __restrict__ Wq, int ncb,
                                                          float* __restrict__ out, long ldo,
                                                          const int* __restrict__ scatter, int E, int accumulate,
-                                                         const float* __restrict__ bias) {
-  __shared__ uint4 Bs[2][1536];                  // [buffer][half][plane][cb][lane]
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ amax) {
+  // PASSES == 2: two fp16 planes, three passes (mfma_bf16.h).  The rows of gZ are consumed k-step by k-step, so their
+  // scale is per tensor: amax[0] = max |gZ| from the kernel that produced it; the weight's max sits behind its planes.
+  constexpr bool F16 = PASSES == 2;
+  constexpr int NP = F16 ? 2 : 3;
+  constexpr int HP = NP * 256;                   // 16-byte pieces of one (a, half, k-step) block
+  __shared__ uint4 Bs[2][2 * HP];                // [buffer][half][plane][cb][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
   const int row_w = blockIdx.x * 256 + wave * 32;
@@ -33,22 +39,30 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sA = 1.f, inv_all = 1.f;
+  if constexpr (F16) {
+    float iA, sW, iW;
+    pow2_scale(amax[0], sA, iA);
+    pow2_scale(reinterpret_cast<const float*>(Wq + (long)ncb * 8 * HP)[0], sW, iW);
+    inv_all = iA * iW;
+  }
 
-  // B staging: thread tid moves 16-byte pieces tid, tid + 512, tid + 1024 of the k-step's [half0 | half1] image
+  // B staging: thread tid moves 16-byte pieces tid, tid + 512 (, tid + 1024) of the k-step's [half0 | half1] image
   uint4 sb0, sb1, sb2;
   const int p1 = tid + 512, p2 = tid + 1024;
 #define GE_BLOAD(ks_)                                                                                    \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
-    const uint4* h0 = Wq + ((a_ * 2 + 0) * 4 + s_) * 768;                                                \
-    const uint4* h1 = Wq + ((a_ * 2 + 1) * 4 + s_) * 768;                                                \
+    const uint4* h0 = Wq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
+    const uint4* h1 = Wq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
     sb0 = h0[tid];                                                                                       \
-    sb1 = p1 < 768 ? h0[p1] : h1[p1 - 768];                                                              \
-    sb2 = h1[p2 - 768];                                                                                  \
+    sb1 = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
+    if (NP == 3) sb2 = h1[p2 - HP];                                                                      \
   }
 #define GE_BSTORE(buf_)                                                                                  \
   {                                                                                                      \
-    Bs[buf_][tid] = sb0; Bs[buf_][p1] = sb1; Bs[buf_][p2] = sb2;                                         \
+    Bs[buf_][tid] = sb0; Bs[buf_][p1] = sb1;                                                             \
+    if (NP == 3) Bs[buf_][p2] = sb2;                                                                     \
   }
   // raw gZ (rows a/b, 8 columns each) of the next k-step (ra*, rb*) and of the one after (sa*, sb*): loads are
   // issued two k-steps (~3 us) before their values are split, enough bytes in flight per CU to cover HBM latency
@@ -62,8 +76,14 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   }
 #define GE_SPLIT(R0_, R1_, Q1_, Q2_, Q3_)                                                                \
   {                                                                                                      \
-    const float v[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                         \
-    split3_x8(v, Q1_, Q2_, Q3_);                                                                         \
+    if constexpr (F16) {                                                                                 \
+      const float v[8] = {R0_.x * sA, R0_.y * sA, R0_.z * sA, R0_.w * sA,                                \
+                          R1_.x * sA, R1_.y * sA, R1_.z * sA, R1_.w * sA};                               \
+      split2_x8_f16(v, Q1_, Q2_);                                                                        \
+    } else {                                                                                             \
+      const float v[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                       \
+      split3_x8(v, Q1_, Q2_, Q3_);                                                                       \
+    }                                                                                                    \
   }
   bf16x8 qa1, qa2, qa3, qb1, qb2, qb3;           // current k-step's gZ fragments (rows a, b)
   bf16x8 na1, na2, na3, nb1, nb2, nb3;           // next k-step's
@@ -79,13 +99,13 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #define GE_MFMA1(F1_, F2_, F3_, Q1_, Q2_, Q3_, P_)                                                       \
   {                                                                                                      \
     if (PASSES >= 6) {                                                                                   \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, Q1_, P_, 0, 0, 0);                               \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q3_, P_, 0, 0, 0);                               \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q2_, P_, 0, 0, 0);                               \
+      P_ = mma16<F16>(F3_, Q1_, P_);                                                                     \
+      P_ = mma16<F16>(F1_, Q3_, P_);                                                                     \
+      P_ = mma16<F16>(F2_, Q2_, P_);                                                                     \
     }                                                                                                    \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q1_, P_, 0, 0, 0);                                 \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q2_, P_, 0, 0, 0);                                 \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q1_, P_, 0, 0, 0);                                 \
+    P_ = mma16<F16>(F2_, Q1_, P_);                                                                       \
+    P_ = mma16<F16>(F1_, Q2_, P_);                                                                       \
+    P_ = mma16<F16>(F1_, Q1_, P_);                                                                       \
   }
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     for (int g = 0; g < 8; ++g) {                // 16-column output block g = (half, cb)
       bf16x8 n1, n2, n3;
       if (g < 7) {
-        const int o = ((g + 1) >> 2) * 768 + ((g + 1) & 3) * 64;
+        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;
         n1 = bs[o]; n2 = bs[o + 256];
         if (PASSES >= 6) n3 = bs[o + 512];
       }
@@ -121,6 +141,10 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #undef GE_MFMA1
   // acc[2 g + nb][j] = out[row(nb)][16 g + 4 kg + j]
   const long oa = scatter ? (long)scatter[rca] : rca, ob = scatter ? (long)scatter[rcb] : rcb;
+  if constexpr (F16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc[i] * inv_all;
+  }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,10 +189,23 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 template <int PASSES>
 __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Eq, float* __restrict__ slab,
-                                                         int E, int ncb, int nsteps, int S) {
+                                                         int E, int ncb, int nsteps, int S,
+                                                         const float* __restrict__ gmax, const float* __restrict__ emax) {
+  // PASSES == 2: two fp16 planes, three passes; both operands are indexed by the reduction index (the edge slot), so
+  // both scales are per tensor: gmax[0] = max |gZ| (from its producer), emax[0] = max |e| (the planes carry 2^k e)
+  constexpr bool F16 = PASSES == 2;
+  constexpr int NP = F16 ? 2 : 3;
+  constexpr int HP = NP * 256;
   constexpr int FLUSH = 64;
-  __shared__ uint4 Es[2][1536];                          // e planes of one k-step: [half][plane][cb][lane]
-  __shared__ __attribute__((aligned(16))) unsigned char Gs[2][2][3][8192];   // [buffer][column block][plane][32 x 256 B]
+  __shared__ uint4 Es[2][2 * HP];                        // e planes of one k-step: [half][plane][cb][lane]
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[2][2][NP][8192];   // [buffer][column block][plane][32 x 256 B]
+  float sG = 1.f, inv_all = 1.f;
+  if constexpr (F16) {
+    float iG, sE, iE;
+    pow2_scale(gmax[0], sG, iG);
+    pow2_scale(emax[0], sE, iE);
+    inv_all = iG * iE;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
   const int grp = wave >> 2, wq = wave & 3;              // column block of the pair, 32-column slice in it
@@ -188,15 +225,16 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
 #define GW_ELOAD(ks_)                                                                                    \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
-    const uint4* h0 = Eq + ((a_ * 2 + 0) * 4 + s_) * 768;                                                \
-    const uint4* h1 = Eq + ((a_ * 2 + 1) * 4 + s_) * 768;                                                \
+    const uint4* h0 = Eq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
+    const uint4* h1 = Eq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
     se0 = h0[tid];                                                                                       \
-    se1 = p1 < 768 ? h0[p1] : h1[p1 - 768];                                                              \
-    se2 = h1[p2 - 768];                                                                                  \
+    se1 = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
+    if (NP == 3) se2 = h1[p2 - HP];                                                                      \
   }
 #define GW_ESTORE(buf_)                                                                                  \
   {                                                                                                      \
-    Es[buf_][tid] = se0; Es[buf_][p1] = se1; Es[buf_][p2] = se2;                                         \
+    Es[buf_][tid] = se0; Es[buf_][p1] = se1;                                                             \
+    if (NP == 3) Es[buf_][p2] = se2;                                                                     \
   }
   // raw gZ tile pieces: float4 number gt + 256 i of the k-step's contiguous [32][128] tile, i < 4
   float4 r0, r1, r2, r3, s0, s1, s2, s3;
@@ -215,11 +253,17 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     const int row = idx >> 5, c4 = idx & 31;                                                             \
     const int off = 256 * row + 16 * ((c4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (c4 & 1); \
     uint2 x1, x2, x3;                                                                                    \
-    split3_pair(R_.x * sg_, R_.y * sg_, x1.x, x2.x, x3.x);                                               \
-    split3_pair(R_.z * sg_, R_.w * sg_, x1.y, x2.y, x3.y);                                               \
+    if constexpr (F16) {                                                                                 \
+      const float m_ = (sg_) * sG;                                                                       \
+      split2_pair_f16(R_.x * m_, R_.y * m_, x1.x, x2.x);                                                 \
+      split2_pair_f16(R_.z * m_, R_.w * m_, x1.y, x2.y);                                                 \
+    } else {                                                                                             \
+      split3_pair(R_.x * sg_, R_.y * sg_, x1.x, x2.x, x3.x);                                             \
+      split3_pair(R_.z * sg_, R_.w * sg_, x1.y, x2.y, x3.y);                                             \
+    }                                                                                                    \
     *reinterpret_cast<uint2*>(&Gs[buf_][grp][0][off]) = x1;                                              \
     *reinterpret_cast<uint2*>(&Gs[buf_][grp][1][off]) = x2;                                              \
-    if (PASSES >= 6) *reinterpret_cast<uint2*>(&Gs[buf_][grp][2][off]) = x3;                             \
+    if (PASSES >= 6) *reinterpret_cast<uint2*>(&Gs[buf_][grp][NP - 1][off]) = x3;                        \
   }
   // transposed fragment of plane pl_, column block nb_ of this wave: k = 8 kg + j  <->  slot 8 kg + j
   const int l16q = n16 >> 2, l16p = n16 & 3;
@@ -241,13 +285,13 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
 #define GW_MFMA1(F1_, F2_, F3_, Q1_, Q2_, Q3_, P_)                                                       \
   {                                                                                                      \
     if (PASSES >= 6) {                                                                                   \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F3_, Q1_, P_, 0, 0, 0);                               \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q3_, P_, 0, 0, 0);                               \
-      P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q2_, P_, 0, 0, 0);                               \
+      P_ = mma16<F16>(F3_, Q1_, P_);                                                                     \
+      P_ = mma16<F16>(F1_, Q3_, P_);                                                                     \
+      P_ = mma16<F16>(F2_, Q2_, P_);                                                                     \
     }                                                                                                    \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_, Q1_, P_, 0, 0, 0);                                 \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q2_, P_, 0, 0, 0);                                 \
-    P_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1_, Q1_, P_, 0, 0, 0);                                 \
+    P_ = mma16<F16>(F2_, Q1_, P_);                                                                       \
+    P_ = mma16<F16>(F1_, Q2_, P_);                                                                       \
+    P_ = mma16<F16>(F1_, Q1_, P_);                                                                       \
   }
   // the workgroup's slab tile: rows = its 256 columns of gZ, 128 outputs each
   float* tile = slab + ((long)split * ncb * 128 + (long)cb128 * 128 + 32 * wq) * 128;
@@ -257,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                   \
       float4* o = reinterpret_cast<float4*>(tile + (long)(16 * nb + n16) * 128 + 16 * g + 4 * kg);       \
       const f32x4 v = acc[2 * g + nb];                                                                   \
-      float4 w = make_float4(v[0] * sg_, v[1] * sg_, v[2] * sg_, v[3] * sg_);                            \
+      const float fs_ = F16 ? (sg_) * inv_all : (sg_);                                                   \
+      float4 w = make_float4(v[0] * fs_, v[1] * fs_, v[2] * fs_, v[3] * fs_);                            \
       if (!(first_)) { const float4 u = *o; w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w; }            \
       *o = w;                                                                                            \
       acc[2 * g + nb] = f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
@@ -292,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     for (int g = 0; g < 8; ++g) {                // 16 outputs k = 16 g ... : e fragment g = (half, cb)
       bf16x8 n1, n2, n3;
       if (g < 7) {
-        const int o = ((g + 1) >> 2) * 768 + ((g + 1) & 3) * 64;
+        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;
         n1 = es[o]; n2 = es[o + 256];
         if (PASSES >= 6) n3 = es[o + 512];
       }
@@ -333,21 +378,33 @@ bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, 
 
 // We: element (col, k) at We[col * s_col + k * s_out] (col < W2 inputs, k < 128 outputs).  Wq: edge_z_wq_floats(W2)
 // floats of workspace.  bias [128] or null (added to the product, before any accumulation into `out`).
+// amax (f16x3 mode only): device pointer to max |gZ|; without it the bf16x6 form runs.
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
-                   hipStream_t stream) {
+                   hipStream_t stream, const float* amax) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
+  const bool f16 = bilinear_mode() == 2 && amax && s_out == 1 && (s_col % 4) == 0 && (((uintptr_t)We) & 15) == 0;
   // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * s_col + c * s_out]
-  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));
+  if (f16) {   // per-tensor weight scale: max |We| behind the two planes
+    float* wmax = Wq + (size_t)ncb * 16384;
+    if (hipMemsetAsync(wmax, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
+    CGAT_TRY(absmax_rows128_launch(We, s_col, W2, wmax, stream));
+    CGAT_TRY(prepare_T_f16_scaled_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, wmax, stream));
+  } else {
+    CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));
+  }
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);   // the per-edge launch / node-side and dense-layer uses
   const int grid = cdiv(E, 256);
-  if (bilinear_mode() != 3)
+  if (f16)
+    hipLaunchKernelGGL(edge_ge_kernel<2>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
+                       scatter, E, accumulate, bias, amax);
+  else if (bilinear_mode() != 3)
     hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate, bias);
+                       scatter, E, accumulate, bias, amax);
   else
     hipLaunchKernelGGL(edge_ge_kernel<3>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate, bias);
+                       scatter, E, accumulate, bias, amax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -368,8 +425,9 @@ size_t edge_gw_ws_floats(int E, int W2) {
 }
 
 // out[col * ldo + k] = sum_t G[t, col] * e[perm[t] * lde + k],   G[t, 128 a + j] at gZ[t * ldg + a * gzb + j]
+// gmax, emax (f16x3 mode only): device pointers to max |gZ| and max |e|; without them the bf16x6 form runs.
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
-                   float* ws, float* out, long ldo, hipStream_t stream) {
+                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax, const float* emax) {
   if (E <= 0) {
     GemmParams z = gemm_params(W2, 128, 0, nullptr, 1, nullptr, 1, out, ldo);
     return gemm_launch(z, nullptr, 0, stream);   // K = 0: zero fill
@@ -378,16 +436,20 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
   float* planes = ws;
   float* slab = ws + (((size_t)na * 128 * 128 * 3 + 1) / 2 + 15) / 16 * 16;
   // operand (a = slot block, b = slot in block, c = k) = e[perm[128 a + b] * lde + c], zero past E
-  CGAT_TRY(prepare_T_bf16_rows_launch(e, lde, perm, E, planes, na, stream));
+  const bool f16 = bilinear_mode() == 2 && gmax && emax;
+  CGAT_TRY(prepare_T_bf16_rows_launch(e, lde, perm, E, planes, na, stream, f16 ? emax : nullptr));
   {
     CGAT_PROF(perm ? "edge_gw" : "rows_gw", stream);
     const int nsteps = cdiv(E, 32);
-    if (bilinear_mode() != 3)
+    if (f16)
+      hipLaunchKernelGGL(edge_gw_kernel<2>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
+                         slab, E, ncb, nsteps, S, gmax, emax);
+    else if (bilinear_mode() != 3)
       hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
-                         slab, E, ncb, nsteps, S);
+                         slab, E, ncb, nsteps, S, gmax, emax);
     else
       hipLaunchKernelGGL(edge_gw_kernel<3>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
-                         slab, E, ncb, nsteps, S);
+                         slab, E, ncb, nsteps, S, gmax, emax);
     CGAT_LAUNCH_CHECK();
   }
   return splitk_reduce_launch(slab, S, W2, 128, out, ldo, stream);

@@ -87,6 +87,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
                   int act = CGAT_ACT_NONE);
+int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream);  // folds into out[0]
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream);
 // batched form for 128 x 128 dense-layer weights W(o, k) = src[o * so + k * sk]: image i at dst + i * WPREP_IMAGE_FLOATS
@@ -99,7 +100,9 @@ struct WPrepBatch {
 };
 int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
-                               hipStream_t stream);
+                               hipStream_t stream, const float* emax = nullptr);   // emax: fp16 form scaled by max |rows|
+int prepare_T_f16_scaled_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, const float* tmax,
+                                hipStream_t stream);
 // dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]
 bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out);
 size_t linear128_ws_bytes(int n_out = 128);
@@ -111,11 +114,13 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);
 size_t edge_gw_ws_floats(int E, int W2);
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
-                   float* ws, float* out, long ldo, hipStream_t stream);
+                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax = nullptr,
+                   const float* emax = nullptr);   // device maxima of |gZ| and |e| -> fp16 form in the f16x3 mode
 bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
-                   hipStream_t stream);
+                   hipStream_t stream,
+                   const float* amax = nullptr);   // amax: device max |gZ| -> fp16 form in the f16x3 mode
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

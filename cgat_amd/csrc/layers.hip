@@ -6,6 +6,7 @@
 #include "../../include/cgat_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include "mfma_bf16.h"
 
 // ---------------------------------------------------------------------------------------
 // launch context: persistent workspace carve-outs + one scratch region shared (in stream
@@ -178,8 +179,12 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
                                                            const int* __restrict__ rowptr,
                                                            const float* __restrict__ wA_out, int N, int H, int Hd,
                                                            float* __restrict__ tt, float* __restrict__ ga,
-                                                           float* __restrict__ Gi, float* __restrict__ partialW) {
+                                                           float* __restrict__ Gi, float* __restrict__ partialW,
+                                                           float* __restrict__ gzmax) {
+  // gzmax (optional, VEC path): max |gZ| is folded into gzmax[0] (zeroed before) -- the per-tensor scale the fp16
+  // forms of the two kernels that consume gZ need (edgebwd.hip); a maximum does not depend on the order it is taken in
   extern __shared__ float pw[];  // [HHd] per-column partial sums of g_a * leaky(zA)
+  float gm = 0.f;
   const int HHd = H * Hd, W2 = 2 * HHd;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < HHd; c += 256) pw[c] = 0.f;
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
               }
               float* dst = gz_block ? gZ + (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : gZ + (long)t * W2 + col;
               *reinterpret_cast<float4*>(dst) = g;
+              gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
               gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
             }
           }
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   }
   __syncthreads();
   for (int c = tid; c < HHd; c += 256) partialW[(long)blockIdx.x * HHd + c] = pw[c];
+  if (VEC && gzmax) block_absmax_commit(gm, gzmax);
 }
 
 struct AttnDims {
@@ -417,11 +424,13 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
 static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* Wcat,
                                           float* gWcat, float* gbcat, const float* gZ, long gz_ld, long gzb, float* Gi,
                                           float* Gj, bool have_Gi, const float* x, const float* e, float* g_x, float* g_e,
-                                          float* Wq, float* gw_ws) {
+                                          float* Wq, float* gw_ws, const float* scales = nullptr) {
+  // scales (f16x3 mode, optional): device {max |gZ|, max |e|} -> the per-edge products run on two fp16 planes
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
   // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
   if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
-    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s));
+    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
+                       scales));
   } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = xb;
@@ -431,7 +440,8 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   }
   // grad W_e = gZ^T @ e[perm]
   if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
-    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s));
+    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s, scales,
+                       scales ? scales + 1 : nullptr));
   } else {
     GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = xb;
@@ -490,6 +500,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   float* Gj = c.take<float>((size_t)d.N * d.W2);
   float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
   float* gw_ws = c.take<float>(edge_gw_ws_floats(d.E, d.W2));
+  float* scales = c.take<float>(64);   // [0] max |gZ|, [1] max |edge_attr| (f16x3 mode)
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(const_cast<float*>(saved), d);
   const float invH = 1.f / d.H;
@@ -527,24 +538,29 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   }
   // g_alpha, softmax backward, gZ, the destination-side segment sum Gi and the partial sums for
   // grad fc_out_A, all per whole destination segment in one pass (edge_seg_bwd_kernel)
+  bool have_scales = false;
   if (!c.dry && d.N > 0) {
     CGAT_CHECK_ARG(d.H <= 16, "nodes_attention_backward: more than 16 heads");
     CGAT_PROF("edge_seg_bwd", c.s);
     size_t shm = (size_t)d.HHd * sizeof(float);
     const bool vec = (d.Hd % 4 == 0) && ((((uintptr_t)sv.Z) | ((uintptr_t)gZ) | ((uintptr_t)gS) | ((uintptr_t)Gi) |
                                           ((uintptr_t)p->A_out_w)) & 15) == 0;
+    have_scales = vec && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0;
+    if (have_scales) CGAT_HIP(hipMemsetAsync(scales, 0, 2 * sizeof(float), c.s));
     if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial,
+                         have_scales ? scales : (float*)nullptr);
     else
       hipLaunchKernelGGL(edge_seg_bwd_kernel<false>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, (float*)nullptr);
     CGAT_LAUNCH_CHECK();
   }
+  if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, gZ, gz_ld, gzb, Gi, Gj, true, x, e, g_x, g_e, Wq,
-                                          gw_ws));
+                                          gw_ws, have_scales ? scales : nullptr));
   RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));

@@ -83,6 +83,21 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// at most one atomic per workgroup (thousands of same-address atomics cost more than the pass itself)
+__device__ __forceinline__ void block_absmax_commit(float m, float* out) {
+  __shared__ float wm[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
+    // the slot only grows, so a (possibly stale) plain read that is already >= m makes the atomic unnecessary
+    if (m > *reinterpret_cast<volatile float*>(out))
+      atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
+  }
+}
+
 // global address = scalar base + per-lane 32-bit byte offset; LDS address = lds_addr + 16 (4) * lane
 __device__ __forceinline__ void glds_b128(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
