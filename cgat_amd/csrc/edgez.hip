@@ -246,6 +246,294 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 #undef EZ_MFMA
 }
 
+// ---------------------------------------------------------------------------------------
+// The per-edge launch with the x_j projection folded in (f16x3 arithmetic):
+//     Z[t, :] = [W_e | W_j] [e[perm[t]] ; x[src[t]]] + Pi[dst[t], :]
+// Why, and what bounds these kernels: timing-only ablations (tools/edgez_ablation.sh; E = 1 000 080)
+//                                   edge_z (K = 128, Pi and Pj gathered)     this kernel (K = 256, Pi gathered)
+//     as is                                      3.15 ms                     3.2 -> 2.76 ms (see below)
+//     without the Z stores                       (-17 %)                     2.1 -> 1.92
+//     without the epilogue's loads               (-55 %)                     2.7 -> 2.27
+//     MFMA + LDS-ring skeleton only              ~0.95                       1.7
+// Neither form hid its epilogue behind the other workgroup of the CU; pointing the old kernel's Pj gather at cached
+// rows (3.0 ms) or sharing the weight stream between 256 rows (3.6 ms) changed nothing.  The reason is the in-order
+// vmcnt: stores count in it, so the first ring wait after an epilogue that needs a load issued AFTER the stores
+// drains them, and inside the epilogue every load issued after a store does the same.  Two changes took this kernel
+// from 3.2 to 2.76 ms: an 8-slot ring (the first load younger than the stores is needed five k-steps later instead of
+// two; waits of vmcnt(18)/(10), derivation at the wait) and all Pi loads of a slice issued before its first store.
+// Folding the x_j projection into the product (K = 256) is what makes room for that: it removes the Pj gather (6 KB
+// per edge, a third of the epilogue's requests, 16 VGPRs of addresses) at the price of matrix work the kernel has
+// room for, and the per-node projection Pj = x W_j^T is no longer computed.  Still exposed: ~0.85 ms of store
+// latency (five k-steps = 1.3 us is not enough under load) and the Pi loads' L2 latency (0.2 ms); a ring on a
+// producer wave, whose vmcnt never sees a store, is the next step.
+// Operand: prepare_W2_f16 planes, chunk (a, half, s) = 8 KB at Wq + ((a*2 + half)*8 + s) * 512 uint4, s < 4 the W_e
+// k-steps, s >= 4 the W_j ones, one scale per column block a over both (wmax behind the planes); the row scale is the
+// maximum over the concatenated 256-value row.
+template <int ABL>   // timing-only ablations (wrong results): 1 no Z stores, 2 no Pi loads, 4 no logits
+__global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict__ e, long lde,
+                                                         const int* __restrict__ perm, const float* __restrict__ xn,
+                                                         long ldx, const uint4* __restrict__ Wq, int ncb,
+                                                         const float* __restrict__ Pi, const int* __restrict__ dsti,
+                                                         const int* __restrict__ srci, long ld_add,
+                                                         float* __restrict__ Z, long ldz, int E,
+                                                         const float* __restrict__ wA, const float* __restrict__ bA,
+                                                         int H, int cb_per_head, float* __restrict__ a_out) {
+  constexpr int CH16 = 2 * 4 * 64;              // 16-byte pieces per chunk = 8 KB
+  constexpr int RING = 8;                       // ring slots (see the vmcnt note at the loop's wait)
+  __shared__ uint4 smem[RING * CH16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int row_w = blockIdx.x * 128 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_a + 16;
+  const int rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned t_off = (unsigned)tid * 16;
+  const long last_chunk = (long)ncb * 16 - 1;
+  const float* wmax = reinterpret_cast<const float*>(Wq + (long)ncb * 16 * CH16);
+
+  // q[plane][2 s + nb]: s < 4 from e[perm[row]], s >= 4 from x[src[row]]
+  bf16x8 q1[16], q2[16];
+  float rs_a, rs_b;
+  {
+    const float* ra[2] = {e + (perm ? (long)perm[rca] : (long)rca) * lde, e + (perm ? (long)perm[rcb] : (long)rcb) * lde};
+    const float* rx[2] = {xn + (long)srci[rca] * ldx, xn + (long)srci[rcb] * ldx};
+    float qv[2][64];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>((s < 4 ? ra[nb] : rx[nb]) + 32 * (s & 3) + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      if (nb) rs_b = iq; else rs_a = iq;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+      }
+    }
+  }
+  const float* pia = Pi + (long)dsti[rca] * ld_add;
+  const float* pib = Pi + (long)dsti[rcb] * ld_add;
+  float* za = Z + (long)rca * ldz;
+  float* zb = Z + (long)rcb * ldz;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define EX_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Wq + gi * CH16;                                                          \
+    const unsigned dst = wave_t + (unsigned)((gi_) & (RING - 1)) * (CH16 * 16);                \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 256, t_off, dst + 4096);                                                    \
+  }
+  EX_TLOAD(0l);
+  EX_TLOAD(1l);
+  EX_TLOAD(2l);
+  EX_TLOAD(3l);
+  EX_TLOAD(4l);
+  EX_TLOAD(5l);
+  EX_TLOAD(6l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fb1, fb2;
+#define EX_READ(F1_, F2_, slot_, cb_)                                                          \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[4 * 64];                                                                          \
+  }
+#define EX_MFMA1(F1_, F2_, qi_, P_)                                                            \
+  {                                                                                            \
+    P_ = mma16<true>(F2_, q1[qi_], P_);                                                        \
+    P_ = mma16<true>(F1_, q2[qi_], P_);                                                        \
+    P_ = mma16<true>(F1_, q1[qi_], P_);                                                        \
+  }
+#define EX_MFMA(F1_, F2_, s_, cb_)                                                             \
+  {                                                                                            \
+    EX_MFMA1(F1_, F2_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                      \
+    EX_MFMA1(F1_, F2_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                      \
+  }
+  EX_READ(fa1, fa2, 0, 0);
+  f32x4 part[8];
+  float dot_a = 0.f, dot_b = 0.f;
+  const int ncbA = a_out ? H * cb_per_head : 0;
+  for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {                  // chunk (cb, half, s) sits in ring slot s
+        EX_TLOAD((long)cb * 16 + half * 8 + s + 7);
+#pragma unroll
+        for (int cbp = 0; cbp < 2; ++cbp) {
+          EX_READ(fb1, fb2, s, 2 * cbp + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          EX_MFMA(fa1, fa2, s, 2 * cbp);
+          if (cbp == 0) EX_READ(fa1, fa2, s, 2)
+          else EX_READ(fa1, fa2, (s + 1) & 7, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          EX_MFMA(fb1, fb2, s, 2 * cbp + 1);
+        }
+        // At the end of k-step s chunk s + 2 must have landed (its fragments are read ahead during s + 1); it was
+        // issued five k-steps ago.  vmcnt retires IN ORDER and counts stores: everything younger than that chunk may
+        // stay in flight -- the five later chunks (10 loads) and, for s < 5, the eight Z stores of the previous
+        // slice's epilogue, which were issued after it.  With a 4-slot ring the first wait after an epilogue already
+        // had to drain the stores (a load issued after them was needed two k-steps later): the epilogue's write
+        // latency was paid in full on every slice.
+        if (s < 5) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      {
+        float sw, iw;
+        pow2_scale(wmax[cb], sw, iw);
+        const float ma = rs_a * iw, mb = rs_b * iw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { part[2 * i + 0] = part[2 * i + 0] * ma; part[2 * i + 1] = part[2 * i + 1] * mb; }
+      }
+      // ---- epilogue of the 64-column slice: z = part + Pi[dst]; store; logits ----
+      const int col0 = cb * 128 + half * 64 + 4 * kg;
+      const bool isA = cb < ncbA;
+      // all Pi loads of the slice before its first store: a load issued after a store cannot be waited for without
+      // draining that store (in-order vmcnt)
+      float4 pia4[4], pib4[4];
+#pragma unroll
+      for (int c16 = 0; c16 < 4; ++c16) {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        pia4[c16] = (ABL & 2) ? zero4 : *reinterpret_cast<const float4*>(pia + col0 + 16 * c16);
+        pib4[c16] = (ABL & 2) ? zero4 : *reinterpret_cast<const float4*>(pib + col0 + 16 * c16);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int c16 = 0; c16 < 4; ++c16) {
+        const int col = col0 + 16 * c16;
+        const float4 ia = pia4[c16], ib = pib4[c16];
+        const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
+        const float4 va = make_float4(pa[0] + ia.x, pa[1] + ia.y, pa[2] + ia.z, pa[3] + ia.w);
+        const float4 vb = make_float4(pb[0] + ib.x, pb[1] + ib.y, pb[2] + ib.z, pb[3] + ib.w);
+        if (row_a < E && (!(ABL & 1) || va.x == 1234.5f)) *reinterpret_cast<float4*>(za + col) = va;
+        if (row_b < E && (!(ABL & 1) || vb.x == 1234.5f)) *reinterpret_cast<float4*>(zb + col) = vb;
+        if (isA && !(ABL & 4)) {
+          const float4 w = *reinterpret_cast<const float4*>(wA + col);
+          dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
+                   (va.z > 0.f ? va.z : 0.01f * va.z) * w.z + (va.w > 0.f ? va.w : 0.01f * va.w) * w.w;
+          asm volatile("" : "+v"(dot_a));   // keep the two accumulations apart: see the note on packed math above
+          dot_b += (vb.x > 0.f ? vb.x : 0.01f * vb.x) * w.x + (vb.y > 0.f ? vb.y : 0.01f * vb.y) * w.y +
+                   (vb.z > 0.f ? vb.z : 0.01f * vb.z) * w.z + (vb.w > 0.f ? vb.w : 0.01f * vb.w) * w.w;
+          asm volatile("" : "+v"(dot_b));
+        }
+      }
+      if (isA && half == 1 && (cb + 1) % cb_per_head == 0) {
+        const int h = cb / cb_per_head;
+        float da = dot_a, db = dot_b;
+        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        if (kg == 0) {
+          const float bh = bA ? bA[h] : 0.f;
+          if (row_a < E) a_out[(long)row_a * H + h] = da + bh;
+          if (row_b < E) a_out[(long)row_b * H + h] = db + bh;
+        }
+        dot_a = 0.f; dot_b = 0.f;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef EX_TLOAD
+#undef EX_READ
+#undef EX_MFMA1
+#undef EX_MFMA
+}
+
+// planes of the two 128 x 128 blocks W_e[a], W_j[a] (element (k, c) = W[(128 a + c) * ldw + k]) under one scale
+__global__ __launch_bounds__(256) void prepare_W2_f16_kernel(const float* __restrict__ We, const float* __restrict__ Wj,
+                                                             long ldw, _Float16* __restrict__ dst,
+                                                             float* __restrict__ wmax) {
+  __shared__ float wm[4];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  float v[2][64];
+  float m = 0.f;
+#pragma unroll
+  for (int src = 0; src < 2; ++src)
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int i = r * 256 + tid, c = i >> 7, b = i & 127;      // k is the contiguous index of the source
+      v[src][r] = (src ? Wj : We)[((long)a * 128 + c) * ldw + b];
+      m = fmaxf(m, fabsf(v[src][r]));
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) wm[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  if (tid == 0) wmax[a] = m;
+  float st, it;
+  pow2_scale(m, st, it);
+#pragma unroll
+  for (int src = 0; src < 2; ++src)
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int i = r * 256 + tid, c = i >> 7, b = i & 127;
+      const float x = v[src][r] * st;
+      const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+      const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+      const int kh = 2 * src + (b >> 6), s2 = (b >> 5) & 1, kg = (b & 31) >> 3, j = b & 7;
+      const long blk = ((((long)a * 2 + half) * 4 + kh) * 2 + s2) * 2;
+      const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+      dst[(blk + 0) * 2048 + in] = h;
+      dst[(blk + 1) * 2048 + in] = l;
+    }
+}
+
+size_t edge_zx_wq_floats(int W2) { return (size_t)W2 * 256 + W2 / 128 + 64; }
+bool edge_zx_fast(int C, int Ce, int W2, int H, int Hd, long ld_add, long ldz, const void* e, const void* x,
+                  const void* Pi, const void* Z, const void* wA) {
+  static int off = -1;
+  if (off < 0) { const char* ev = getenv("CGAT_NO_EDGE_ZX"); off = (ev && ev[0] == '1') ? 1 : 0; }
+  return !off && bilinear_mode() == 2 && C == 128 && Ce == 128 && W2 % 128 == 0 && Hd % 128 == 0 && H * Hd * 2 == W2 &&
+         (ld_add % 4) == 0 && (ldz % 4) == 0 &&
+         ((((uintptr_t)e) | ((uintptr_t)x) | ((uintptr_t)Pi) | ((uintptr_t)Z) | ((uintptr_t)wA)) & 15) == 0;
+}
+// We / Wj: the edge_attr and x_j slices of the stacked first-layer weight (row stride ldw); Wq: edge_zx_wq_floats(W2)
+int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, long ldx, const float* We, const float* Wj,
+                   long ldw, float* Wq, int W2, const float* Pi, const int* dsti, const int* srci, long ld_add, float* Z,
+                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream) {
+  if (E <= 0) return CGAT_OK;
+  const int ncb = W2 / 128;
+  hipLaunchKernelGGL(prepare_W2_f16_kernel, dim3(ncb), dim3(256), 0, stream, We, Wj, ldw, (_Float16*)Wq,
+                     Wq + (size_t)ncb * 32768);
+  CGAT_LAUNCH_CHECK();
+  CGAT_PROF("edge_z", stream);
+#define EZX_GO(A_) hipLaunchKernelGGL(edge_zx_kernel<A_>, dim3(cdiv(E, 128)), dim3(256), 0, stream, e, lde, perm, x, ldx, (const uint4*)Wq, ncb, Pi, dsti, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
+  const char* abl = getenv("CGAT_EZX_ABL");   // dev knob, timing only
+  switch (abl ? atoi(abl) : 0) {
+    case 1: EZX_GO(1); break; case 2: EZX_GO(2); break; case 3: EZX_GO(3); break; case 7: EZX_GO(7); break;
+    default: EZX_GO(0); break;
+  }
+#undef EZX_GO
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz, const void* e, const void* Pi,
                  const void* Pj, const void* Z, const void* wA) {
   return bilinear_mode() != 0 && Ce == 128 && W2 % 128 == 0 && Hd % 128 == 0 && H * Hd * 2 == W2 && (lde % 4) == 0 &&

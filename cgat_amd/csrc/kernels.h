@@ -83,6 +83,13 @@ int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb,
 bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz, const void* e, const void* Pi,
                  const void* Pj, const void* Z, const void* wA);
 size_t edge_z_wq_floats(int W2);
+// per-edge launch with the x_j projection folded in (f16x3 mode, C == Ce == 128): edgez.hip edge_zx_kernel
+size_t edge_zx_wq_floats(int W2);
+bool edge_zx_fast(int C, int Ce, int W2, int H, int Hd, long ld_add, long ldz, const void* e, const void* x,
+                  const void* Pi, const void* Z, const void* wA);
+int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, long ldx, const float* We, const float* Wj,
+                   long ldw, float* Wq, int W2, const float* Pi, const int* dsti, const int* srci, long ld_add, float* Z,
+                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,

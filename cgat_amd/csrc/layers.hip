@@ -361,17 +361,24 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   float* Pi = c.take<float>((size_t)d.N * d.W2);
   float* Pj = c.take<float>((size_t)d.N * d.W2);
   float* a = c.take<float>((size_t)d.E * d.H);
-  float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
+  float* Wq = c.take<float>(edge_z_wq_floats(d.W2) > edge_zx_wq_floats(d.W2) ? edge_z_wq_floats(d.W2)
+                                                                              : edge_zx_wq_floats(d.W2));
   c.seal();
   AttnSaved sv = c.dry ? AttnSaved{} : attn_saved(saved, d);
+  // f16x3 mode at the benchmark widths: the x_j projection is folded into the per-edge kernel (edge_zx_kernel), so
+  // Pj is never formed
+  const bool zx = !c.dry && d.N > 0 &&
+                  edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Pi, sv.Z, p->A_out_w) &&
+                  edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Pi, Pj, Pi, bcat);
 
   CGAT_TRY(stack_in_weights(c, p, d, Wcat, bcat));
   // first conv layer split by operand: W_in [x_i;e;x_j] = W_i x_i + W_e e + W_j x_j
   if (!c.dry && d.N > 0 && edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Pi, Pj, Pi, bcat)) {
     RUN(edge_z_launch(x, d.C, nullptr, Wcat, d.D, Wq, d.W2, bcat, nullptr, nullptr, nullptr, 0, Pi, d.W2, d.N, nullptr,
                       nullptr, d.H, d.Hd, nullptr, c.s));
-    RUN(edge_z_launch(x, d.C, nullptr, Wcat + d.C + d.Ce, d.D, Wq, d.W2, nullptr, nullptr, nullptr, nullptr, 0, Pj, d.W2,
-                      d.N, nullptr, nullptr, d.H, d.Hd, nullptr, c.s));
+    if (!zx)
+      RUN(edge_z_launch(x, d.C, nullptr, Wcat + d.C + d.Ce, d.D, Wq, d.W2, nullptr, nullptr, nullptr, nullptr, 0, Pj, d.W2,
+                        d.N, nullptr, nullptr, d.H, d.Hd, nullptr, c.s));
   } else {
     GemmParams g = gemm_params(d.N, d.W2, d.C, x, d.C, Wcat, d.D, Pi, d.W2);
     g.bias = bcat;
@@ -383,7 +390,10 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   // and the attention logits a[t,h] = fc_out_A(leaky(zA)): one fused split-bf16 kernel at the benchmark widths,
   // the generic GEMM + row-dot otherwise (and in the f32 arithmetic mode)
   const bool fused_z = !c.dry && edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Pi, Pj, sv.Z, p->A_out_w);
-  if (fused_z) {
+  if (zx) {
+    RUN(edge_zx_launch(e, d.Ce, plan->dst_perm, x, d.C, Wcat + d.C, Wcat + d.C + d.Ce, d.D, Wq, d.W2, Pi, plan->dst_sorted,
+                       plan->src_sorted, d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
+  } else if (fused_z) {
     RUN(edge_z_launch(e, d.Ce, plan->dst_perm, Wcat + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted,
                       d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
   } else {
@@ -394,7 +404,7 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
     g.ld_add = d.W2;
     CGAT_TRY(c.gemm(g));
   }
-  if (!fused_z)
+  if (!fused_z && !zx)
     RUN(rowdot_launch(sv.Z, d.W2, CGAT_ACT_LEAKY, p->A_out_w, 0, nullptr, p->A_out_b, nullptr, d.E, d.H, d.Hd, a, c.s));
   RUN(seg_softmax_fwd_launch(a, nullptr, plan->dst_rowptr, d.N, d.H, 1e-16f, sv.alpha, sv.ssum, c.s));
   // S[n,h,:] = sum_{t -> n} alpha[t,h] leaky(zM[t,h,:])  -- fc_out of MH_M commutes with the weighted sum
