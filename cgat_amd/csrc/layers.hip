@@ -246,14 +246,29 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
         const float4 gsv = isA ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gSn + cc);
         const float* coef = isA ? ga : alpha;
         float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), ps = gi;
+        // Rows four at a time, the NEXT four loaded before this batch's gZ stores are issued: vmcnt retires in order
+        // and counts stores, so a load issued after a store cannot be waited for without draining that store -- with
+        // load / store / load / ... every batch paid the full write latency.
+        float4 zn[4];
+        float cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = r0 + u < r1 ? r0 + u : r1 - 1;
+          zn[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+          cn[u] = coef[(long)t * H + h];
+        }
         for (int tb = r0; tb < r1; tb += 4) {
           float4 zv[4];
           float cf[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int t = tb + u < r1 ? tb + u : r1 - 1;
-            zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
-            cf[u] = coef[(long)t * H + h];
+          for (int u = 0; u < 4; ++u) { zv[u] = zn[u]; cf[u] = cn[u]; }
+          if (tb + 4 < r1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = tb + 4 + u < r1 ? tb + 4 + u : r1 - 1;
+              zn[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+              cn[u] = coef[(long)t * H + h];
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
