@@ -392,7 +392,10 @@ def main():
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
         W2b = 2 * HEADS * 256 * 4
-        hbm_alg = {"edge_z": E * (2 * W2b + C_FEA * 4) + N * W2b,            # Z written, Pj gathered, e read, Pi rows once
+        # f16x3: the per-edge forward kernel computes the x_j projection itself (edge_zx_kernel): Z written, e and
+        # x[src] rows read, Pi rows once; other modes: Z written, Pj gathered (W2b per edge), e read, Pi rows once
+        ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2b if mode == "f16x3" else E * (2 * W2b + C_FEA * 4) + N * W2b
+        hbm_alg = {"edge_z": ez_bytes,
                    "edge_seg_bwd": E * 2 * W2b + N * (W2b + W2b // 2),       # Z read, gZ written, Gi written, gS read
                    "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
                    "edge_gw": E * (W2b + C_FEA * (4 if mode == "f16x3" else 6))}   # gZ read, fp16x2 / bf16x3 planes of e read
