@@ -367,8 +367,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
     for (int ch = 0; ch < 4; ++ch) {
       const int half = ch >> 1, c2 = ch & 1;
       if constexpr (!(ABL & 2)) {
-        if (ch == 0) RG_PLOAD(a + 2);
         RG_TLOAD((long)a * 4 + ch + 3);
+        if (ch == 0) RG_PLOAD(a + 2);          // AFTER the T loads: see the wait below
       }
       if (c2 == 0) {
 #pragma unroll
@@ -402,8 +402,11 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
             acc[2 * (4 * half + cb) + 1][t] = fmaf(pas_b, part[2 * cb + 1][t], acc[2 * (4 * half + cb) + 1][t]);
           }
       }
-      if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      // chunk i + 2 (issued one iteration ago) must have landed.  Younger than it: this iteration's T loads and, for
+      // ch < 2, the p load issued right behind the T loads of ch == 0 (needed two `a` later; issued BEFORE them, as it
+      // used to be, every ch == 0 wait drained it -- a 64-line strided load -- within one k-step)
+      if (ch < 2) wait_vmcnt<NP + 1>();
+      else wait_vmcnt<NP>();
       if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
@@ -604,8 +607,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {                // k-step (a, s) sits in ring slot s
-      if (s == 0) DU_PLOAD(a + 2);
       DU_TLOAD((long)a * 4 + s + 3);
+      if (s == 0) DU_PLOAD(a + 2);             // AFTER the T loads: see the wait below
 #pragma unroll
       for (int cbp = 0; cbp < 2; ++cbp) {
         DU_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
@@ -641,8 +644,15 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
           dvp[dv_b + a * dv_ld] = sgb * db;
         }
       }
-      if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      // chunk i + 2 (issued one iteration ago) must have landed; everything issued after it may stay in flight
+      // (in-order vmcnt, stores included): the previous `a`'s two dv stores + this step's T loads + the p load (s = 0),
+      // the p load + T loads (s = 1), T loads (s = 2), T loads + this `a`'s dv stores (s = 3).  With vmcnt(NP)
+      // everywhere the s = 3 wait, whose two youngest operations are the stores, drained the T loads issued a
+      // quarter of a microsecond earlier.
+      if (s == 0) wait_vmcnt<NP + 3>();
+      else if (s == 1) wait_vmcnt<NP + 1>();
+      else if (s == 2) wait_vmcnt<NP>();
+      else wait_vmcnt<NP + 2>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }

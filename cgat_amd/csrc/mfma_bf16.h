@@ -98,6 +98,12 @@ __device__ __forceinline__ void block_absmax_commit(float m, float* out) {
   }
 }
 
+// counted wait on the vector-memory counter.  vmcnt retires IN ORDER and counts stores as well as loads: vmcnt(N)
+// returns when everything except the N youngest operations has completed, so N must cover every operation issued
+// AFTER the one being waited for, and an operation that need not be complete yet must be younger than it.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // global address = scalar base + per-lane 32-bit byte offset; LDS address = lds_addr + 16 (4) * lane
 __device__ __forceinline__ void glds_b128(const void* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
