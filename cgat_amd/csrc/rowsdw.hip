@@ -9,6 +9,9 @@
 // fp32 products.  Replaces, per dense layer, a split-K pass of the generic GEMM engine (67 us), its slab reduction
 // (12 us) and a separate column-sum pass over G (11 us).
 //
+// Tried and dropped (round 1): staging each 32-row batch once per workgroup through a double-buffered LDS image
+// (G as four component planes, X as float4 rows; no redundant loads) -- 48 us per launch against 42 us for this form.
+//
 // Workgroup = 8 waves = 2 row halves x 4 column components: wave (h, w) accumulates
 //     D_j[m][n] = sum_rows G[row][4 m + w] * X[row][4 n + j]        j = 0..3
 // (the lane's float4 of X gives the B operands of four interleaved column blocks), so a lane's four accumulators at
