@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (EdgeHiddenFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+from .ops import (EdgeHiddenFn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -187,11 +187,10 @@ class GATConvNodes(nn.Module):
         hid = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                             # [E, 2*H*Hd], sorted slots
         E = hid.shape[0]
 
-        def second(net, off):
-            return torch.stack([linear(hid[:, off + h * Hd:off + (h + 1) * Hd], net.fc_out.weight[h * Co:(h + 1) * Co],
-                                       net.fc_out.bias[h * Co:(h + 1) * Co]) for h in range(H)], dim=1)   # [E,H,Co]
-        alpha = SegmentSoftmaxFn.apply(second(a, 0).reshape(E, -1), None, plan.dst_rowptr, 1e-16)
-        msg = second(m, H * Hd).reshape(E, -1) * alpha
+        # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
+        sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co)
+        alpha = SegmentSoftmaxFn.apply(sa.reshape(E, -1), None, plan.dst_rowptr, 1e-16)
+        msg = sm.reshape(E, -1) * alpha
         agg = SegmentSumFn.apply(msg, plan.dst_rowptr, plan.dst_sorted.long())
         return agg.reshape(plan.N, H, Co).mean(dim=1)
 
