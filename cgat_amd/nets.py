@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (EdgeHiddenFn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+from .ops import (EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -46,9 +46,8 @@ class MultiHeadNetwork(nn.Module):
         fea = fea.reshape(-1, self.input_dim)
         H, Hd, O = self.nb_heads, self.hidden_layer_dim, self.output_dim
         hid = linear(fea, self.fc_in.weight, self.fc_in.bias, _lib.ACT_LEAKY)            # [M, H*Hd]
-        outs = [linear(hid[:, h * Hd:(h + 1) * Hd], self.fc_out.weight[h * O:(h + 1) * O],
-                       self.fc_out.bias[h * O:(h + 1) * O]) for h in range(H)]
-        return torch.stack(outs, dim=1)                                                   # [M, H, O]
+        # all heads' second layers as one autograd node (no per-slice zero-filled gradients of hid)
+        return HeadsLinear1Fn.apply(hid, self.fc_out.weight, self.fc_out.bias, H, Hd, O)  # [M, H, O]
 
     def __repr__(self):
         return self.__class__.__name__

@@ -432,6 +432,44 @@ class LinearFn(torch.autograd.Function):
         return g_x, (None if g_w is None else g_w.reshape(ctx.wshape)), g_b, None
 
 
+def _heads_forward(hid, nets, H, Hd, Co):
+    """nets: list of (weight [H*Co, Hd], bias [H*Co] or None); network i reads columns [i*H*Hd, (i+1)*H*Hd) of hid."""
+    E, W2 = hid.shape
+    outs = [torch.empty(E, H * Co, dtype=torch.float32, device=hid.device) for _ in nets]
+    ws = workspace(lib.cgat_linear_forward_workspace_bytes(E, Hd, Co), hid.device)
+    with torch.cuda.device(hid.device):
+        for net, (w, b) in enumerate(nets):
+            for h in range(H):
+                xs = hid[:, (net * H + h) * Hd:(net * H + h + 1) * Hd]
+                check(lib.cgat_linear_forward(_ptr(xs), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
+                                              None if b is None else _ptr(b[h * Co:(h + 1) * Co]),
+                                              _ptr(outs[net][:, h * Co:(h + 1) * Co]), H * Co, E, Hd, Co, _lib.ACT_NONE,
+                                              _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
+    return outs
+
+
+def _heads_backward(hid, weights, has_b, grads, H, Hd, Co, need_hid):
+    E, W2 = hid.shape
+    dev = hid.device
+    gs = [_f32c(g.reshape(E, H * Co)) for g in grads]
+    g_hid = torch.empty_like(hid) if need_hid else None
+    g_w = [torch.empty(H * Co, Hd, dtype=torch.float32, device=dev) for _ in weights]
+    g_b = [torch.empty(H * Co, dtype=torch.float32, device=dev) if hb else None for hb in has_b]
+    ws = workspace(lib.cgat_linear_backward_workspace_bytes(E, Hd, Co), dev)
+    with torch.cuda.device(dev):
+        for net, w in enumerate(weights):
+            for h in range(H):
+                col = (net * H + h) * Hd
+                check(lib.cgat_linear_backward(_ptr(hid[:, col:col + Hd]), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd, None, Co,
+                                               _ptr(gs[net][:, h * Co:(h + 1) * Co]), H * Co, None,
+                                               None if g_hid is None else _ptr(g_hid[:, col:col + Hd]), W2, 0,
+                                               _ptr(g_w[net][h * Co:(h + 1) * Co]), Hd,
+                                               None if g_b[net] is None else _ptr(g_b[net][h * Co:(h + 1) * Co]),
+                                               E, Hd, Co, _lib.ACT_NONE, _ptr(ws), ws.numel(), _stream()),
+                      "cgat_linear_backward")
+    return g_hid, g_w, g_b
+
+
 class HeadsLinearFn(torch.autograd.Function):
     """Second layers of two multi-head networks on one hidden matrix (vector attention, reference CGAT.py:97-98,
     103-109 applied per head): out_A[:, h, :] = hid[:, h*Hd:(h+1)*Hd] W_A[h]^T + b_A[h], out_M the same on the second
@@ -443,19 +481,10 @@ class HeadsLinearFn(torch.autograd.Function):
     def forward(ctx, hid, wa, ba, wm, bm, H, Hd, Co):
         _require_gpu(hid, wa, wm)
         hid = _f32c(hid)
-        E, W2 = hid.shape
+        E = hid.shape[0]
         ws_ = [_f32c(w.detach().reshape(H * Co, Hd)) for w in (wa, wm)]
         bs_ = [None if b is None else _f32c(b.detach()) for b in (ba, bm)]
-        outs = [torch.empty(E, H * Co, dtype=torch.float32, device=hid.device) for _ in range(2)]
-        ws = workspace(lib.cgat_linear_forward_workspace_bytes(E, Hd, Co), hid.device)
-        with torch.cuda.device(hid.device):
-            for net in range(2):
-                for h in range(H):
-                    xs = hid[:, (net * H + h) * Hd:(net * H + h + 1) * Hd]
-                    check(lib.cgat_linear_forward(_ptr(xs), W2, _ptr(ws_[net][h * Co:(h + 1) * Co]), Hd,
-                                                  None if bs_[net] is None else _ptr(bs_[net][h * Co:(h + 1) * Co]),
-                                                  _ptr(outs[net][:, h * Co:(h + 1) * Co]), H * Co, E, Hd, Co, _lib.ACT_NONE,
-                                                  _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
+        outs = _heads_forward(hid, list(zip(ws_, bs_)), H, Hd, Co)
         ctx.dims = (H, Hd, Co)
         ctx.shapes = (wa.shape, wm.shape)
         ctx.has_b = (ba is not None, bm is not None)
@@ -466,25 +495,33 @@ class HeadsLinearFn(torch.autograd.Function):
     def backward(ctx, g_a, g_m):
         hid, w0, w1 = ctx.saved_tensors
         H, Hd, Co = ctx.dims
-        E, W2 = hid.shape
-        dev = hid.device
-        gs = [_f32c(g.reshape(E, H * Co)) for g in (g_a, g_m)]
-        g_hid = torch.empty_like(hid) if ctx.needs_input_grad[0] else None
-        g_w = [torch.empty(H * Co, Hd, dtype=torch.float32, device=dev) for _ in range(2)]
-        g_b = [torch.empty(H * Co, dtype=torch.float32, device=dev) if ctx.has_b[n] else None for n in range(2)]
-        ws = workspace(lib.cgat_linear_backward_workspace_bytes(E, Hd, Co), dev)
-        with torch.cuda.device(dev):
-            for net, w in enumerate((w0, w1)):
-                for h in range(H):
-                    col = (net * H + h) * Hd
-                    check(lib.cgat_linear_backward(_ptr(hid[:, col:col + Hd]), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd, None, Co,
-                                                   _ptr(gs[net][:, h * Co:(h + 1) * Co]), H * Co, None,
-                                                   None if g_hid is None else _ptr(g_hid[:, col:col + Hd]), W2, 0,
-                                                   _ptr(g_w[net][h * Co:(h + 1) * Co]), Hd,
-                                                   None if g_b[net] is None else _ptr(g_b[net][h * Co:(h + 1) * Co]),
-                                                   E, Hd, Co, _lib.ACT_NONE, _ptr(ws), ws.numel(), _stream()),
-                          "cgat_linear_backward")
+        g_hid, g_w, g_b = _heads_backward(hid, (w0, w1), ctx.has_b, (g_a, g_m), H, Hd, Co, ctx.needs_input_grad[0])
         return (g_hid, g_w[0].reshape(ctx.shapes[0]), g_b[0], g_w[1].reshape(ctx.shapes[1]), g_b[1], None, None, None)
+
+
+class HeadsLinear1Fn(torch.autograd.Function):
+    """The same for one network: out[:, h, :] = hid[:, h*Hd:(h+1)*Hd] W[h]^T + b[h] (MultiHeadNetwork.fc_out)."""
+
+    @staticmethod
+    def forward(ctx, hid, w, b, H, Hd, Co):
+        _require_gpu(hid, w)
+        hid = _f32c(hid)
+        E = hid.shape[0]
+        w2 = _f32c(w.detach().reshape(H * Co, Hd))
+        bb = None if b is None else _f32c(b.detach())
+        out = _heads_forward(hid, [(w2, bb)], H, Hd, Co)[0]
+        ctx.dims = (H, Hd, Co)
+        ctx.wshape = w.shape
+        ctx.has_b = b is not None
+        ctx.save_for_backward(hid, w2)
+        return out.reshape(E, H, Co)
+
+    @staticmethod
+    def backward(ctx, g):
+        hid, w2 = ctx.saved_tensors
+        H, Hd, Co = ctx.dims
+        g_hid, g_w, g_b = _heads_backward(hid, (w2,), (ctx.has_b,), (g,), H, Hd, Co, ctx.needs_input_grad[0])
+        return g_hid, g_w[0].reshape(ctx.wshape), g_b[0], None, None, None
 
 
 def linear(x, w, b=None, act=_lib.ACT_NONE):
