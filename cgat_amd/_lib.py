@@ -128,6 +128,8 @@ PROTOTYPES = {
                                   C.c_int64, vp]),
     "cgat_lamb_step": (C.c_int, [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, vp, vp]),
+    "cgat_embedding_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cgat_embedding_backward": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
     "cgat_robust_loss": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "cgat_collate_batch": (C.c_int, [C.POINTER(PackedDatasetStruct), vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64,
                                      C.POINTER(CollatedStruct), vp]),

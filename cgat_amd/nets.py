@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear,
+from .ops import (EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -303,7 +303,7 @@ class CGAtNet(nn.Module):
         G = getattr(batch, "num_graphs", None)
         if G is None:
             G = int(crystal_elem_idx[-1]) + 1                                   # one host sync per batch
-        edge_attr = self.nbr_embedding(batch.edge_attr)                         # [E] int64 -> [E,Ce]
+        edge_attr = small_embedding(batch.edge_attr, self.nbr_embedding.weight)  # [E] int64 -> [E,Ce]
         elem_fea = linear(batch.x, self.embedding.weight, None)                 # [N,200] -> [N,C]
         elem_fea_0 = elem_fea
         edge_attr_0 = edge_attr

@@ -524,6 +524,40 @@ class HeadsLinear1Fn(torch.autograd.Function):
         return g_hid, g_w[0].reshape(ctx.wshape), g_b[0], None, None, None
 
 
+class SmallEmbeddingFn(torch.autograd.Function):
+    """table[idx] for a small table looked up once per edge (nn.Embedding(neighbor_number + 1, Ce) in CGAtNet): the
+    forward is a row gather, the backward a deterministic per-class row sum (cgat_embedding_backward) instead of
+    torch's sort + atomic scatter."""
+
+    @staticmethod
+    def forward(ctx, idx, table):
+        _require_gpu(idx, table)
+        ctx.save_for_backward(idx)
+        ctx.tshape = table.shape
+        return table.detach().index_select(0, idx.reshape(-1)).reshape(*idx.shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        K, Cc = ctx.tshape
+        g2 = _f32c(g.reshape(-1, Cc))
+        ii = idx.reshape(-1).contiguous()
+        out = torch.empty(K, Cc, dtype=torch.float32, device=g2.device)
+        ws = workspace(lib.cgat_embedding_backward_workspace_bytes(K, Cc), g2.device)
+        with torch.cuda.device(g2.device):
+            check(lib.cgat_embedding_backward(_ptr(g2), Cc, _ptr(ii), g2.shape[0], K, Cc, _ptr(out), _ptr(ws), ws.numel(),
+                                              _stream()), "cgat_embedding_backward")
+        return None, out
+
+
+def small_embedding(idx, table):
+    """nn.Embedding lookup with the deterministic backward when the table is small enough, F.embedding otherwise."""
+    if (table.is_cuda and idx.dtype == torch.int64 and table.dtype == torch.float32 and table.shape[1] <= 128 and
+            table.shape[0] * table.shape[1] <= 8192):
+        return SmallEmbeddingFn.apply(idx, table)
+    return torch.nn.functional.embedding(idx, table)
+
+
 def linear(x, w, b=None, act=_lib.ACT_NONE):
     lead = x.shape[:-1]
     y = LinearFn.apply(x.reshape(-1, x.shape[-1]), w, b, act)

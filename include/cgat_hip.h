@@ -94,6 +94,13 @@ int cgat_collate_batch(const cgat_packed_dataset* ds, const int32_t* ids, const 
                        const int32_t* comp_off, const int32_t* cedge_off, int32_t B, int64_t E_total, int64_t Ec_total,
                        const cgat_collated* out, void* stream);
 
+/* Gradient of a small embedding table looked up once per edge (reference CGAT/CGAT.py: nbr_embedding =
+ * nn.Embedding(neighbor_number + 1, nbr_embedding_size), CGAtNet.forward): g_table[k, :] = sum_{t: idx[t] == k} g[t, :].
+ * Deterministic (no atomics).  idx: int64 [rows]; C <= 128, K * C <= 8192. */
+size_t cgat_embedding_backward_workspace_bytes(int32_t K, int32_t C);
+int cgat_embedding_backward(const float* g, int64_t ldg, const int64_t* idx, int64_t rows, int32_t K, int32_t C,
+                            float* g_table, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- fused optimiser steps and robust losses (after the hot path) ------------
  * One launch over all parameter tensors.  `table[n_tensors]` (device) holds the tensors; the chunk list cuts them
  * into pieces of cgat_mt_chunk_elems() elements: chunk c covers table[chunk_tensor[c]] from element chunk_off[c];

@@ -367,3 +367,23 @@ def test_ring_kernels_race_screen(env, rows):
         else:
             for a, b in zip(first, cur):
                 assert torch.equal(a, b), rep
+
+
+@pytest.mark.parametrize("rows,K,C", [(0, 13, 128), (1, 13, 128), (1000, 13, 128), (1000080, 13, 128), (5000, 64, 128), (777, 5, 32)])
+def test_small_embedding_backward(env, rows, K, C):
+    """Deterministic gradient of a small embedding table (nbr_embedding, looked up once per edge) vs an fp64
+    index_add, and bitwise repeatability."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(rows + K)
+    idx = torch.randint(0, K, (rows,), generator=g).to(dev)
+    table = torch.randn(K, C, generator=g).to(dev).requires_grad_(True)
+    cot = torch.randn(rows, C, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        y = ops.small_embedding(idx, table)
+        assert torch.equal(y, table.detach()[idx])
+        (gt,) = torch.autograd.grad((y * cot).sum(), [table])
+        outs.append(gt)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, idx, cot.double())
+    assert rel(outs[0], ref) <= TOL if rows else float(outs[0].abs().max()) == 0.0
