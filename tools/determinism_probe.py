@@ -60,10 +60,13 @@ Z, al = parts(saved)
 wA = W[2].reshape(3, 256); bA = W[3].reshape(3)
 zl = torch.nn.functional.leaky_relu(Z[:, :768].reshape(E, 3, 256), 0.01)
 a_ref = (zl * wA[None]).sum(-1) + bA[None]
-dst = plan.dst_sorted if hasattr(plan, "dst_sorted") else None
-# softmax over destination segments: edges are destination-sorted with 12 per node in this synthetic batch
-ar = a_ref.view(N, 12, 3)
-al_ref = torch.softmax(ar, dim=1).reshape(E, 3)
+# softmax over destination segments with the plan's CSR (in-degrees vary in the synthetic batch)
+rp = plan.dst_rowptr.long()
+seg = torch.repeat_interleave(torch.arange(N, device=dev), rp[1:] - rp[:-1])
+mx = torch.full((N, 3), -1e30, device=dev).scatter_reduce(0, seg[:, None].expand(E, 3), a_ref, "amax")
+ex = (a_ref - mx[seg]).exp()
+sm = torch.zeros(N, 3, device=dev).index_add_(0, seg, ex)
+al_ref = ex / (sm[seg] + 1e-16)
 bad = ((al - al_ref).abs() > 1e-5).any(1)
 idx = torch.nonzero(bad).flatten()
 print("rows with wrong alpha:", int(bad.sum()), "of", E)
