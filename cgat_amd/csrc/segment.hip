@@ -114,6 +114,7 @@ __global__ void seg_wsum_kernel(const float* __restrict__ x, long ldx, const int
 // Same sum, four consecutive features per thread (16-byte loads) and the rows of a segment fetched four at a time
 // before they are added in CSR order: the loads of a batch are independent, so a 12-row segment costs three memory
 // round trips instead of twelve.  Needs F % 4 == 0, fw % 4 == 0, 16-byte aligned rows.
+template <int SEG_U>
 __global__ __launch_bounds__(256) void seg_wsum_vec_kernel(const float* __restrict__ x, long ldx,
                                                            const int* __restrict__ ridx, const float* __restrict__ w,
                                                            int wF, int fw, const int* __restrict__ rowptr, int F, int act,
@@ -125,18 +126,21 @@ __global__ __launch_bounds__(256) void seg_wsum_vec_kernel(const float* __restri
     const float* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
     const long pitch = xblock ? 128 : ldx;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0; r < r1; r += 4) {
-      float4 v[4];
-      float wv[4];
+    // SEG_U rows per batch: a workgroup's time is (number of batches) x (memory round trip), not bytes.  For rows in
+    // CSR order (the forward's weighted sum of messages) 12 rows per trip took the 3 GB pass from 0.98 to 0.68 ms;
+    // for gathered rows (the source-side sum of gZ) 12 in flight per thread is slower than 4 (1.30 vs 0.98 ms)
+    for (int r = r0; r < r1; r += SEG_U) {
+      float4 v[SEG_U];
+      float wv[SEG_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SEG_U; ++u) {
         const int rr = r + u < r1 ? r + u : r1 - 1;
         const long row = ridx ? (long)ridx[rr] : (long)rr;
         v[u] = *reinterpret_cast<const float4*>(xb + row * pitch);
         wv[u] = w ? w[(long)rr * wF + wf] : 1.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SEG_U; ++u) {
         if (r + u < r1) {
           acc.x += act_f(v[u].x, act) * wv[u];
           acc.y += act_f(v[u].y, act) * wv[u];
@@ -157,8 +161,12 @@ int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, i
   if (vec) {
     int threads = F >= 1024 ? 256 : (F >= 512 ? 192 : (F >= 256 ? 64 : 64));
     if (F / 4 < threads) threads = ((F / 4 + 63) / 64) * 64;
-    hipLaunchKernelGGL(seg_wsum_vec_kernel, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out,
-                       ldo, xblock);
+    if (ridx)
+      hipLaunchKernelGGL(seg_wsum_vec_kernel<4>, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out,
+                         ldo, xblock);
+    else
+      hipLaunchKernelGGL(seg_wsum_vec_kernel<12>, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out,
+                         ldo, xblock);
     CGAT_LAUNCH_CHECK();
     return CGAT_OK;
   }
