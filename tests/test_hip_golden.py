@@ -171,6 +171,25 @@ def test_ragged_graphs_vs_oracle():
                          lambda: O.GATConvNodes(64, 64, 32, 5, concat=True), inputs, call)
 
 
+def test_ragged_graphs_fast_widths_vs_oracle():
+    """Ragged crystals (2..33 atoms, 7 neighbours) at the BENCHMARK widths (C = Ce = 128, H = 3, Hd = 256): E and N
+    are multiples of neither 128 nor 256 nor 8, so every tiled kernel of the default path (edge_zx, edge_seg_bwd,
+    edge_ge / edge_gw with their fp16 scales, the contraction kernels, rows_dw128) runs with partial last tiles."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    rs = np.random.RandomState(21)
+    sizes = rs.randint(2, 34, size=41).tolist()
+    b, _ = recipe.build_graphs(sizes, K=7, species_per_graph=rs.randint(1, 5, size=41).tolist(), seed=22)
+    g = torch.Generator().manual_seed(15)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    assert E % 128 != 0 and N % 8 != 0
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True),
+                         lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
+
+
 def test_full_stack_vs_oracle_random_init():
     """Config 3 shape (msg_heads=3, 4 layers, 200-d embeddings) on 40 crystals, random init."""
     import cgat_amd as P
