@@ -387,3 +387,49 @@ def test_small_embedding_backward(env, rows, K, C):
     assert torch.equal(outs[0], outs[1])
     ref = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, idx, cot.double())
     assert rel(outs[0], ref) <= TOL if rows else float(outs[0].abs().max()) == 0.0
+
+
+def test_f16x3_row_and_tensor_scales(env):
+    """The fp16-split arithmetic far from unit scale: rows spanning 1e-6 .. 1e4 (per-row scales: the error is held PER
+    ROW, relative to that row), operands of 3e-4 / 2e3 / 1e-5 in the weight-gradient contraction (per-tensor scales of
+    the k-indexed operands and of their product) and a tiny weight tensor; against fp64, same 2e-5 as at unit scale."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode("f16x3")
+    try:
+        W, rows = 128, 4099
+        g = torch.Generator().manual_seed(99)
+        p, q, z = (torch.randn(rows, W, generator=g).to(dev) for _ in range(3))
+        T = (torch.randn(W, W, W, generator=g) / W).to(dev) * 1e-3
+        scale = torch.logspace(-6, 4, rows).to(dev)[:, None]
+        qs = q * scale
+        # forward contraction, rows of very different magnitude
+        out = torch.empty(rows, W, device=dev)
+        ws = torch.empty(max(_lib.lib.cgat_bilinear_rows_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, qs.data_ptr(), W, T.data_ptr(), None, W, out.data_ptr(), W,
+                                               rows, W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
+        ref = torch.einsum("na,nb,abc->nc", p.double(), qs.double(), T.double())
+        assert float(((out.double() - ref).abs().amax(1) / ref.abs().amax(1)).max()) <= TOL
+        # fused backward pair with the same rows as the gradient operand
+        o1, o2 = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
+        ws2 = torch.empty(max(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), 256), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, qs.data_ptr(), W, z.data_ptr(), W, T.data_ptr(), None, W,
+                                               o1.data_ptr(), W, None, W, o2.data_ptr(), W, rows, ws2.data_ptr(), ws2.numel(),
+                                               None), "bilinear_dual")
+        M = torch.einsum("nb,abc->nac", qs.double(), T.double())
+        r1, r2 = torch.einsum("na,nac->nc", p.double(), M), torch.einsum("nc,nac->na", z.double(), M)
+        assert float(((o1.double() - r1).abs().amax(1) / r1.abs().amax(1)).max()) <= TOL
+        assert float(((o2.double() - r2).abs().amax(1) / r2.abs().amax(1)).max()) <= TOL
+        # weight gradient: every operand at its own scale
+        pp, qq, rr = p * 3e-4, q * 2e3, z * 1e-5
+        wout = torch.empty(W, W, W, device=dev)
+        ws3 = torch.empty(max(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.cgat_bilinear_wgrad(pp.data_ptr(), W, qq.data_ptr(), W, rr.data_ptr(), W, wout.data_ptr(), rows, W,
+                                                W, W, ws3.data_ptr(), ws3.numel(), None), "bilinear_wgrad")
+        assert rel(wout, torch.einsum("na,nb,nc->abc", pp.double(), qq.double(), rr.double())) <= TOL
+        # dense layer: scaled rows, tiny weights (per-row scale in the kernel, per-block scale of the weight)
+        w = (torch.randn(W, W, generator=g) / W ** 0.5).to(dev) * 1e-4
+        y = ops.linear(qs, w, None, _lib.ACT_NONE)
+        refy = qs.double() @ w.double().t()
+        assert float(((y.double() - refy).abs().amax(1) / refy.abs().amax(1)).max()) <= TOL
+    finally:
+        ops.set_bilinear_mode(ops.DEFAULT_MODE)
