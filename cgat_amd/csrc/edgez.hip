@@ -431,8 +431,11 @@ __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
         const float4 va = make_float4(pa[0] + ia.x, pa[1] + ia.y, pa[2] + ia.z, pa[3] + ia.w);
         const float4 vb = make_float4(pb[0] + ib.x, pb[1] + ib.y, pb[2] + ib.z, pb[3] + ib.w);
-        if (row_a < E && (!(ABL & 1) || va.x == 1234.5f)) *reinterpret_cast<float4*>(za + col) = va;
-        if (row_b < E && (!(ABL & 1) || vb.x == 1234.5f)) *reinterpret_cast<float4*>(zb + col) = vb;
+        // no `row < E` guard: the ring's vmcnt allowances count exactly eight stores per epilogue, and a wave whose
+        // second row block lies past the end would skip four of them (lanes past the end hold the clamped row E - 1
+        // and rewrite it with identical values)
+        if (!(ABL & 1) || va.x == 1234.5f) *reinterpret_cast<float4*>(za + col) = va;
+        if (!(ABL & 1) || vb.x == 1234.5f) *reinterpret_cast<float4*>(zb + col) = vb;
         if (isA && !(ABL & 4)) {
           const float4 w = *reinterpret_cast<const float4*>(wA + col);
           dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
