@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
   constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
   constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
-  __shared__ uint4 smem[4 * CH16];
+  // DEEP (the per-edge launch in the fp16 form): 8 ring slots, vmcnt allowances that let the epilogue's stores stay
+  // in flight, all gathers of a slice before its first store, unconditional stores (see edge_zx_kernel's header)
+  constexpr bool DEEP = F16 && ADDS;
+  constexpr int RING = DEEP ? 8 : 4;
+  __shared__ uint4 smem[RING * CH16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
   const int row_w = blockIdx.x * 128 + wave * 32;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   {                                                                                            \
     const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
     const uint4* tb = Wq + gi * CH16;                                                          \
-    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    const unsigned dst = wave_t + (unsigned)((gi_) & (RING - 1)) * (CH16 * 16);                \
     glds_b128(tb, t_off, dst);                                                                 \
     glds_b128(tb + 256, t_off, dst + 4096);                                                    \
     if (NP == 3) glds_b128(tb + 512, t_off, dst + 8192);                                       \
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   EZ_TLOAD(0l);
   EZ_TLOAD(1l);
   EZ_TLOAD(2l);
+  if constexpr (DEEP) { EZ_TLOAD(3l); EZ_TLOAD(4l); EZ_TLOAD(5l); EZ_TLOAD(6l); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -159,19 +164,26 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {                  // chunk (cb, half, s) sits in ring slot s
-        EZ_TLOAD((long)cb * 8 + half * 4 + s + 3);
+      for (int s = 0; s < 4; ++s) {                  // chunk (cb, half, s) sits in ring slot (4 half + s) % RING
+        constexpr int SM = RING - 1;
+        const int slot = (half * 4 + s) & SM;
+        EZ_TLOAD((long)cb * 8 + half * 4 + s + RING - 1);
 #pragma unroll
         for (int cbp = 0; cbp < 2; ++cbp) {
-          EZ_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
+          EZ_READ(fb1, fb2, fb3, slot, 2 * cbp + 1);
           __builtin_amdgcn_sched_barrier(0);
           EZ_MFMA(fa1, fa2, fa3, s, 2 * cbp);
-          if (cbp == 0) EZ_READ(fa1, fa2, fa3, s, 2)
-          else EZ_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
+          if (cbp == 0) EZ_READ(fa1, fa2, fa3, slot, 2)
+          else EZ_READ(fa1, fa2, fa3, (slot + 1) & SM, 0);
           __builtin_amdgcn_sched_barrier(0);
           EZ_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
         }
-        if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (DEEP) {
+          // chunk i + 2 was issued five iterations ago; younger than it: five chunks (10 loads), the eight stores
+          // of the epilogue that preceded this slice and, for s == 0, also those of the slice before
+          if (s == 0) wait_vmcnt<26>();
+          else wait_vmcnt<18>();
+        } else if constexpr (F16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -186,14 +198,25 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
       // ---- epilogue of the 64-column slice: z = part + Pi[dst] + Pj[src]; store; logits ----
       const int col0 = cb * 128 + half * 64 + 4 * kg;
       const bool isA = cb < ncbA;
+      float4 hia[DEEP ? 4 : 1], hja[DEEP ? 4 : 1], hib[DEEP ? 4 : 1], hjb[DEEP ? 4 : 1];
+      if constexpr (DEEP) {                          // every gather of the slice before its first store
+#pragma unroll
+        for (int c16 = 0; c16 < 4; ++c16) {
+          hia[c16] = *reinterpret_cast<const float4*>(pia + col0 + 16 * c16);
+          hja[c16] = *reinterpret_cast<const float4*>(pja + col0 + 16 * c16);
+          hib[c16] = *reinterpret_cast<const float4*>(pib + col0 + 16 * c16);
+          hjb[c16] = *reinterpret_cast<const float4*>(pjb + col0 + 16 * c16);
+        }
+        asm volatile("" ::: "memory");
+      }
 #pragma unroll
       for (int c16 = 0; c16 < 4; ++c16) {
         const int col = col0 + 16 * c16;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 ia = (ADDS || pia) ? *reinterpret_cast<const float4*>(pia + col) : zero4;
-        const float4 ja = ADDS ? *reinterpret_cast<const float4*>(pja + col) : zero4;
-        const float4 ib = ADDS ? *reinterpret_cast<const float4*>(pib + col) : ia;
-        const float4 jb = ADDS ? *reinterpret_cast<const float4*>(pjb + col) : zero4;
+        const float4 ia = DEEP ? hia[DEEP ? c16 : 0] : ((ADDS || pia) ? *reinterpret_cast<const float4*>(pia + col) : zero4);
+        const float4 ja = DEEP ? hja[DEEP ? c16 : 0] : (ADDS ? *reinterpret_cast<const float4*>(pja + col) : zero4);
+        const float4 ib = DEEP ? hib[DEEP ? c16 : 0] : (ADDS ? *reinterpret_cast<const float4*>(pib + col) : ia);
+        const float4 jb = DEEP ? hjb[DEEP ? c16 : 0] : (ADDS ? *reinterpret_cast<const float4*>(pjb + col) : zero4);
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
         float4 va = make_float4(pa[0] + ia.x + ja.x, pa[1] + ia.y + ja.y, pa[2] + ia.z + ja.z, pa[3] + ia.w + ja.w);
         float4 vb = make_float4(pb[0] + ib.x + jb.x, pb[1] + ib.y + jb.y, pb[2] + ib.z + jb.z, pb[3] + ib.w + jb.w);
@@ -213,8 +236,9 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
             if (row_b < E) { const float4 u = *reinterpret_cast<const float4*>(zb + col); vb.x += u.x; vb.y += u.y; vb.z += u.z; vb.w += u.w; }
           }
         }
-        if (row_a < E) *reinterpret_cast<float4*>(za + col) = va;
-        if (row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
+        // DEEP: unconditional (the allowances count eight stores; clamped rows rewrite identical values)
+        if (DEEP || row_a < E) *reinterpret_cast<float4*>(za + col) = va;
+        if (DEEP || row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
         if (isA) {
           const float4 w = *reinterpret_cast<const float4*>(wA + col);
           dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
