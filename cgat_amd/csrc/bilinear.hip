@@ -1579,6 +1579,352 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// f16x3 weight gradient, BATCHED over predicted layers and software-pipelined (round 2).
+//
+// Same arithmetic and data layout as bilinear_wgrad128_bf16_kernel<2> above (pT, qT transposes, Rq = two fp16 planes of
+// 2^k r in B-fragment order, products p*q split on the fly, 512-row partial sums with alternating sign), two changes:
+//  * one launch covers every (layer, row split, a pair) unit: the four predicted layers of a hypernetwork give
+//    4 x 64 = 256 units = one workgroup per CU with NO row split, so the slabs, their summation pass and three of
+//    the four launches disappear (the per-layer launches of round 1 had to split the rows four ways to fill the chip,
+//    or ran on half of it beside another stream).  A workgroup loops over units when the grid is smaller.
+//  * the loop is a software pipeline in source order, pinned with sched_barrier: the round-1 kernel ran, per 16-row
+//    step and wave, [4 LDS reads -> 24 VALU of product split -> 12 MFMAs] back to back, and because the two waves of
+//    a SIMD leave the chunk barrier together they both sat in the read + split phase at the same time with the matrix
+//    pipe idle (measured 0.50 of the MFMA issue rate).  Here the A fragments of step s+1 are produced in the issue
+//    slots an MFMA leaves free (it holds the vector port for 8 of its 32 cycles) while the MFMAs of step s run, the
+//    B fragments are double-buffered one column block ahead, and a three-slot LDS ring lets the fragments of the next
+//    chunk be fetched BEFORE the chunk barrier, so no wave starts a chunk with an empty matrix pipe.
+// ---------------------------------------------------------------------------------------
+#define WGB_MAX 8
+struct WgradBatchDesc {
+  float* out[WGB_MAX];   // final [NA][128][128] outputs (splits == 1)
+  float* slab;           // [layer][split][NA][128][128] partial sums (splits > 1)
+  long sT, sR;           // per-layer strides: floats of pT / qT, uint4 of Rq
+  int n_layers, splits, npairs, NA, rows_pad, rows_per_split;
+};
+struct WgradPrepDesc {
+  const float* p[WGB_MAX];
+  const float* q[WGB_MAX];
+  const float* r[WGB_MAX];
+};
+
+// mx[4 * layer + which] = max |tensor|, which 0 / 1 / 2 = p / q / r  (mx zeroed before)
+__global__ void absmax_rows_batch_kernel(WgradPrepDesc d, long ldp, long ldq, long ldr, int rows, int NA,
+                                         float* __restrict__ mx) {
+  const int layer = blockIdx.y / 3, which = blockIdx.y % 3;
+  const float* t = which == 0 ? d.p[layer] : (which == 1 ? d.q[layer] : d.r[layer]);
+  const long ld = which == 0 ? ldp : (which == 1 ? ldq : ldr);
+  const int cols = which == 0 ? NA : 128;
+  float m = 0.f;
+  if (cols == 128 && (ld & 3) == 0 && (((uintptr_t)t) & 15) == 0) {
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (long n = (long)blockIdx.x * 8 + r0; n < rows; n += (long)gridDim.x * 8) {
+      const float4 v = *reinterpret_cast<const float4*>(t + n * ld + 4 * c4);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)rows * cols; i += (long)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(t[(i / cols) * ld + (i % cols)]));
+  }
+  block_absmax_commit(m, mx + 4 * layer + which);
+}
+
+// z = 2 * layer + which: which 0 -> pT [128][rows_pad] = (p * 2^k * sign(n))^T, 2^k from max|p| max|q| (the products
+// p*q must fit fp16) and sign(n) = -1 in the odd 512-row groups of n's row split (the kernel's partial sums alternate
+// in sign); which 1 -> qT = q^T.  Rows beyond `rows` and columns beyond NA are zero.
+__global__ void transpose_pad_batch_kernel(WgradPrepDesc d, long ldp, long ldq, int rows, int NA, int rows_pad,
+                                           int rows_per_split, float* __restrict__ pT, float* __restrict__ qT, long sT,
+                                           const float* __restrict__ mx) {
+  __shared__ float t[32][33];
+  const int layer = blockIdx.z >> 1, which = blockIdx.z & 1;
+  const float* in = which ? d.q[layer] : d.p[layer];
+  const long ld = which ? ldq : ldp;
+  const int cols = which ? 128 : NA;
+  float* out = (which ? qT : pT) + (long)layer * sT;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float scale = 1.f;
+  if (!which) {
+    float ipq;
+    pow2_scale(mx[4 * layer] * mx[4 * layer + 1], scale, ipq);
+    if ((((n0 % rows_per_split) >> 5) >> 4) & 1) scale = -scale;   // a 32-row tile never straddles a 512-row group
+  }
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    t[i][tx] = (n < rows && c < cols) ? in[(long)n * ld + c] * scale : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (c < 128 && n < rows_pad) out[(long)c * rows_pad + n] = t[tx][i];
+  }
+}
+__global__ void split_rows_f16_batch_kernel(WgradPrepDesc d, long ldr, int rows, int rows_pad, _Float16* __restrict__ dst,
+                                            long sR_halfs, const float* __restrict__ mx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows_pad * 128) return;
+  const int layer = blockIdx.y;
+  const int n = (int)(i >> 7), c = (int)(i & 127);
+  float v = n < rows ? d.r[layer][(long)n * ldr + c] : 0.f;
+  const int s = n >> 4, h = (n >> 3) & 1, j = n & 7, cb = c >> 5, rr = c & 31;
+  const long base = (long)s * 2 * 4;
+  float sr, ir;
+  pow2_scale(mx[4 * layer + 2], sr, ir);
+  v *= sr;
+  const _Float16 x1 = (_Float16)v, x2 = (_Float16)(v - (float)x1);
+  _Float16* d16 = dst + (long)layer * sR_halfs;
+  d16[((((base + 0 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x1;
+  d16[((((base + 1 * 4 + cb) * 2 + h) * 32 + rr) * 8) + j] = x2;
+}
+
+// Ring slot (one 32-row chunk): Rs = two k-steps x two planes x four column blocks x 64 lanes x 16 B of r fragments;
+// Qs = the q^T tile [128 b][32 n] with the eight 16-byte pieces of a row XOR-swizzled by (b >> 1) & 7 (LDS-DMA writes
+// 1 KB per wave instruction linearly, so there is no room for a padded pitch: the swizzle is applied on the GLOBAL
+// address each lane fetches, and makes the 16-byte fragment reads of 32 consecutive rows conflict-free); Ps = the
+// two staged p rows.
+#define WGP_RS_B 16384
+#define WGP_QS_B 16384
+#define WGP_PS_B 256
+#define WGP_BUF_B (WGP_RS_B + WGP_QS_B + WGP_PS_B)
+#define WGP_SLOTS 4
+#define WGP_SB() __builtin_amdgcn_sched_barrier(0)
+
+// one pair of products -> one 32-bit word of each fragment plane (6 VALU)
+#define WGP_SPLIT(k_, pa_, pb_, qa_, qb_)                                    \
+  {                                                                          \
+    unsigned w1_, w2_;                                                       \
+    split2_pair_f16((pa_) * (qa_), (pb_) * (qb_), w1_, w2_);                 \
+    asm volatile("" : "+v"(w1_), "+v"(w2_)); /* packed words NOW: the conversions must not sink into the next step */ \
+    nh[k_] = w1_; nl[k_] = w2_;                                              \
+  }
+
+__global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16p_kernel(const float* __restrict__ pT_,
+                                                                        const float* __restrict__ qT_,
+                                                                        const uint4* __restrict__ Rq_,
+                                                                        const float* __restrict__ mx_,
+                                                                        WgradBatchDesc u) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WGP_SLOTS * WGP_BUF_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hi = lane >> 5;
+  const int grp = wave >> 2, wb = wave & 3;
+  const int total = u.n_layers * u.splits * u.npairs, streams = u.n_layers * u.splits;
+  const bool xcd_map = total % 8 == 0 && streams <= 8 && 8 % streams == 0 && u.npairs % (8 / streams) == 0 &&
+                       gridDim.x % 8 == 0;
+  const int rows_pad = u.rows_pad;
+  // ---- per-lane LDS read offsets inside a slot ----
+  const unsigned rd_rs = lane * 16;
+  const int rowb = wb * 32 + r;
+  const int fsw = (rowb >> 1) & 7;
+  unsigned rd_q[2][2];   // [k-step][first / second 16-byte piece of the lane's 8 values]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rd_q[ks][e] = WGP_RS_B + rowb * 128 + (((ks * 4 + 2 * hi + e) ^ fsw) << 4);
+  const unsigned rd_ps = WGP_RS_B + WGP_QS_B + (grp * 32 + 8 * hi) * 4;
+  // ---- LDS-DMA: scalar LDS bases of this wave's pieces, per-lane global byte offsets ----
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned dma_w = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const unsigned voff_r = (unsigned)tid * 16;
+  const unsigned voff_q = (unsigned)(((tid >> 3) * (long)rows_pad + 4 * ((tid & 7) ^ ((tid >> 4) & 7))) * 4);
+  const unsigned voff_q2 = voff_q + (unsigned)((long)64 * rows_pad * 4);
+
+  for (int v = blockIdx.x; v < total; v += gridDim.x) {
+    // XCD-aware placement: workgroups are dealt to the 8 XCDs round-robin by linear id, and every workgroup of a
+    // (layer, split) stream reads the same q^T / r tiles.  Mapped so that the workgroups sharing an XCD share ONE stream
+    // and run in near lockstep, the tiles enter that L2 once instead of once per workgroup (speed only).
+    int stream, pair;
+    if (xcd_map) {
+      const int xcd = v & 7, w = v >> 3, xps = 8 / streams;
+      stream = xcd / xps;
+      pair = (xcd % xps) * (total / 8) + w;
+    } else {
+      stream = v / u.npairs;
+      pair = v % u.npairs;
+    }
+    stream = __builtin_amdgcn_readfirstlane(stream);   // uniform: keep the unit's addressing on the scalar unit
+    pair = __builtin_amdgcn_readfirstlane(pair);
+    const int layer = stream / u.splits, z = stream % u.splits;
+    const int a0 = pair * 2;
+    const int nbeg = z * u.rows_per_split;
+    const int nend = min(rows_pad, nbeg + u.rows_per_split);
+    const int nchunks = (nend - nbeg) / 32;   // rows_per_split and rows_pad are multiples of 32
+    const char* pT = reinterpret_cast<const char*>(pT_ + (long)layer * u.sT + (long)a0 * rows_pad);
+    const char* qT = reinterpret_cast<const char*>(qT_ + (long)layer * u.sT);
+    const char* Rq = reinterpret_cast<const char*>(Rq_ + (long)layer * u.sR);
+    const float* mx = mx_ + 4 * layer;
+    const unsigned voff_p = (unsigned)(((lane >> 5) * (long)rows_pad + (lane & 31)) * 4);
+
+    f32x16 acc[4], tot[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { acc[cb][t] = 0.f; tot[cb][t] = 0.f; }
+    float inv_all;
+    {
+      float spq, ipq, sr, ir;
+      pow2_scale(mx[0] * mx[1], spq, ipq);
+      pow2_scale(mx[2], sr, ir);
+      inv_all = ipq * ir;
+    }
+    if (nchunks > 0) {
+      // chunk ci -> ring slot ci % 4; five LDS-DMA instructions per wave (the index is clamped: the last iterations
+      // re-load the last chunk into a slot nobody reads, which keeps the vmcnt arithmetic uniform)
+#define WGP_DMA(ci_)                                                                        \
+  {                                                                                         \
+    const int cc_ = (ci_) < nchunks ? (ci_) : nchunks - 1;                                  \
+    const long n0_ = nbeg + (long)cc_ * 32;                                                 \
+    const unsigned d_ = dma_w + (unsigned)((ci_) & 3) * WGP_BUF_B;                          \
+    const char* rb_ = Rq + (n0_ >> 4) * 8192;                                               \
+    glds_b128(rb_, voff_r, d_);                                                             \
+    glds_b128(rb_ + 8192, voff_r, d_ + 8192);                                               \
+    glds_b128(qT + n0_ * 4, voff_q, d_ + WGP_RS_B);                                         \
+    glds_b128(qT + n0_ * 4, voff_q2, d_ + WGP_RS_B + 8192);                                 \
+    glds_b32(pT + n0_ * 4, voff_p, sbase + (unsigned)((ci_) & 3) * WGP_BUF_B + WGP_RS_B + WGP_QS_B); \
+  }
+      WGP_DMA(0);
+      WGP_DMA(1);
+      WGP_DMA(2);
+      wait_vmcnt<5>();                  // chunks 0 and 1 have landed (this wave's pieces) ...
+      __builtin_amdgcn_s_barrier();     // ... and everybody else's
+      asm volatile("" ::: "memory");
+      // fragments of the first step
+      unsigned nh[4], nl[4];
+      bf16x8 B[2][2];
+      {
+        const float4 qa = *reinterpret_cast<const float4*>(smem + rd_q[0][0]);
+        const float4 qb = *reinterpret_cast<const float4*>(smem + rd_q[0][1]);
+        const float4 pa = *reinterpret_cast<const float4*>(smem + rd_ps);
+        const float4 pb = *reinterpret_cast<const float4*>(smem + rd_ps + 16);
+        WGP_SPLIT(0, pa.x, pa.y, qa.x, qa.y) WGP_SPLIT(1, pa.z, pa.w, qa.z, qa.w)
+        WGP_SPLIT(2, pb.x, pb.y, qb.x, qb.y) WGP_SPLIT(3, pb.z, pb.w, qb.z, qb.w)
+        B[0][0] = *reinterpret_cast<const bf16x8*>(smem + rd_rs);
+        B[0][1] = *reinterpret_cast<const bf16x8*>(smem + rd_rs + 4096);
+      }
+      // One 16-row step: 12 MFMAs on the fragments (a1, a2) made during the previous step; meanwhile the p, q values
+      // of the NEXT step (slot offset so_, k-step kn_) are read and split into (nh, nl), and the B fragments are
+      // fetched one column block ahead (the last prefetch reads the next step's first block at bn_).
+#define WGP_STEP(bc_, bn_, so_, kn_)                                                                               \
+  {                                                                                                                \
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, make_uint4(nh[0], nh[1], nh[2], nh[3]));                          \
+    const bf16x8 a2 = __builtin_bit_cast(bf16x8, make_uint4(nl[0], nl[1], nl[2], nl[3]));                          \
+    WGP_SB();                                                                                                      \
+    /* ---- column block 0: issue the reads of the next step's p, q ---- */                                        \
+    B[1][0] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 1024);                                               \
+    B[1][1] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 4096 + 1024);                                        \
+    const float4 qa = *reinterpret_cast<const float4*>(smem + (so_) + rd_q[kn_][0]);                               \
+    const float4 pa = *reinterpret_cast<const float4*>(smem + (so_) + rd_ps + (kn_) * 64);                         \
+    WGP_SB();                                                                                                      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2), __builtin_bit_cast(f16x8, B[0][0]), acc[0], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    const float4 qb = *reinterpret_cast<const float4*>(smem + (so_) + rd_q[kn_][1]);                               \
+    const float4 pb = *reinterpret_cast<const float4*>(smem + (so_) + rd_ps + (kn_) * 64 + 16);                    \
+    WGP_SB();                                                                                                      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[0][1]), acc[0], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[0][0]), acc[0], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    /* ---- column block 1: split pairs 0, 1 ---- */                                                               \
+    B[0][0] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 2048);                                               \
+    B[0][1] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 4096 + 2048);                                        \
+    WGP_SB();                                                                                                      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2), __builtin_bit_cast(f16x8, B[1][0]), acc[1], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    WGP_SPLIT(0, pa.x, pa.y, qa.x, qa.y)                                                                           \
+    WGP_SB();                                                                                                      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[1][1]), acc[1], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    WGP_SPLIT(1, pa.z, pa.w, qa.z, qa.w)                                                                           \
+    WGP_SB();                                                                                                      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[1][0]), acc[1], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    /* ---- column block 2: split pairs 2, 3 ---- */                                                               \
+    B[1][0] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 3072);                                               \
+    B[1][1] = *reinterpret_cast<const bf16x8*>(smem + (bc_) + 4096 + 3072);                                        \
+    WGP_SB();                                                                                                      \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2), __builtin_bit_cast(f16x8, B[0][0]), acc[2], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    WGP_SPLIT(2, pb.x, pb.y, qb.x, qb.y)                                                                           \
+    WGP_SB();                                                                                                      \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[0][1]), acc[2], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    WGP_SPLIT(3, pb.z, pb.w, qb.z, qb.w)                                                                           \
+    WGP_SB();                                                                                                      \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[0][0]), acc[2], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    /* ---- column block 3: first B block of the next step ---- */                                                 \
+    B[0][0] = *reinterpret_cast<const bf16x8*>(smem + (bn_));                                                      \
+    B[0][1] = *reinterpret_cast<const bf16x8*>(smem + (bn_) + 4096);                                               \
+    WGP_SB();                                                                                                      \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2), __builtin_bit_cast(f16x8, B[1][0]), acc[3], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[1][1]), acc[3], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, B[1][0]), acc[3], 0, 0, 0); \
+    WGP_SB();                                                                                                      \
+  }
+#pragma clang loop unroll(disable)
+      for (int c = 0; c < nchunks; ++c) {
+        // chunk c + 3 into the slot chunk c - 1 was computed from (its readers passed the barrier that ended c - 1)
+        WGP_DMA(c + 3);
+        if ((c & 15) == 0 && c > 0) {   // two-level summation over the long row dimension (512-row partials);
+          // groups alternate in sign (cancels the MFMA accumulator's rounding bias, see bilinear_rows128_ring16_kernel)
+          const float sg = (((c >> 4) - 1) & 1) ? -1.f : 1.f;
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              tot[cb][t] = fmaf(acc[cb][t], sg, tot[cb][t]);
+              acc[cb][t] = 0.f;
+            }
+        }
+        const unsigned o0 = (unsigned)(c & 3) * WGP_BUF_B, o1 = (unsigned)((c + 1) & 3) * WGP_BUF_B;
+        // step 0 of chunk c: next = step 1 of the same slot
+        WGP_STEP(o0 + rd_rs, o0 + rd_rs + 8192, o0, 1)
+        // step 1: next = step 0 of chunk c + 1 (landed and published by the barrier that ended chunk c - 1)
+        WGP_STEP(o0 + rd_rs + 8192, o1 + rd_rs, o1, 0)
+        // chunk c + 2 (issued one iteration ago) must have landed before the barrier publishes it; younger than it:
+        // only this iteration's five loads
+        wait_vmcnt<5>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads still in flight target this unit's ring
+#undef WGP_DMA
+#undef WGP_STEP
+    }
+    const int a = a0 + grp;
+    if (a < u.NA) {
+      float* o = u.splits == 1 ? u.out[layer] + (long)a * 128 * 128
+                               : u.slab + (((long)layer * u.splits + z) * u.NA + a) * 128 * 128;
+      const float sg_last = (nchunks > 0 && (((nchunks - 1) >> 4) & 1)) ? -1.f : 1.f;
+      // the lane id is laundered so that the 64 per-lane store addresses are computed HERE, once per unit, instead of
+      // being hoisted out of the unit loop and kept alive (= spilled) across the main loop
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int e_r = tl & 31, e_hi = (tl >> 5) & 1, e_wb = (tl >> 6) & 3;
+      float* ol = o + (long)(e_wb * 32 + 4 * e_hi) * 128 + e_r;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        acc[cb] = (acc[cb] * sg_last + tot[cb]) * inv_all;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ol[((t & 3) + 8 * (t >> 2)) * 128 + cb * 32] = acc[cb][t];
+      }
+    }
+    __syncthreads();   // the ring is re-filled by the next unit's prologue
+  }
+}
+
+// out[layer][i] = sum_z slab[layer][z][i]
+__global__ void slab_sum_batch_kernel(const float* __restrict__ slab, int splits, long n, WgradBatchDesc u) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* sl = slab + (long)blockIdx.y * splits * n;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += sl[(long)z * n + i];
+  u.out[blockIdx.y][i] = s;
+}
+
 static int wgrad_splits(int nrows, int NA) {
   int s = cdiv(512, NA);                 // aim at >= 2 workgroups per CU
   int maxs = nrows / 256;                // at least 8 chunks of 32 rows per split
@@ -1604,12 +1950,118 @@ static size_t wgrad_bf16_ws(int nrows, int NA, size_t* o_pT, size_t* o_qT, size_
   return off;
 }
 
+// ---- batched f16x3 launch (bilinear_wgrad128_f16p_kernel) ----
+// row splits per layer: enough units to fill the chip once (more only adds slab traffic), at least 8 chunks per split
+static int wgrad_batch_pick(int n_layers, int nrows, int NA, int* rps_out) {
+  const int npairs = cdiv(NA, 2), np = cdiv(nrows, 32) * 32;
+  int splits = 256 / (n_layers * npairs);
+  if (splits > np / 256) splits = np / 256;
+  if (splits < 1) splits = 1;
+  const int rps = cdiv(np / 32, splits) * 32;
+  if (rps_out) *rps_out = rps;
+  return cdiv(np, rps);
+}
+static size_t wgrad_batch_ws(int n_layers, int nrows, int NA, int splits, size_t* o_pT, size_t* o_qT, size_t* o_Rq,
+                             size_t* o_slab, size_t* o_mx) {
+  const size_t np = (size_t)cdiv(nrows, 32) * 32;
+  size_t off = 0;
+  *o_pT = off; off += ws_round((size_t)n_layers * np * 128, 4);
+  *o_qT = off; off += ws_round((size_t)n_layers * np * 128, 4);
+  *o_Rq = off; off += ws_round((size_t)n_layers * np * 128 * 2, 2);
+  *o_slab = off; if (splits > 1) off += ws_round((size_t)n_layers * splits * NA * 128 * 128, 4);
+  *o_mx = off; off += 256;
+  return off;
+}
+bool bilinear_wgrad_batch_fast(int n_layers, int NA, int NB, int NC, long ldq, long ldr) {
+  return bilinear_mode() == 2 && n_layers >= 1 && n_layers <= WGB_MAX && NA >= 1 && NA <= 128 && NB == 128 && NC == 128 &&
+         (ldr % 4) == 0 && !force_generic();
+}
+size_t bilinear_wgrad_batch_ws_bytes(int n_layers, int nrows, int NA, int NB, int NC) {
+  const size_t single = bilinear_wgrad_ws_bytes(nrows, NA, NB, NC);
+  if (NB != 128 || NC != 128 || NA > 128 || NA < 1 || n_layers > WGB_MAX || n_layers < 1 || nrows <= 0) return single;
+  size_t a, b, c, d, e;
+  const size_t batch = wgrad_batch_ws(n_layers, nrows, NA, wgrad_batch_pick(n_layers, nrows, NA, nullptr), &a, &b, &c, &d, &e);
+  return batch > single ? batch : single;
+}
+// out[l][a,b,c] = sum_n p[l][n,a] q[l][n,b] r[l][n,c] for l < n_layers in ONE launch (f16x3 mode; other modes: one
+// launch per layer).  max_wgs: workgroups of the grid (0 = 256, one per CU; 128 = half of the chip for running beside
+// an HBM-bound kernel on another stream -- every workgroup then walks two units)
+int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, const float* const* q, long ldq,
+                                const float* const* r, long ldr, float* const* out, int nrows, int NA, int NB, int NC,
+                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs) {
+  if (n_layers <= 0) return CGAT_OK;
+  bool aligned = true;
+  for (int l = 0; l < n_layers && l < WGB_MAX; ++l)
+    aligned = aligned && ((((uintptr_t)q[l]) | ((uintptr_t)r[l])) & 15) == 0;
+  // (the q^T tile is fetched with 32-bit lane offsets: 128 rows of rows_pad floats must stay below 4 GB)
+  if (!aligned || nrows <= 0 || nrows > 8000000 || !bilinear_wgrad_batch_fast(n_layers, NA, NB, NC, ldq, ldr)) {
+    for (int l = 0; l < n_layers; ++l)
+      CGAT_TRY(bilinear_wgrad_launch(p[l], ldp, q[l], ldq, r[l], ldr, out[l], nrows, NA, NB, NC, ws, ws_bytes, stream,
+                                     max_wgs > 0 && max_wgs < 256 ? max_wgs / cdiv(NA, 2) : 0));
+    return CGAT_OK;
+  }
+  if (max_wgs <= 0 || max_wgs > 256) max_wgs = 256;
+  const int npairs = cdiv(NA, 2);
+  const int np = cdiv(nrows, 32) * 32;
+  int rps = 0;
+  const int splits = wgrad_batch_pick(n_layers, nrows, NA, &rps);
+  size_t o_pT, o_qT, o_Rq, o_slab, o_mx;
+  const size_t need = wgrad_batch_ws(n_layers, nrows, NA, splits, &o_pT, &o_qT, &o_Rq, &o_slab, &o_mx);
+  if (!ws || ws_bytes < need) {
+    cgat_set_error("bilinear_wgrad_batch: workspace too small (%zu < %zu)", ws_bytes, need);
+    return CGAT_ERR_WORKSPACE;
+  }
+  float* pT = (float*)((char*)ws + o_pT);
+  float* qT = (float*)((char*)ws + o_qT);
+  _Float16* Rq = (_Float16*)((char*)ws + o_Rq);
+  float* mx = (float*)((char*)ws + o_mx);
+  WgradPrepDesc pd;
+  WgradBatchDesc u;
+  memset(&pd, 0, sizeof(pd));
+  memset(&u, 0, sizeof(u));
+  for (int l = 0; l < n_layers; ++l) { pd.p[l] = p[l]; pd.q[l] = q[l]; pd.r[l] = r[l]; u.out[l] = out[l]; }
+  u.slab = (float*)((char*)ws + o_slab);
+  u.sT = (long)np * 128;
+  u.sR = (long)np * 128 * 2 * 2 / 16;
+  u.n_layers = n_layers; u.splits = splits; u.npairs = npairs; u.NA = NA; u.rows_pad = np; u.rows_per_split = rps;
+  CGAT_HIP(hipMemsetAsync(mx, 0, 256, stream));
+  hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA, mx);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(transpose_pad_batch_kernel, dim3(np / 32, 4, 2 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, nrows, NA,
+                     np, rps, pT, qT, u.sT, (const float*)mx);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(split_rows_f16_batch_kernel, dim3(cdiv((long)np * 128, 256), n_layers), dim3(256), 0, stream, pd, ldr,
+                     nrows, np, Rq, u.sR * 8, (const float*)mx);
+  CGAT_LAUNCH_CHECK();
+  const int units = n_layers * splits * npairs;
+  int grid = units < max_wgs ? units : max_wgs;
+  {
+    CGAT_PROF("bilinear_wgrad", stream);
+    hipLaunchKernelGGL(bilinear_wgrad128_f16p_kernel, dim3(grid), dim3(512), 0, stream, (const float*)pT, (const float*)qT,
+                       (const uint4*)Rq, (const float*)mx, u);
+  }
+  CGAT_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long n = (long)NA * 128 * 128;
+    hipLaunchKernelGGL(slab_sum_batch_kernel, dim3(cdiv(n, 256), n_layers), dim3(256), 0, stream, (const float*)u.slab, splits,
+                       n, u);
+    CGAT_LAUNCH_CHECK();
+  }
+  return CGAT_OK;
+}
+
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
   if (NB == 128 && NC == 128) {
     size_t a, b, c, d;
     size_t bf = wgrad_bf16_ws(nrows, NA, &a, &b, &c, &d);
     size_t f32 = ws_round((size_t)wgrad_splits(nrows, NA) * NA * NB * NC, 4);
-    return bf > f32 ? bf : f32;
+    if (f32 > bf) bf = f32;
+    if (NA >= 1 && NA <= 128 && nrows > 0) {   // the f16x3 form: batched kernel with one layer
+      size_t e;
+      const size_t one = wgrad_batch_ws(1, nrows, NA, wgrad_batch_pick(1, nrows, NA, nullptr), &a, &b, &c, &d, &e);
+      if (one > bf) bf = one;
+    }
+    return bf;
   }
   return 0;
 }
@@ -1619,6 +2071,11 @@ size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream,
                           int force_splits) {
+  if (wgrad_fast(q, ldq, r, ldr, NB, NC) && bilinear_mode() == 2 && nrows > 0 && nrows <= 8000000 && NA <= 128) {
+    // f16x3: the batched, software-pipelined kernel with one layer (row splits fill the chip)
+    return bilinear_wgrad_batch_launch(1, &p, ldp, &q, ldq, &r, ldr, &out, nrows, NA, NB, NC, ws, ws_bytes, stream,
+                                       force_splits > 0 ? force_splits * cdiv(NA, 2) : 0);
+  }
   if (wgrad_fast(q, ldq, r, ldr, NB, NC) && bilinear_mode() != 0 && nrows > 0) {
     size_t o_pT, o_qT, o_Rq, o_slab;
     const size_t need = wgrad_bf16_ws(nrows, NA, &o_pT, &o_qT, &o_Rq, &o_slab);

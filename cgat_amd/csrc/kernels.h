@@ -76,6 +76,12 @@ size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream,
                           int force_splits = 0);
+// the same for n_layers (<= 8) operand triples in ONE launch (f16x3 mode: batched, software-pipelined kernel; other
+// modes: one launch per layer).  max_wgs: grid size (0 = one workgroup per CU; 128 = half of the chip)
+size_t bilinear_wgrad_batch_ws_bytes(int n_layers, int nrows, int NA, int NB, int NC);
+int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, const float* const* q, long ldq,
+                                const float* const* r, long ldr, float* const* out, int nrows, int NA, int NB, int NC,
+                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs = 0);
 // three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
 int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
                           hipStream_t stream);

@@ -81,11 +81,12 @@ struct Ctx {
     if (dry) return CGAT_OK;
     return colsum_launch(x, ldx, rows, cols, out, alpha, scratch, scratch_bytes, s);
   }
-  int wgrad(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out, int rows, int NA,
-            int NB, int NC) {
-    need(bilinear_wgrad_ws_bytes(rows, NA, NB, NC));
+  // all predicted layers' dT in one launch (f16x3) on this context's stream
+  int wgrad_batch(int n, const float* const* p, const float* const* q, const float* const* r, float* const* out, int rows,
+                  int W) {
+    need(bilinear_wgrad_batch_ws_bytes(n, rows, W, W, W));
     if (dry) return CGAT_OK;
-    return bilinear_wgrad_launch(p, ldp, q, ldq, r, ldr, out, rows, NA, NB, NC, scratch, scratch_bytes, s);
+    return bilinear_wgrad_batch_launch(n, p, W, q, W, r, W, out, rows, W, W, W, scratch, scratch_bytes, s);
   }
   int bilinear(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init, long ldi,
                float* out, long ldo, int rows, int NA, int NB, int NC) {
@@ -837,11 +838,11 @@ struct HnetSide {
   hipStream_t s;
   void* ws;
   size_t bytes;
-  int wgrad_splits;   // 0 = default grid (one workgroup per CU)
+  int wgrad_wgs;      // workgroups of the dT launch: 0 = one per CU, 128 = half of the chip
 };
 static size_t hnet_side_ws_bytes(int rows, const cgat_hnet_params* p) {
   const size_t rw = (size_t)rows * p->W;
-  return ws_round((size_t)p->n_hyper * rw, 4) + bilinear_wgrad_ws_bytes(rows, p->W, p->W, p->W) + 256;
+  return ws_round((size_t)p->n_hyper * rw, 4) + bilinear_wgrad_batch_ws_bytes(p->n_hyper, rows, p->W, p->W, p->W) + 256;
 }
 static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const float* h0, const float* v,
                               const float* saved, const float* g_y, float* g_h0, float* g_v,
@@ -851,7 +852,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const size_t rw = (size_t)rows * W;
   float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
   float* g_hin = c.take<float>(rw);
-  float* g_u = c.take<float>(rw);
+  float* g_u = c.take<float>((size_t)p->n_hyper * rw);   // one per predicted layer: all dT run in ONE launch at the end
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
   float* g_t = c.take<float>(rw);
   float* g_pre = c.take<float>(rw);
@@ -877,7 +878,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     const cgat_hyperlinear_grads& G = gr->layer[l];
     const float* gu = gout;  // gradient wrt the pre-norm output u_l
     if (l < p->n_hyper - 1) {
-      float* gu_buf = (side && !c.dry) ? (float*)side->ws + (size_t)l * rw : g_u;
+      float* gu_buf = c.dry ? nullptr : ((side ? (float*)side->ws : g_u) + (size_t)l * rw);
       RUN(layernorm_tanh_bwd_launch(sv.u(l), sv.vin(l + 1), gout, gu_buf, rows, W, 1e-5f, c.s));
       gu = gu_buf;
     }
@@ -885,11 +886,8 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     const float* vin = (l == 0) ? v : sv.vin(l);
     const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
     // ---- head parameter gradients ----
-    if (side && !c.dry) {   // dT[o][i][k]: deferred to the side stream, see the end of this function
-      deferred[n_deferred++] = {gu, vin, z, G.head_w};
-    } else {
-      CGAT_TRY(c.wgrad(gu, W, vin, W, z, W, G.head_w, rows, W, W, W));  // [o][i][k]
-    }
+    // dT[o][i][k] = sum_n gu[n,o] vin[n,i] z[n,k]: deferred, all predicted layers in one launch (end of this function)
+    deferred[n_deferred++] = {gu, vin, z, G.head_w};
     // Bm grad [o][i] = gu^T vin, U grad [o][k] = gu^T z, bias grad = column sums of gu: one pass over the three operands
     int fused = W == 128 ? c.dw128(gu, W, vin, W, G.head_b, W, z, W, G.head_w + WW * W, W, G.head_b + WW, rows) : -1;
     if (fused > 0) return fused;
@@ -950,18 +948,23 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     RUN(copy2d_launch(g_hin, W, g_h0, W, rows, W, c.s));
   }
   if (n_deferred > 0) {
-    // The dT contractions start when everything above has been issued on the main stream, i.e. together with
-    // whatever the caller enqueues next (the HBM-bound attention backward); started earlier they would only
-    // time-slice the matrix cores with the other contractions of this pass.
-    hipEvent_t ev;
-    CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    CGAT_HIP(hipEventRecord(ev, c.s));
-    CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
-    CGAT_HIP(hipEventDestroy(ev));
-    const size_t off = ws_round((size_t)p->n_hyper * rw, 4);
-    for (int i = 0; i < n_deferred; ++i)
-      CGAT_TRY(bilinear_wgrad_launch(deferred[i].gu, W, deferred[i].vin, W, deferred[i].z, W, deferred[i].out, rows, W, W,
-                                     W, (char*)side->ws + off, side->bytes - off, side->s, side->wgrad_splits));
+    const float *dp[CGAT_MAX_HYPER], *dq[CGAT_MAX_HYPER], *dr[CGAT_MAX_HYPER];
+    float* dout[CGAT_MAX_HYPER];
+    for (int i = 0; i < n_deferred; ++i) { dp[i] = deferred[i].gu; dq[i] = deferred[i].vin; dr[i] = deferred[i].z; dout[i] = deferred[i].out; }
+    if (side && !c.dry) {
+      // On the side stream the dT launch starts when everything above has been issued on the main stream, i.e. together
+      // with whatever the caller enqueues next (the HBM-bound attention backward), on `wgrad_wgs` workgroups.
+      hipEvent_t ev;
+      CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      CGAT_HIP(hipEventRecord(ev, c.s));
+      CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
+      CGAT_HIP(hipEventDestroy(ev));
+      const size_t off = ws_round((size_t)p->n_hyper * rw, 4);
+      CGAT_TRY(bilinear_wgrad_batch_launch(n_deferred, dp, W, dq, W, dr, W, dout, rows, W, W, W, (char*)side->ws + off,
+                                           side->bytes - off, side->s, side->wgrad_wgs));
+    } else {
+      CGAT_TRY(c.wgrad_batch(n_deferred, dp, dq, dr, dout, rows, W));
+    }
   }
   return check_ws(c, "hnet_backward");
 }
@@ -1009,12 +1012,8 @@ extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_param
   }
   Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
   c.scratch_need = dry.scratch_need;
-  static int side_splits = -1;   // CGAT_SIDE_WGRAD_SPLITS: 2 (default) = 128 workgroups, the other half of the chip stays
-  if (side_splits < 0) {         // free for the main stream's HBM-bound kernels; 0 = full grid
-    const char* e = getenv("CGAT_SIDE_WGRAD_SPLITS");
-    side_splits = e ? atoi(e) : 2;
-  }
-  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_splits};
+  // half of the chip stays free for the main stream's HBM-bound kernels
+  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, 128};
   return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);
 }
 extern "C" int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,

@@ -4,6 +4,9 @@
 // turns the scatter into contiguous, atomics-free segment reductions.  A second CSR over the
 // sorted positions keyed by edge_index[0] serves the transposed accumulation (grad wrt x_j).
 //
+// Keys outside [0, S) are dropped: rowptr[S] then ends below n, which is how the caller detects an invalid
+// edge_index / batch index (cgat_amd/ops.py raises IndexError, as the reference's index_select would).
+//
 // csr_from_keys: histogram (integer atomics) -> exclusive scan -> cursor fill -> per-segment
 // ascending sort of the filled ids.  The final sort makes the order *stable* (ids ascending
 // inside a segment), hence independent of atomic arrival order: the plan, and every
@@ -57,11 +60,19 @@ __global__ void fill_kernel_csr(const int* __restrict__ keys, int n, int S, cons
   perm[rowptr[k] + pos] = i;
 }
 
-// ascending insertion sort of each segment's ids (segments are short: in-degree of an atom)
-__global__ void sort_segments_kernel(const int* __restrict__ rowptr, int S, int* __restrict__ perm) {
+// ascending sort of each segment's ids.  Short segments (the in-degree of an atom) by one thread's insertion sort;
+// longer ones are queued (long_list, counter long_n) for sort_long_segments_kernel, so that a hub atom or a large
+// crystal does not leave one lane with an O(d^2) loop.
+#define SEG_SHORT 32
+__global__ void sort_segments_kernel(const int* __restrict__ rowptr, int S, int* __restrict__ perm,
+                                     int* __restrict__ long_list, int* __restrict__ long_n) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   int r0 = rowptr[s], r1 = rowptr[s + 1];
+  if (r1 - r0 > SEG_SHORT) {
+    long_list[atomicAdd(long_n, 1)] = s;   // order of the queue is irrelevant: every segment is sorted independently
+    return;
+  }
   for (int i = r0 + 1; i < r1; ++i) {
     int v = perm[i];
     int j = i - 1;
@@ -70,6 +81,62 @@ __global__ void sort_segments_kernel(const int* __restrict__ rowptr, int S, int*
       --j;
     }
     perm[j + 1] = v;
+  }
+}
+
+// One 1024-thread workgroup per queued segment: rank sort (ids are distinct, so rank = number of smaller ids is a
+// permutation): every thread keeps up to 8 ids in registers, the segment passes through LDS in 1024-id tiles, then
+// the ids are written to their ranks -- d^2 / 1024 comparisons per thread, no temporary array.
+#define SEG_LONG_PER_THREAD 8
+__global__ __launch_bounds__(1024) void sort_long_segments_kernel(const int* __restrict__ rowptr, int* __restrict__ perm,
+                                                                  const int* __restrict__ long_list,
+                                                                  const int* __restrict__ long_n) {
+  __shared__ int tile[1024];
+  const int tid = threadIdx.x;
+  const int nl = *long_n;
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int s = long_list[li];
+    const int r0 = rowptr[s], d = rowptr[s + 1] - r0;
+    if (d > 1024 * SEG_LONG_PER_THREAD) {   // beyond the register budget: one lane, correct but slow
+      if (tid == 0) {
+        for (int i = r0 + 1; i < r0 + d; ++i) {
+          int v = perm[i];
+          int j = i - 1;
+          while (j >= r0 && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+          perm[j + 1] = v;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    int v[SEG_LONG_PER_THREAD], rank[SEG_LONG_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < SEG_LONG_PER_THREAD; ++k) {
+      const int i = tid + 1024 * k;
+      v[k] = i < d ? perm[r0 + i] : 0x7fffffff;
+      rank[k] = 0;
+    }
+    const int tiles = (d + 1023) / 1024;
+    for (int t = 0; t < tiles; ++t) {
+      __syncthreads();
+      int mine = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < SEG_LONG_PER_THREAD; ++k)
+        if (k == t) mine = v[k];
+      tile[tid] = mine;
+      __syncthreads();
+      const int lim = min(1024, d - 1024 * t);
+      for (int j = 0; j < lim; ++j) {
+        const int x = tile[j];
+#pragma unroll
+        for (int k = 0; k < SEG_LONG_PER_THREAD; ++k) rank[k] += x < v[k] ? 1 : 0;
+      }
+    }
+    __syncthreads();   // every id is in registers before the first one is overwritten
+#pragma unroll
+    for (int k = 0; k < SEG_LONG_PER_THREAD; ++k)
+      if (tid + 1024 * k < d) perm[r0 + rank[k]] = v[k];
+    __syncthreads();
   }
 }
 
@@ -93,10 +160,14 @@ int csr_from_keys_launch(const int* keys, int n, int S, int* rowptr, int* perm, 
   }
   hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, s, count, S, rowptr);
   CGAT_LAUNCH_CHECK();
-  if (n > 0) {
+  if (n > 0 && S > 0) {
     hipLaunchKernelGGL(fill_kernel_csr, dim3(cdiv(n, 256)), dim3(256), 0, s, keys, n, S, rowptr, cursor, perm);
     CGAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_segments_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, rowptr, S, perm);
+    // `count` is free once the scan has consumed it: it becomes the queue of long segments, cursor[S] its length
+    hipLaunchKernelGGL(sort_segments_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, rowptr, S, perm, count, cursor + S);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_long_segments_kernel, dim3(S < 256 ? (S > 0 ? S : 1) : 256), dim3(1024), 0, s, rowptr, perm,
+                       (const int*)count, (const int*)(cursor + S));
     CGAT_LAUNCH_CHECK();
   }
   return CGAT_OK;

@@ -49,6 +49,25 @@ def workspace(nbytes, device):
     return buf
 
 
+_validate_indices = os.environ.get("CGAT_VALIDATE_INDICES", "1") != "0"
+
+
+def set_validate_indices(flag):
+    """Index validation of the CSR plans (default on): an edge_index / segment index entry outside [0, N) raises
+    IndexError, as the reference's index_select / scatter would.  It costs one host sync per plan build; a training
+    loop that trusts its collation can switch it off."""
+    global _validate_indices
+    _validate_indices = bool(flag)
+
+
+def _check_plan_complete(rowptr, n, what):
+    # the plan builder drops out-of-range keys, so the last row pointer falls short of n exactly when one exists
+    if _validate_indices and n > 0:
+        got = int(rowptr[-1])
+        if got != n:
+            raise IndexError(f"cgat_amd: {n - got} of {n} entries of {what} are outside [0, {rowptr.numel() - 1})")
+
+
 class EdgePlan:
     """CSR plan of a batch (C struct cgat_plan): built once per edge_index, shared by all layers,
     forward and backward."""
@@ -74,6 +93,8 @@ class EdgePlan:
             check(lib.cgat_plan_build(_ptr(ei), E, N, _ptr(self.dst_rowptr), _ptr(self.dst_perm),
                                       _ptr(self.dst_sorted), _ptr(self.src_sorted), _ptr(self.src_rowptr),
                                       _ptr(self.src_pos), _ptr(ws), ws.numel(), _stream()), "cgat_plan_build")
+        _check_plan_complete(self.dst_rowptr, E, "edge_index[1]")
+        _check_plan_complete(self.src_rowptr, E, "edge_index[0]")
         self.c = _lib.Plan(N, E, self.dst_rowptr.data_ptr(), self.dst_perm.data_ptr(), self.dst_sorted.data_ptr(),
                            self.src_sorted.data_ptr(), self.src_rowptr.data_ptr(), self.src_pos.data_ptr())
 
@@ -110,6 +131,7 @@ class SegmentPlan:
         with torch.cuda.device(dev):
             check(lib.cgat_csr_from_keys(_ptr(keys), n, S, _ptr(self.rowptr), _ptr(self.perm), _ptr(ws), ws.numel(),
                                          _stream()), "cgat_csr_from_keys")
+        _check_plan_complete(self.rowptr, n, "the segment index")
         self.perm64 = self.perm.long()
 
 

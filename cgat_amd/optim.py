@@ -23,6 +23,7 @@ class _MultiTensor(torch.optim.Optimizer):
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._plan = {}
+        self._live_grads = []
 
     def _tensors(self, group):
         ps = [p for p in group["params"] if p.grad is not None]
@@ -36,7 +37,8 @@ class _MultiTensor(torch.optim.Optimizer):
                 st["step"] = 0
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            st["step"] += 1
+            # a state loaded from torch.optim.AdamW carries `step` as a tensor: same name, normalised to an int here
+            st["step"] = int(st["step"]) + 1
         return ps
 
     def _launch_plan(self, ps):
@@ -53,11 +55,17 @@ class _MultiTensor(torch.optim.Optimizer):
             self._plan[key] = (torch.from_numpy(np.concatenate(ct)).to(dev), torch.from_numpy(np.concatenate(co)).to(dev),
                                torch.from_numpy(np.asarray(first, np.int32)).to(dev), first[-1])
         tab = np.empty((len(ps), 5), np.int64)
+        # re-laid (non-contiguous) gradients stay alive until the NEXT step's launch has been queued; not in
+        # self.state: state_dict() must hold exactly torch.optim.AdamW's entries (step, exp_avg, exp_avg_sq)
+        live = []
         for i, p in enumerate(ps):
             st = self.state[p]
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            st["_g"] = g   # keep a possibly re-laid gradient alive until the launch has been queued
+            g = p.grad
+            if not g.is_contiguous():
+                g = g.contiguous()
+                live.append(g)
             tab[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+        self._live_grads = live
         return self._plan[key], torch.from_numpy(tab).to(dev)
 
 

@@ -27,7 +27,7 @@ def _loss_sum(model, batch, x, e, x0, lo, hi, A, K):
     return y.square().sum()
 
 
-def _worker(rank, world, port, bucket_bytes, out):
+def _worker(rank, world, port, bucket_bytes, out, mode="plain"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -45,15 +45,37 @@ def _worker(rank, world, port, bucket_bytes, out):
     torch.manual_seed(1)
     model = O.GATConvNodes(C, C, C, 3, concat=True)
     unused = torch.nn.Parameter(torch.ones(3))            # a parameter that never receives a gradient
-    params = list(model.parameters()) + [unused]
+    half = torch.nn.Parameter(torch.ones(3))              # used on rank 0 only: must end with the mean on both ranks
+    params = list(model.parameters()) + [unused, half]
     avg = GradientAverager(params, bucket_bytes=bucket_bytes)
     lo, hi = shard_range(G, rank, world)
-    for _ in range(2):                                     # two steps: hooks must re-arm
-        for p in params:
-            p.grad = None
-        (_loss_sum(model, batch, x, e, x0, lo, hi, A, K) * world / G).backward()
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=1e-2) if mode == "optim" else None
+    for it in range(2):                                    # two steps: hooks must re-arm
+        if mode == "views" or (mode == "optim" and it == 1):
+            avg.zero_grad()                                # gradients accumulate straight into the bucket views
+        else:
+            for p in params:
+                p.grad = None                              # what optimizer.zero_grad(set_to_none=True) leaves
+        extra = (half.sum() * 3.0) if rank == 0 else 0.0
+        if mode == "accumulate":                           # two micro-batches per rank (train.py:62 accumulate_grad_batches)
+            mid = (lo + hi) // 2
+            with avg.no_sync():
+                (_loss_sum(model, batch, x, e, x0, lo, mid, A, K) * world / G + extra).backward()
+            (_loss_sum(model, batch, x, e, x0, mid, hi, A, K) * world / G).backward()
+        else:
+            (_loss_sum(model, batch, x, e, x0, lo, hi, A, K) * world / G + extra).backward()
         avg.finish()
-    if rank == 0:
+        if opt is not None:
+            opt.step()
+    if mode == "optim":
+        # replicas must stay bit-identical: same mean gradient, same update, and the globally unused parameter
+        # untouched (no weight decay applied to it on either rank)
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        if rank == 0:
+            out.put((float((both[0] - both[1]).abs().max()), bool((unused.detach() == 1).all()), len(avg.buckets)))
+    elif rank == 0:
         torch.manual_seed(1)
         ref = O.GATConvNodes(C, C, C, 3, concat=True)
         (_loss_sum(ref, batch, x, e, x0, 0, G, A, K) / G).backward()
@@ -64,26 +86,38 @@ def _worker(rank, world, port, bucket_bytes, out):
         for p, q in zip(model.parameters(), ref.parameters()):
             den = max(q.grad.abs().max().item(), 1e-3 * scale)
             worst = max(worst, (p.grad - q.grad).abs().max().item() / den)
+        worst = max(worst, float((half.grad - 1.5).abs().max()))     # (3 + 0) / 2 ranks
         out.put((worst, unused.grad is None, len(avg.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [64 << 20, 4096])
-def test_two_rank_gradient_mean_equals_full_batch(bucket_bytes):
+def _run(bucket_bytes, mode):
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
-    worst, unused_none, nb = out.get()
+    return out.get()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 4096])
+@pytest.mark.parametrize("mode", ["plain", "views", "accumulate"])
+def test_two_rank_gradient_mean_equals_full_batch(bucket_bytes, mode):
+    worst, unused_none, nb = _run(bucket_bytes, mode)
     assert worst <= 2e-5, worst
     assert unused_none
     assert nb >= (1 if bucket_bytes > 1 << 20 else 2)
+
+
+def test_two_rank_replicas_identical_after_optimizer_steps():
+    diff, unused_untouched, _ = _run(4096, "optim")
+    assert diff == 0.0
+    assert unused_untouched
 
 
 def test_shard_range_partitions():

@@ -266,6 +266,35 @@ def test_plan_large_scan(env):
     assert empty.dst_rowptr.cpu().tolist() == [0] * 6
 
 
+def test_plan_hub_segments_and_invalid_indices(env):
+    """Segments far beyond an atom's in-degree (a hub with 3 000 and one with 20 000 incoming edges: the workgroup rank
+    sort and its one-lane fallback) stay bit-exact vs a stable sort; an index outside [0, N) raises IndexError as the
+    reference's index_select would."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(8)
+    N, E = 500, 40000
+    dst = torch.randint(0, N, (E,), generator=g)
+    dst[torch.randperm(E, generator=g)[:3000]] = 7
+    dst[torch.randperm(E, generator=g)[:20000]] = 11
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), dst])
+    plan = ops.EdgePlan(ei.to(dev), N)
+    assert torch.equal(plan.dst_perm.cpu().long(), torch.sort(ei[1], stable=True).indices)
+    src_sorted = ei[0][plan.dst_perm.cpu().long()]
+    assert torch.equal(plan.src_pos.cpu().long(), torch.sort(src_sorted, stable=True).indices)
+    sp = ops.SegmentPlan(dst.to(dev), N)
+    assert torch.equal(sp.perm.cpu().long(), torch.sort(dst, stable=True).indices)
+    bad = ei.clone()
+    bad[1, 123] = N
+    with pytest.raises(IndexError):
+        ops.EdgePlan(bad.to(dev), N)
+    bad = ei.clone()
+    bad[0, 5] = -1
+    with pytest.raises(IndexError):
+        ops.EdgePlan(bad.to(dev), N)
+    with pytest.raises(IndexError):
+        ops.SegmentPlan(torch.tensor([0, 1, 9], device=dev), 3)
+
+
 @pytest.mark.parametrize("F,with_mult", [(3, False), (1, True), (48, False)])
 def test_segment_softmax(env, F, with_mult):
     _, _lib, ops, dev = env

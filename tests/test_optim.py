@@ -108,6 +108,38 @@ def test_fused_adamw_matches_torch_on_a_model():
 
 
 @pytest.mark.gpu
+def test_fused_adamw_state_is_torch_adamw_state():
+    """The checkpoint ABI of the optimiser: state_dict() holds exactly torch.optim.AdamW's entries (no gradient
+    copies), and a state written by torch.optim.AdamW (tensor-valued `step`) resumes in FusedAdamW."""
+    from cgat_amd import optim as PO
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(7 + i)).to(dev))
+                  for i, s in enumerate([(5, 7), (33,), (128, 4)])]
+    ps_t, ps_f = mk(), mk()
+    grads = [[torch.randn(p.shape, generator=g).to(dev) for p in ps_t] for _ in range(4)]
+    ref = torch.optim.AdamW(ps_t, lr=1e-3, weight_decay=1e-2)
+    warm = torch.optim.AdamW(ps_f, lr=1e-3, weight_decay=1e-2)
+    for step in range(2):                                   # two torch steps on both, then hand over
+        for opt, ps in ((ref, ps_t), (warm, ps_f)):
+            for p, gr in zip(ps, grads[step]):
+                p.grad = gr.clone()
+            opt.step()
+    fused = PO.FusedAdamW(ps_f, lr=1e-3, weight_decay=1e-2)
+    fused.load_state_dict(warm.state_dict())
+    for step in range(2, 4):
+        for p, q, gr in zip(ps_t, ps_f, grads[step]):
+            p.grad, q.grad = gr.clone(), gr.t().contiguous().t() if gr.dim() == 2 else gr.clone()   # a non-contiguous one
+        ref.step(); fused.step()
+    for p, q in zip(ps_t, ps_f):
+        assert rel(q.detach().cpu().numpy(), p.detach().cpu().numpy()) <= TOL
+    sd = fused.state_dict()
+    for st in sd["state"].values():
+        assert set(st.keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        assert int(st["step"]) == 4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["l1", "l2"])
 def test_robust_losses_match_reference(name):
     from cgat_amd import optim as PO
