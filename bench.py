@@ -45,32 +45,51 @@ def make_inputs(graphs, seed, device):
     return b.edge_index.to(device), x, e, x0, cot
 
 
-def cpu_baseline(n_graphs=100, reps=3):
+def _cpu_layer_time(layer, n_graphs, backward, reps, warm):
+    """Median seconds of one pass of the oracle layer over n_graphs synthetic crystals on the host cores."""
+    ei, x, e, x0, cot = make_inputs(n_graphs, 0, "cpu")
+    times = []
+    for r in range(reps + warm):
+        t0 = time.perf_counter()
+        if backward:
+            xx, ee, xx0 = (t.clone().requires_grad_(True) for t in (x, e, x0))
+            y = layer(xx, ei, ee, xx0)
+            torch.autograd.grad((y * cot).sum(), [xx, ee, xx0] + list(layer.parameters()))
+        else:
+            with torch.no_grad():
+                layer(x, ei, e, x0)
+        dt = time.perf_counter() - t0
+        if r >= warm:
+            times.append(dt)
+    times.sort()
+    return times[len(times) // 2], int(ei.shape[1])
+
+
+def cpu_baseline():
     """The oracle (op-for-op restatement of the reference's CPU path: cat -> head repeat -> grouped
     Conv1d -> LeakyReLU -> conv -> segment softmax -> scatter-add -> Linear(C -> C*C+C) hypernet ->
-    bmm -> LayerNorm -> tanh) timed on this box's host cores, same layer, fwd+bwd, on a bounded
-    sample of the same synthetic workload."""
-    import cgat_amd as P
+    bmm -> LayerNorm -> tanh) timed on this box's host cores as BASELINE.md §3 specifies: BASELINE config 1 run
+    whole (1000 crystals, E = 240 000, one layer forward, no_grad) and the metric's fwd+bwd at two sizes of the same
+    synthetic workload (E = 24 000 and 60 000; the 1M-edge batch needs ~240 GB of host memory for the reference's
+    materialised hypernetwork weights) with the linearity of the per-edge cost checked between them.  `value` is the
+    fwd+bwd rate at the larger size."""
     from oracle import cgat_oracle as O
     torch.manual_seed(1)
     layer = O.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True)
-    ei, x, e, x0, cot = make_inputs(n_graphs, 0, "cpu")
-    times = []
-    for r in range(reps + 1):
-        xx, ee, xx0 = (t.clone().requires_grad_(True) for t in (x, e, x0))
-        t0 = time.perf_counter()
-        y = layer(xx, ei, ee, xx0)
-        torch.autograd.grad((y * cot).sum(), [xx, ee, xx0] + list(layer.parameters()))
-        dt = time.perf_counter() - t0
-        if r > 0:
-            times.append(dt)
-    times.sort()
-    med = times[len(times) // 2]
-    E = ei.shape[1]
-    return {"value": E / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_graphs} crystals ({E} edges) of the same synthetic workload, same layer fwd+bwd, "
-                      f"fp32, median of {reps} after 1 warm-up ({med:.2f} s per pass); per-edge cost is "
-                      "batch-size independent (SURVEY §8d)"}
+    t24, e24 = _cpu_layer_time(layer, 100, True, reps=2, warm=1)
+    t60, e60 = _cpu_layer_time(layer, 250, True, reps=2, warm=0)
+    tf, ef = _cpu_layer_time(layer, 1000, False, reps=1, warm=0)
+    r24, r60 = e24 / t24, e60 / t60
+    return {"value": r60, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "config1_fwd": {"edges": ef, "seconds": round(tf, 3), "edges_per_s": round(ef / tf, 1),
+                            "what": "BASELINE configs[0]: 1000 crystals, one layer forward, no_grad, run whole"},
+            "fwdbwd_24k": {"edges": e24, "seconds": round(t24, 3), "edges_per_s": round(r24, 1)},
+            "fwdbwd_60k": {"edges": e60, "seconds": round(t60, 3), "edges_per_s": round(r60, 1)},
+            "linearity": {"per_edge_cost_ratio_60k_over_24k": round((t60 / e60) / (t24 / e24), 3),
+                          "what": "1.0 = the per-edge cost does not depend on the batch size, i.e. the rate measured "
+                                  "at 60 000 edges extrapolates to the 1M-edge batch"},
+            "sample": f"oracle layer fwd+bwd on {e24} and {e60} edges (median of 2), forward on {ef} edges (1 pass), "
+                      "fp32, all host threads; run BEFORE the GPU leg"}
 
 
 def cpu_baseline_collate(data, emb, n_graphs, reps=5):
@@ -220,6 +239,156 @@ def bench_optim(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_train(args, rank, world, device):
+    """BASELINE configs[3]: the end-to-end data-parallel training step on a DCGAT-shaped synthetic dataset (ragged
+    crystals of 2..40 atoms, 24 stored / 12 used neighbours, y = e_above_hull * n_atoms): device collation of the
+    rank's crystals -> CGAtNet(200,128,4,msg_heads=3) forward -> RobustL1 -> backward with the bucketed gradient
+    all-reduce (RCCL over xGMI) overlapped -> one fused AdamW launch.  weak: every rank trains on --graphs crystals
+    per step; strong: the --graphs crystals of a step are split across the ranks."""
+    import numpy as np
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    from cgat_amd.graph import synthetic_dataset_dict
+    from cgat_amd.trainer import DataParallelTrainer
+    per_rank = args.graphs if args.scaling == "weak" else max(1, args.graphs // world)
+    n_data = 2 * per_rank                                  # this rank's shard of the dataset, resident in HBM
+    data, emb = synthetic_dataset_dict(n_data, (2, 40), 24, seed=100 + rank)
+    ds = P.PackedDataset.from_dict(data, emb, max_neighbor_number=K_NBR, device=device)
+    torch.manual_seed(1)                                   # identical replicas
+    net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
+    tr = DataParallelTrainer(net, ds, lr=1e-4, weight_decay=1e-6, rank=rank, world=world)
+    ops.set_validate_indices(False)                        # the collation kernel is the only producer of the indices
+    rs = np.random.RandomState(rank)
+    batches = [rs.permutation(n_data)[:per_rank] for _ in range(args.warmup + args.steps)]
+    edges = 0
+    for i in range(args.warmup):
+        tr.step(batches[i])
+    _fence(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _, e = tr.step(batches[args.warmup + i])
+        edges += e
+    _fence(world)
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([elapsed, float(edges)], device=device, dtype=torch.float64)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, edges = float(mx[0]), float(tot[1])
+    if rank == 0:
+        n_par = sum(p.numel() for p in net.parameters())
+        out = {"metric": "batch-edges/sec through the end-to-end data-parallel training step (collate -> CGAtNet fwd+bwd -> "
+                         "gradient all-reduce -> AdamW), DCGAT-shaped synthetic dataset [BASELINE configs[3]]",
+               "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+               "vs_baseline": None, "dtype": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
+               "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
+               "config": {"workload": f"train step: {per_rank} ragged crystals (2..40 atoms, 24 stored / {K_NBR} used nbrs) per "
+                                      f"rank and step, CGAtNet(200,128,4,msg_heads=3,update_edges=True), RobustL1, FusedAdamW, "
+                                      f"{n_par} parameters = {4 * n_par / 1e6:.0f} MB of gradients all-reduced per step",
+                          "edges_per_step_all_ranks": edges / args.steps,
+                          "parallelism": f"dp{world} (graphs sharded, bucketed gradient all-reduce overlapped with backward)"},
+               "roofline": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _fence(world):
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _time_steps(step, warmup, steps, world):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; seconds."""
+    for _ in range(warmup):
+        step()
+    _fence(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _fence(world)
+    return time.perf_counter() - t0
+
+
+def make_layer_workload(graphs, rank, world, device):
+    """One GATConvNodes layer (non-first: H_Net with damping), forward + full backward."""
+    import cgat_amd as P
+    from cgat_amd.dist import GradientAverager
+    torch.manual_seed(1)                                   # identical parameters on every rank
+    layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
+    params = list(layer.parameters())
+    ei, x, e, x0, cot = make_inputs(graphs, rank, device)  # each rank: its own crystals
+    x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
+    averager = GradientAverager(params) if world > 1 else None
+
+    def step():
+        if averager is not None:
+            averager.zero_grad()                           # gradients accumulate straight into the all-reduce buckets
+        else:
+            for p in params:
+                p.grad = None
+        x.grad = e.grad = x0.grad = None
+        y = layer(x, ei, e, x0)
+        y.backward(cot)
+        if averager is not None:
+            averager.finish()
+    return step, x.shape[0], ei.shape[1]
+
+
+def make_stack_workload(graphs, rank, world, device):
+    """BASELINE configs[2]: CGAtNet(200,128,4,msg_heads=3) forward + backward of the L1 loss on the same batch."""
+    import cgat_amd as P
+    from cgat_amd.dist import GradientAverager
+    torch.manual_seed(1)
+    net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
+    params = list(net.parameters())
+    b, roost = P.synthetic_batch(graphs, ATOMS, K_NBR, seed=rank)
+    b = b.to(device)
+    roost = tuple(t.to(device) for t in roost)
+    averager = GradientAverager(params) if world > 1 else None
+
+    def step():
+        if averager is not None:
+            averager.zero_grad()
+        else:
+            for p in params:
+                p.grad = None
+        out = net(b, roost)
+        loss = (out[:, 0] - b.y).abs().mean()              # L1 on the prediction column, as the harness' default
+        loss.backward()
+        if averager is not None:
+            averager.finish()
+    return step, b.num_nodes, b.edge_index.shape[1]
+
+
+# Executed-algorithmic work of ONE layer step (forward + backward) at N atoms, E edges, C = Ce = 128, H = 3, Hd = 256:
+# what the kernels compute after the algebra of DESIGN.md §3 (one product counted once, whatever number of matrix-core
+# passes the arithmetic mode spends on it).
+def layer_step_flops(N, E):
+    C, W2 = C_FEA, 2 * HEADS * 256
+    hyper = 12 * 2.0 * N * C ** 3                          # 4 forward + 4 fused-backward + 4 weight-gradient contractions
+    dense = 4 * 18 * 2.0 * N * C * C                       # per predicted layer: 6 dense 128x128 layers, x3 (fwd, dX, dW)
+    edge = 2.0 * E * (2 * C) * W2 + 2 * 2.0 * E * W2 * C   # per-edge pre-activations (K = Ce + C), g_e and dW_e products
+    node = 2.0 * N * C * W2 * (1 + 4) + 3 * 2 * 2.0 * N * (W2 // 2) * C   # Pi; g_x / dW_i / dW_j; fc_out of MH_M x3
+    return hyper + dense + edge + node
+
+
+def layer_step_bytes(N, E):
+    """(compulsory, executed) HBM bytes of one layer step: SURVEY 8(d)'s 4.0 KB per edge, and the Z-sized passes the
+    implementation actually makes (Z written once and read twice, gZ written once and read three times,
+    6 x [N, C] saved per predicted layer, operands of the contractions)."""
+    W2b = 2 * HEADS * 256 * 4
+    compulsory = 4.0e3 * E
+    executed = E * W2b * 7 + E * C_FEA * 4 * 6 + N * C_FEA * 4 * (4 * 6 * 3 + 4 * 12) + N * W2b * 6
+    return compulsory, executed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,7 +399,10 @@ def main():
     ap.add_argument("--no-exclusive-pass", action="store_true",
                     help="skip the 2-step serial pass after the timed region (exclusive durations of the kernels that "
                          "run concurrently); used for the rocprofv3 runs so that their averages cover the timed steps only")
-    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim"], default="layer",
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the untimed-for-`value` legs after the timed region (other arithmetic modes, full stack)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="--workload train: per-rank or total batch fixed")
+    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -238,7 +410,7 @@ def main():
     import torch.distributed as dist
     import cgat_amd as P
     from cgat_amd import ops
-    from cgat_amd.dist import GradientAverager, init_from_env
+    from cgat_amd.dist import init_from_env
 
     rank, world, device = init_from_env()
     if device.type != "cuda":
@@ -250,63 +422,34 @@ def main():
         return bench_collate(args, rank, world, device)
     if args.workload == "optim":
         return bench_optim(args, rank, world, device)
-    torch.manual_seed(1)                                   # identical parameters on every rank
-    if args.workload == "layer":
-        layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
-        params = list(layer.parameters())
-        ei, x, e, x0, cot = make_inputs(args.graphs, rank, device)     # each rank: its own crystals
-        N, E = x.shape[0], ei.shape[1]
-        x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
-        averager = GradientAverager(params) if world > 1 else None
+    if args.workload == "train":
+        return bench_train(args, rank, world, device)
 
-        def step():
-            for p in params:
-                p.grad = None
-            x.grad = e.grad = x0.grad = None
-            y = layer(x, ei, e, x0)
-            y.backward(cot)
-            if averager is not None:
-                averager.finish()
-    else:
-        net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
-        params = list(net.parameters())
-        b, roost = P.synthetic_batch(args.graphs, ATOMS, K_NBR, seed=rank)
-        b = b.to(device)
-        roost = tuple(t.to(device) for t in roost)
-        N, E = b.num_nodes, b.edge_index.shape[1]
-        averager = GradientAverager(params) if world > 1 else None
+    # CPU leg FIRST (rank 0, N = 1 only): the GPU leg that follows is then one contiguous block of device work
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
+        cpu = cpu_baseline()
 
-        def step():
-            for p in params:
-                p.grad = None
-            out = net(b, roost)
-            loss = (out[:, 0] - b.y).abs().mean()          # L1 on the prediction column, as the harness' default
-            loss.backward()
-            if averager is not None:
-                averager.finish()
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    make = make_layer_workload if args.workload == "layer" else make_stack_workload
+    step, N, E = make(args.graphs, rank, world, device)
 
     for _ in range(args.warmup):
         step()
-    fence()
+    _fence(world)
     ops.prof_reset()
     ops.prof_enable(True)                                  # HIP events around the kernel launches, on their stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    _fence(world)
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     ALL_TAGS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
                 "edge_gw", "rows_ge", "rows_gw", "linear128", "rows_dw", "gemm_f32")
     prof = {t: ops.prof_get(t) for t in ALL_TAGS}          # (launches, total ms) inside the timed region
-    # With the weight-gradient contractions on the side stream (the default), they and the attention-backward kernels
-    # they run beside share the chip, so their timed-region durations are not exclusive.  A short serial pass AFTER the
-    # timed region (not part of `value`) gives those kernels' exclusive durations; both are reported.
+    # With the weight-gradient contractions on the side stream they and the attention-backward kernels they run
+    # beside share the chip, so their timed-region durations are not exclusive.  A short serial pass AFTER the timed
+    # region (not part of `value`) gives those kernels' exclusive durations; both are reported.
     concurrent = ("bilinear_wgrad", "edge_seg_bwd", "edge_ge", "edge_gw", "rows_ge", "rows_gw") \
         if (ops.overlap_enabled() and not args.no_exclusive_pass) else ()
     prof_x = {}
@@ -316,7 +459,7 @@ def main():
         ops.prof_enable(True)
         for _ in range(2):
             step()
-        fence()
+        _fence(world)
         ops.prof_enable(False)
         prof_x = {t: ops.prof_get(t) for t in concurrent}
         ops.set_overlap_wgrad(True)
@@ -325,31 +468,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- extra legs (N = 1, after the timed region, never part of `value`): the same step in the two arithmetic modes
+    # whose operands carry >= 24 significand bits, and the full 4-layer stack of BASELINE configs[2] ----
+    mode = P.get_bilinear_mode()
+    modes_ms, stack_ms = {mode: 1e3 * elapsed / args.steps}, None
+    if world == 1 and not args.no_extra_legs and args.workload == "layer":
+        for m in ("f16x3", "bf16x6", "f32"):
+            if m == mode:
+                continue
+            P.set_bilinear_mode(m)
+            modes_ms[m] = 1e3 * _time_steps(step, 1, 5 if m != "f32" else 3, world) / (5 if m != "f32" else 3)
+        P.set_bilinear_mode(mode)
+        del step
+        torch.cuda.empty_cache()
+        sstep, _, _ = make_stack_workload(args.graphs, rank, world, device)
+        stack_ms = 1e3 * _time_steps(sstep, 1, 3, world) / 3
+        del sstep
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        # The three hypernetwork contraction kernels execute 2*N*C^3 flop per launch each (C*(C*C)*2
-        # per row; the fused backward kernel produces two gradients from ONE such contraction, so it is priced at
-        # what it executes, not at the two contractions the reference's autograd performs).  The roofline object is
-        # for the one with the largest share of the step.
-        flops_per_launch = 2.0 * N * C_FEA ** 3
-        mode = P.get_bilinear_mode()
-        kernels = {"bilinear_wgrad": "bilinear_wgrad128_bf16_kernel", "bilinear_dual": "bilinear_rows128_dual_kernel",
+        # The three hypernetwork contraction kernels execute 2*N*C^3 flop per launch and predicted layer each (SURVEY 8a
+        # a8.2: C*(C*C)*2 per row; the fused backward kernel produces two gradients from ONE such contraction, so it is
+        # priced at what it executes, not at the two contractions the reference's autograd performs).
+        flops_per_layer = 2.0 * N * C_FEA ** 3
+        kernels = {"bilinear_wgrad": "bilinear_wgrad128_f16p_kernel", "bilinear_dual": "bilinear_rows128_dual_kernel",
                    "bilinear_rows": "bilinear_rows128_ring16_kernel"}
+        layers_per_launch = {"bilinear_wgrad": 4, "bilinear_dual": 1, "bilinear_rows": 1}   # f16x3: one batched dT launch
         if mode == "f32":
             kernels = {"bilinear_wgrad": "bilinear_wgrad128_kernel", "bilinear_rows": "bilinear_rows128_kernel"}
-            peak = MFMA_F32_PEAK_TFLOPS
+            layers_per_launch["bilinear_wgrad"] = 1
+            peak, passes = MFMA_F32_PEAK_TFLOPS, 1
             note = "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32"
         elif mode == "f16x3":
             passes = 3
             peak = MFMA_BF16_PEAK_TFLOPS / passes          # dense fp16 matrix peak = the bf16 one (2500)
             note = ("fp32 operands scaled by a power of two (per row / per tensor) and split into 2 fp16 pieces (22 bits), "
-                    "3 v_mfma_f32_16x16x32_f16 passes per product, fp32 accumulate (measured at the error of an fp32 "
+                    "3 v_mfma_f32_*_f16 passes per product, fp32 accumulate (measured at the error of an fp32 "
                     f"product chain): executed MFMA flop = 3 x algorithmic, so the roof for ALGORITHMIC flop is the dense "
                     f"fp16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / 3; the f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
         else:
+            kernels["bilinear_wgrad"] = "bilinear_wgrad128_bf16_kernel"
+            layers_per_launch["bilinear_wgrad"] = 1
             passes = 6 if mode == "bf16x6" else 3
             peak = MFMA_BF16_PEAK_TFLOPS / passes
-            note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_16x16x32_bf16 passes per product, fp32 "
+            note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_*_bf16 passes per product, fp32 "
                     f"accumulate (measured fp32-equivalent accuracy): executed MFMA flop = {passes} x algorithmic, so the "
                     f"roof for ALGORITHMIC flop is the dense bf16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {passes}; the "
                     f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
@@ -361,34 +523,37 @@ def main():
             if not n_t:
                 continue
             avg_ms = ms_t / n_t
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            fl = flops_per_layer * layers_per_launch[tag]
+            ach = fl / (avg_ms * 1e-3) / 1e12
             per_kernel[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
                                # per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
                                "traffic": traffic.get(kname, {}).get("hbm_bytes_per_launch"),
                                "launches_per_step": n_t / args.steps, "avg_launch_ms": round(avg_ms, 4),
-                               "ms_per_step": round(ms_t / args.steps, 3), "flops_per_launch": flops_per_launch}
+                               "ms_per_step": round(ms_t / args.steps, 3), "flops_per_launch": fl}
         for tag in per_kernel:
             if tag in concurrent and prof_x.get(tag, (0, 0))[0]:
                 x_ms = prof_x[tag][1] / prof_x[tag][0]
-                x_ach = flops_per_launch / (x_ms * 1e-3) / 1e12
+                x_ach = per_kernel[tag]["flops_per_launch"] / (x_ms * 1e-3) / 1e12
                 per_kernel[tag]["concurrent"] = ("runs on the side stream on half of the CUs beside the HBM-bound attention "
                                                  "backward: the timed-region duration is shared; `exclusive` = the same "
                                                  "kernel alone on the chip, from a serial pass after the timed region")
                 per_kernel[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4), "achieved": round(x_ach, 2),
                                                 "frac": round(x_ach / peak, 4)}
         if per_kernel:
-            # the roofline object is for the contraction kernel with the largest share of the step's critical path
-            # (kernels that run concurrently on the side stream are listed beside it with both durations)
-            cands = [t for t in per_kernel if "concurrent" not in per_kernel[t]] or list(per_kernel)
-            dom = max(cands, key=lambda t: per_kernel[t]["ms_per_step"])
+            # the roofline object is for the kernel with the largest GPU time per step INSIDE the timed region, whatever
+            # stream it ran on; its `frac` is the in-region one (side-stream kernels also carry their exclusive numbers)
+            dom = max(per_kernel, key=lambda t: per_kernel[t]["ms_per_step"])
             roof = dict(per_kernel[dom])
             roof["arithmetic"] = note
             roof["other_contraction_kernels"] = {t: {k: v[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms",
                                                                         "ms_per_step", "traffic", "concurrent", "exclusive")
                                                      if k in v}
                                                  for t, v in per_kernel.items() if t != dom}
+            counters_file = os.path.join(ROOT, "profiles", "mfma_counters.json")
+            if os.path.exists(counters_file):              # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x clock x time)
+                roof["mfma_utilisation_from_counters"] = json.load(open(counters_file))
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
         W2b = 2 * HEADS * 256 * 4
@@ -422,11 +587,15 @@ def main():
                     shares[tag]["concurrent"] = True
         metric = ("edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch" if args.workload == "layer"
                   else "batch-edges/sec through the full CGAT stack (4 layers, fwd+bwd), 1M-edge batch [informational]")
+        dtype = {"f16x3": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
+                 "bf16x6": "f32 storage / bf16x6 split (24-bit operands, fp32 accumulate)",
+                 "bf16x3": "f32 storage / bf16x3 split (16-bit products; diagnostic mode)",
+                 "f32": "f32 (f32-input MFMA)"}[mode]
         out = {
             "metric": metric,
             "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "bilinear_mode": mode,
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
                                     f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention")
                        if args.workload == "layer" else
@@ -436,8 +605,27 @@ def main():
             "roofline": roof, "hbm_bound_kernels": hbm if args.workload == "layer" else None,
             "kernel_ms_per_step": shares,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
-            out["cpu_baseline"] = cpu_baseline()
+        if args.workload == "layer":
+            fl = layer_step_flops(N, E)
+            comp, execd = layer_step_bytes(N, E)
+            out["step_roofline"] = {
+                "what": "the whole step against both roofs: executed-algorithmic flop (each product once) over the step time "
+                        "vs the matrix roof of the arithmetic mode, and HBM bytes over the step time vs 8 TB/s",
+                "flop_per_step": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "tflops_peak": round(peak, 1),
+                "tflops_frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                "hbm_bytes_compulsory": int(comp), "hbm_frac_compulsory": round(comp / (ms * 1e-3) / 8e12, 4),
+                "hbm_bytes_executed": int(execd), "hbm_frac": round(execd / (ms * 1e-3) / 8e12, 4)}
+            out["modes"] = {"what": "ms per step of the same layer step in each arithmetic mode (this process, after the "
+                                    "timed region; `value` is the mode named in bilinear_mode)",
+                            **{m: round(v, 3) for m, v in modes_ms.items()},
+                            "edges_per_s": {m: round(E / (v * 1e-3), 1) for m, v in modes_ms.items()}}
+            if stack_ms is not None:
+                out["stack_fwd_bwd_ms"] = {"ms_per_step": round(stack_ms, 2), "batch_edges_per_s": round(E / (stack_ms * 1e-3), 1),
+                                           "edge_layer_passes_per_s": round(4 * E / (stack_ms * 1e-3), 1),
+                                           "what": "BASELINE configs[2]: CGAtNet(200,128,4,msg_heads=3) fwd+bwd of the L1 loss "
+                                                   "on the same 1M-edge batch, default arithmetic mode (3 steps after 1 warm-up)"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -108,6 +108,8 @@ def synthetic_dataset_dict(num_graphs, atoms_per_graph=20, stored_nbrs=24, seed=
     Used by bench.py --workload collate and the collation tests."""
     import numpy as np
     rs = np.random.RandomState(seed)
+    if isinstance(atoms_per_graph, (tuple, list)):
+        return _ragged_dataset_dict(rs, int(num_graphs), int(atoms_per_graph[0]), int(atoms_per_graph[1]), int(stored_nbrs))
     G, A, K = int(num_graphs), int(atoms_per_graph), int(stored_nbrs)
     z = rs.randint(0, N_ELEMENTS, size=(G, 1)) + rs.randint(0, 4, size=(G, A)) * 17
     z %= N_ELEMENTS
@@ -119,6 +121,27 @@ def synthetic_dataset_dict(num_graphs, atoms_per_graph=20, stored_nbrs=24, seed=
     for g in range(G):
         inp[0][g], inp[1][g], inp[2][g] = shell[g], centre[g], nbr[g]
         syms = [ELEMENT_SYMBOLS[k] for k in z[g]]
+        comps.append(syms)
+        formulas.append("".join(f"{el}{syms.count(el)}" for el in dict.fromkeys(syms)))
+    table = element_table().numpy()
+    emb = {el: table[k].astype("float64").tolist() for k, el in enumerate(ELEMENT_SYMBOLS)}
+    return {"input": inp, "comps": comps, "batch_comp": formulas,
+            "target": {"e_above_hull": rs.randn(G).round(4)}}, emb
+
+
+def _ragged_dataset_dict(rs, G, a_lo, a_hi, K):
+    """The DCGAT-shaped variant (BASELINE configs[3]): crystals of a_lo .. a_hi atoms (uniform), K stored neighbours per
+    atom with periodic images (an atom of a 2-atom cell has 24 neighbours among 2 atoms: multi-edges and self loops)."""
+    import numpy as np
+    inp = np.empty((3, G), dtype=object)
+    comps, formulas = [], []
+    for g in range(G):
+        A = int(rs.randint(a_lo, a_hi + 1))
+        z = (rs.randint(0, N_ELEMENTS) + rs.randint(0, 4, size=A) * 17) % N_ELEMENTS
+        inp[0][g] = (1 + np.cumsum(rs.rand(A, K) < 0.4, axis=1)).astype(np.int64)
+        inp[1][g] = np.broadcast_to(np.arange(A)[:, None], (A, K)).astype(np.int64)
+        inp[2][g] = rs.randint(0, A, size=(A, K)).astype(np.int64)
+        syms = [ELEMENT_SYMBOLS[k] for k in z]
         comps.append(syms)
         formulas.append("".join(f"{el}{syms.count(el)}" for el in dict.fromkeys(syms)))
     table = element_table().numpy()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-kernel sums of rocprofv3 --pmc counter_collection CSVs: python tools/counter_summary.py <dir> [<dir> ...]
+Prints kernel, launches, and the mean per launch of every counter found; with SQ_VALU_MFMA_BUSY_CYCLES and
+GRBM_GUI_ACTIVE in the same pass also the matrix-core utilisation busy / (GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def load(d):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k].add(r["Dispatch_Id"])
+    return acc, cnt
+
+
+def main():
+    out = {}
+    for d in sys.argv[1:]:
+        acc, cnt = load(d)
+        for k in sorted(acc, key=lambda k: -acc[k].get("GRBM_GUI_ACTIVE", acc[k].get("SQ_WAVE_CYCLES", 0))):
+            n = len(cnt[k])
+            row = {c: v / n for c, v in acc[k].items()}
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "GRBM_GUI_ACTIVE" in row and row["GRBM_GUI_ACTIVE"] > 0:
+                row["mfma_util"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (row["GRBM_GUI_ACTIVE"] / 8 * 1024)
+            out.setdefault(k, {"launches": n}).update(row)
+    for k, row in out.items():
+        print(k[:60].ljust(60), " ".join(f"{c}={v:.4g}" for c, v in row.items()))
+    if os.environ.get("COUNTER_JSON"):
+        json.dump(out, open(os.environ["COUNTER_JSON"], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
