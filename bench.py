@@ -33,11 +33,15 @@ MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input matri
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
-def make_inputs(graphs, seed, device):
+def make_inputs(graphs, seed, device, K=K_NBR):
     import cgat_amd as P
-    b, _ = P.synthetic_batch(graphs, ATOMS, K_NBR, seed=seed)
-    g = torch.Generator().manual_seed(1000 + seed)
+    b, _ = P.synthetic_batch(graphs, ATOMS, K, seed=seed)
     N, E = b.num_nodes, b.edge_index.shape[1]
+    if E > (8 << 20):                                      # the 64M-edge batch: features drawn on the device
+        g = torch.Generator(device=device).manual_seed(1000 + seed)
+        x, e, x0, cot = (torch.randn(n, C_FEA, generator=g, device=device) for n in (N, E, N, N))
+        return b.edge_index.to(device), x, e, x0, cot
+    g = torch.Generator().manual_seed(1000 + seed)
     x = torch.randn(N, C_FEA, generator=g).to(device)
     e = torch.randn(E, C_FEA, generator=g).to(device)
     x0 = torch.randn(N, C_FEA, generator=g).to(device)
@@ -316,14 +320,14 @@ def _time_steps(step, warmup, steps, world):
     return time.perf_counter() - t0
 
 
-def make_layer_workload(graphs, rank, world, device):
+def make_layer_workload(graphs, rank, world, device, K=K_NBR):
     """One GATConvNodes layer (non-first: H_Net with damping), forward + full backward."""
     import cgat_amd as P
     from cgat_amd.dist import GradientAverager
     torch.manual_seed(1)                                   # identical parameters on every rank
     layer = P.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True).to(device)
     params = list(layer.parameters())
-    ei, x, e, x0, cot = make_inputs(graphs, rank, device)  # each rank: its own crystals
+    ei, x, e, x0, cot = make_inputs(graphs, rank, device, K)  # each rank: its own crystals
     x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
     averager = GradientAverager(params) if world > 1 else None
 
@@ -402,7 +406,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the untimed-for-`value` legs after the timed region (other arithmetic modes, full stack)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="--workload train: per-rank or total batch fixed")
-    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train"], default="layer",
+    ap.add_argument("--nbrs", type=int, default=None, help="neighbours per atom (default 12; --workload stress: 64)")
+    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -430,8 +435,20 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
         cpu = cpu_baseline()
 
-    make = make_layer_workload if args.workload == "layer" else make_stack_workload
-    step, N, E = make(args.graphs, rank, world, device)
+    stress = args.workload == "stress"
+    K_used = args.nbrs or (64 if stress else K_NBR)
+    if stress:
+        # BASELINE configs[4]: 50 000 crystals x 20 atoms x 64 neighbours = 64 M edges through one layer, fwd + bwd, in
+        # closed chunks of <= 4 M edges (cgat_amd/chunked.py) so that the per-edge workspace stays bounded
+        if args.graphs == GRAPHS:
+            args.graphs = 50000
+        ops.set_validate_indices(False)
+        step, N, E = make_layer_workload(args.graphs, rank, world, device, K=K_used)
+    elif args.workload == "layer":
+        step, N, E = make_layer_workload(args.graphs, rank, world, device, K=K_used)
+    else:
+        step, N, E = make_stack_workload(args.graphs, rank, world, device)
+    layer_like = args.workload in ("layer", "stress")
 
     for _ in range(args.warmup):
         step()
@@ -472,7 +489,7 @@ def main():
     # whose operands carry >= 24 significand bits, and the full 4-layer stack of BASELINE configs[2] ----
     mode = P.get_bilinear_mode()
     modes_ms, stack_ms = {mode: 1e3 * elapsed / args.steps}, None
-    if world == 1 and not args.no_extra_legs and args.workload == "layer":
+    if world == 1 and not args.no_extra_legs and args.workload == "layer" and K_used == K_NBR:
         for m in ("f16x3", "bf16x6", "f32"):
             if m == mode:
                 continue
@@ -564,17 +581,23 @@ def main():
                    "edge_seg_bwd": E * 2 * W2b + N * (W2b + W2b // 2),       # Z read, gZ written, Gi written, gS read
                    "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
                    "edge_gw": E * (W2b + C_FEA * (4 if mode == "f16x3" else 6))}   # gZ read, fp16x2 / bf16x3 planes of e read
+        if stress:
+            hbm_alg["edge_z"] *= 2                          # forward + the backward's per-chunk recomputation
         hbm = {}
         for tag, nbytes in hbm_alg.items():
             n_t, ms_t = prof[tag]
             if n_t:
-                gbs = nbytes / (ms_t / n_t * 1e-3) / 1e9
-                hbm[tag] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(gbs / 8000.0, 4), "avg_launch_ms": round(ms_t / n_t, 4),
-                            "algorithmic_bytes_per_launch": int(nbytes)}
+                gbs = nbytes / (ms_t / args.steps * 1e-3) / 1e9      # bytes of the step / the tag's time in the step
+                hbm[tag] = {"bound": "hbm", "kernel": {"edge_z": "edge_zx_kernel" if mode == "f16x3" else "edge_z_kernel",
+                                                        "edge_seg_bwd": "edge_seg_bwd_kernel", "edge_ge": "edge_ge_kernel",
+                                                        "edge_gw": "edge_gw_kernel"}[tag],
+                            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(gbs / 8000.0, 4), "traffic": None, "launches_per_step": n_t / args.steps,
+                            "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
+                            "algorithmic_bytes_per_launch": int(nbytes / (n_t / args.steps))}
                 if tag in concurrent and prof_x.get(tag, (0, 0))[0]:
                     x_ms = prof_x[tag][1] / prof_x[tag][0]
-                    x_gbs = nbytes / (x_ms * 1e-3) / 1e9
+                    x_gbs = nbytes / (n_t / args.steps) / (x_ms * 1e-3) / 1e9
                     hbm[tag]["concurrent"] = "shares the chip with the side-stream contractions in the timed region"
                     hbm[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4), "achieved": round(x_gbs, 1),
                                              "frac": round(x_gbs / 8000.0, 4)}
@@ -585,7 +608,18 @@ def main():
                 shares[tag] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
                 if tag in concurrent:
                     shares[tag]["concurrent"] = True
+        if stress and hbm:
+            # K = 64: the hypernetwork (per atom) is 1/64 of an edge's share, the step is the HBM-bound edge phase
+            top = max(hbm, key=lambda t: hbm[t]["ms_per_step"])
+            if roof is None or hbm[top]["ms_per_step"] > roof["ms_per_step"]:
+                contr = roof
+                roof = dict(hbm[top])
+                roof["other_kernels"] = {t: v for t, v in hbm.items() if t != top}
+                if contr is not None:
+                    roof["contraction_kernels"] = {k: contr[k] for k in ("kernel", "achieved", "frac", "ms_per_step")}
         metric = ("edges/sec through one CGAT attention layer (fwd+bwd), 1M-edge batch" if args.workload == "layer"
+                  else "edges/sec through one CGAT attention layer (fwd+bwd), 64M-edge large-neighbour batch in closed "
+                       "chunks [BASELINE configs[4]]" if stress
                   else "batch-edges/sec through the full CGAT stack (4 layers, fwd+bwd), 1M-edge batch [informational]")
         dtype = {"f16x3": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
                  "bf16x6": "f32 storage / bf16x6 split (24-bit operands, fp32 accumulate)",
@@ -597,12 +631,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic", "bilinear_mode": mode,
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
-                                    f"{K_NBR} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention")
-                       if args.workload == "layer" else
+                                    f"{K_used} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention" +
+                                    (f", closed chunks of <= {P.chunked.max_edges_per_pass()} edges with per-chunk "
+                                     "recomputation in backward (2 forward + 1 backward passes per step)" if stress else ""))
+                       if layer_like else
                        (f"CGAtNet(200,128,4,msg_heads=3,update_edges=True) fwd+bwd of L1 loss, {args.graphs} crystals: "
                         f"N={N}, E={E}"),
                        "edges_per_rank": E, "parallelism": f"dp{world} (graphs sharded, gradient all-reduce)"},
-            "roofline": roof, "hbm_bound_kernels": hbm if args.workload == "layer" else None,
+            "roofline": roof, "hbm_bound_kernels": hbm if layer_like else None,
             "kernel_ms_per_step": shares,
         }
         if args.workload == "layer":

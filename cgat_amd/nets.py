@@ -14,7 +14,7 @@ import itertools
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, chunked
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
 from .ops import (EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
@@ -224,6 +224,15 @@ class GATConvNodes(nn.Module):
                                  m.fc_in.weight, m.fc_in.bias, m.fc_out.weight, m.fc_out.bias, *flat)
 
     def propagate(self, edge_index, x, edge_attr, x_0):
+        if edge_index.shape[1] > chunked.max_edges_per_pass():
+            # beyond the per-pass budget (BASELINE configs[4]: 64 M edges): closed chunks of the graph, one at a time
+            chunks = chunked.closed_chunks(edge_index, x.shape[0], chunked.max_edges_per_pass())
+            if len(chunks) > 1:
+                run = lambda xs, ei, es, x0s: self._propagate_one(ei, xs, es, x0s)
+                return chunked.ChunkedLayerFn.apply(run, chunks, x, edge_attr, x_0, *self.parameters())
+        return self._propagate_one(edge_index, x, edge_attr, x_0)
+
+    def _propagate_one(self, edge_index, x, edge_attr, x_0):
         plan = get_plan(edge_index, x.shape[0])
         if (ops_overlap_enabled() and not self.vector_attention and not self.final and not self.dropout and
                 type(self).message is GATConvNodes.message and type(self).update is GATConvNodes.update and

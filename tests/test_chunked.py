@@ -1,0 +1,173 @@
+"""Edge-chunked layer execution (BASELINE configs[4] / config 5: 64 neighbours per atom, 64 M edges): chunk discovery
+and the chunked autograd function on CPU (host logic, the oracle as the layer); on the GPU the K = 64 layer against the
+oracle, chunked == unchunked at 1 M edges, and crystal locality at 8 M edges."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_closed_chunks_partition_the_graph():
+    from cgat_amd import chunked
+    from cgat_amd.graph import synthetic_batch
+    b, _ = synthetic_batch(10, 6, 4, seed=1)
+    ch = chunked.closed_chunks(b.edge_index, b.num_nodes, 60)
+    assert ch[0].n0 == 0 and ch[-1].n1 == b.num_nodes and ch[0].e0 == 0 and ch[-1].e1 == b.edge_index.shape[1]
+    for a, c in zip(ch, ch[1:]):
+        assert a.n1 == c.n0 and a.e1 == c.e0
+    for c in ch:
+        assert c.e1 - c.e0 <= 60 and c.n0 % 6 == 0                       # whole crystals only
+        ei = b.edge_index[:, c.e0:c.e1]
+        assert int(ei.min()) >= c.n0 and int(ei.max()) < c.n1            # closed: no edge leaves the node range
+        assert torch.equal(c.edge_index, ei - c.n0)
+    # an edge between two "crystals" fuses them into one closed component (larger than the budget: kept whole)
+    ei = torch.tensor([[0, 0, 1, 2, 3, 3, 4, 5], [1, 3, 0, 3, 2, 2, 5, 4]])
+    ch = chunked.closed_chunks(ei, 6, 2)
+    assert [(c.n0, c.n1, c.e0, c.e1) for c in ch] == [(0, 4, 0, 6), (4, 6, 6, 8)]
+    with pytest.raises(NotImplementedError):
+        chunked.closed_chunks(torch.tensor([[1, 0], [0, 1]]), 2, 1)      # sources not ascending
+
+
+def test_chunked_function_equals_single_pass_on_cpu():
+    """ChunkedLayerFn with the oracle layer as `run`: outputs and every gradient equal the single pass."""
+    from cgat_amd import chunked
+    from cgat_amd.graph import synthetic_batch
+    from oracle import cgat_oracle as O
+    G, A, K, C = 6, 5, 7, 16
+    b, _ = synthetic_batch(G, A, K, seed=2)
+    g = torch.Generator().manual_seed(3)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0 = (torch.randn(n, C, generator=g).double() for n in (N, E, N))
+    torch.manual_seed(1)
+    layer = O.GATConvNodes(C, C, C, 3, concat=True).double()
+    params = list(layer.parameters())
+    cot = torch.randn(N, C, generator=g).double()
+    ins = [t.clone().requires_grad_(True) for t in (x, e, x0)]
+    y1 = layer(ins[0], b.edge_index, ins[1], ins[2])
+    g1 = torch.autograd.grad((y1 * cot).sum(), ins + params, allow_unused=True)
+    chunks = chunked.closed_chunks(b.edge_index, N, 2 * A * K)
+    assert len(chunks) == 3
+    ins2 = [t.clone().requires_grad_(True) for t in (x, e, x0)]
+    run = lambda xs, ei, es, x0s: layer(xs, ei, es, x0s)
+    y2 = chunked.ChunkedLayerFn.apply(run, chunks, ins2[0], ins2[1], ins2[2], *params)
+    g2 = torch.autograd.grad((y2 * cot).sum(), ins2 + params, allow_unused=True)
+    assert float((y1 - y2).abs().max()) <= 1e-12
+    for a, c in zip(g1, g2):
+        assert (a is None) == (c is None)
+        if a is not None:
+            assert float((a - c).abs().max()) <= 1e-10 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.gpu
+def test_config5_k64_layer_vs_oracle_chunked():
+    """Config 5 shape at a size the oracle finishes in seconds: 64 neighbours per atom (in-degree ~64: segments far
+    longer than at K = 12), C = Ce = 128, H = 3, run in 3 closed chunks, against the oracle (fp32 tolerance 1e-4)."""
+    import cgat_amd as P
+    from cgat_amd import chunked
+    from oracle import cgat_oracle as O
+    from test_hip_golden import _compare_with_oracle
+    b, _ = P.synthetic_batch(6, 20, 64, seed=41)
+    g = torch.Generator().manual_seed(42)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    old = chunked.max_edges_per_pass()
+    chunked.set_max_edges_per_pass(2 * 20 * 64)
+    try:
+        _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True),
+                             lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
+    finally:
+        chunked.set_max_edges_per_pass(old)
+
+
+@pytest.mark.gpu
+def test_config5_chunked_equals_unchunked_at_1m_edges():
+    """814 crystals x 20 atoms x 64 neighbours = 1 041 920 edges: the layer in closed chunks of <= 262 144 edges against
+    the single pass -- outputs and all gradients to 1e-5 (only the summation order of the parameter gradients and the
+    tile boundaries differ)."""
+    import cgat_amd as P
+    from cgat_amd import chunked
+    dev = "cuda:0"
+    b, _ = P.synthetic_batch(814, 20, 64, seed=43)
+    g = torch.Generator().manual_seed(44)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0, cot = (torch.randn(n, 128, generator=g).to(dev) for n in (N, E, N, N))
+    ei = b.edge_index.to(dev)
+    torch.manual_seed(1)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    params = list(layer.parameters())
+
+    def run():
+        ins = [t.clone().requires_grad_(True) for t in (x, e, x0)]
+        y = layer(ins[0], ei, ins[1], ins[2])
+        return y.detach(), torch.autograd.grad((y * cot).sum(), ins + params)
+    old = chunked.max_edges_per_pass()
+    try:
+        chunked.set_max_edges_per_pass(1 << 30)
+        y1, g1 = run()
+        chunked.set_max_edges_per_pass(262144)
+        assert len(chunked.closed_chunks(ei, N, 262144)) >= 4
+        y2, g2 = run()
+    finally:
+        chunked.set_max_edges_per_pass(old)
+    assert float((y1 - y2).abs().max()) <= 1e-5 * float(y1.abs().max())
+    scale = max(float(a.abs().max()) for a in g1)
+    for k, (a, c) in enumerate(zip(g1, g2)):
+        assert float((a - c).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3 * scale), k
+
+
+@pytest.mark.gpu
+def test_config5_locality_at_8m_edges():
+    """6250 crystals x 20 atoms x 64 neighbours = 8 M edges in chunks of 2 M: perturbing one crystal's inputs changes
+    that crystal's outputs and input gradients and nobody else's (crystals never share an edge; a chunking bug --
+    a chunk that cuts a crystal, an off-by-one slice -- would leak)."""
+    import cgat_amd as P
+    from cgat_amd import chunked
+    dev = "cuda:0"
+    G, A, K = 6250, 20, 64
+    b, _ = P.synthetic_batch(G, A, K, seed=45)
+    g = torch.Generator(device=dev).manual_seed(46)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0, cot = (torch.randn(n, 128, generator=g, device=dev) for n in (N, E, N, N))
+    ei = b.edge_index.to(dev)
+    torch.manual_seed(1)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+
+    def run(xx, ee):
+        xx, ee = xx.clone().requires_grad_(True), ee.clone().requires_grad_(True)
+        y = layer(xx, ei, ee, x0)
+        gx, ge = torch.autograd.grad((y * cot).sum(), [xx, ee])
+        return y.detach(), gx, ge
+    old = chunked.max_edges_per_pass()
+    chunked.set_max_edges_per_pass(2 << 20)
+    try:
+        y1, gx1, ge1 = run(x, e)
+        c = 3333                                                          # a crystal in the middle of a chunk
+        x2, e2 = x.clone(), e.clone()
+        x2[c * A:(c + 1) * A] += 1.0
+        e2[c * A * K:(c + 1) * A * K] *= 1.5
+        y2, gx2, ge2 = run(x2, e2)
+    finally:
+        chunked.set_max_edges_per_pass(old)
+    assert torch.isfinite(y1).all() and torch.isfinite(gx1).all() and torch.isfinite(ge1).all()
+    # "unchanged" to 1e-5 of the tensor's max-norm, not bitwise: the fp16-split kernels scale some operands by one
+    # power of two per tensor, which the perturbed crystal may move for its whole chunk
+    def same(a, c):
+        return float((a - c).abs().max()) <= 1e-5 * float(a.abs().max())
+    mask = torch.ones(N, dtype=torch.bool, device=dev)
+    mask[c * A:(c + 1) * A] = False
+    assert same(y1[mask], y2[mask]) and same(gx1[mask], gx2[mask])
+    assert not same(y1[~mask], y2[~mask])
+    emask = torch.ones(E, dtype=torch.bool, device=dev)
+    emask[c * A * K:(c + 1) * A * K] = False
+    assert same(ge1[emask], ge2[emask])
+    # the other chunks do not see the perturbed crystal at all: bit-identical there
+    far = torch.zeros(N, dtype=torch.bool, device=dev)
+    far[:1000 * A] = True
+    assert torch.equal(y1[far], y2[far]) and torch.equal(gx1[far], gx2[far])
