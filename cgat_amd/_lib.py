@@ -110,6 +110,10 @@ PROTOTYPES = {
     "cgat_segment_softmax_forward": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "cgat_segment_softmax_backward": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp]),
     "cgat_segment_sum": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, C.c_int64, vp]),
+    "cgat_segment_attention_pool_forward": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, C.c_float,
+                                                      vp, vp, vp, vp]),
+    "cgat_segment_attention_pool_backward": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, vp,
+                                                       vp, vp, vp, C.c_int64, vp, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
     "cgat_set_bilinear_mode": (None, [C.c_int32]),

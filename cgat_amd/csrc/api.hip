@@ -196,6 +196,20 @@ extern "C" int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx
   return seg_wsum_launch(x, ldx, ridx, nullptr, 0, 1, rowptr, S, F, CGAT_ACT_NONE, out, ldo, (hipStream_t)stream);
 }
 
+extern "C" int cgat_segment_attention_pool_forward(const float* a, int32_t aF, const float* mult, const float* m,
+                                                   int64_t ldm, const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F,
+                                                   float eps, float* out, float* mx, float* inv, void* stream) {
+  return seg_attnpool_fwd_launch(a, aF, mult, m, ldm, rowptr, ridx, S, F, eps, out, mx, inv, (hipStream_t)stream);
+}
+extern "C" int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float* mult, const float* m,
+                                                    int64_t ldm, const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F,
+                                                    const float* out, const float* mx, const float* inv,
+                                                    const float* g_out, float* g_a, float* g_m, int64_t ldgm,
+                                                    float* g_mult, void* stream) {
+  return seg_attnpool_bwd_launch(a, aF, mult, m, ldm, rowptr, ridx, S, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult,
+                                 (hipStream_t)stream);
+}
+
 // ---- kernel-level primitives ----
 static GemmParams from_desc(const cgat_gemm_desc* d) {
   GemmParams g = gemm_params(d->M, d->N, d->K, d->A, d->lda, d->B, d->ldb, d->C, d->ldc);

@@ -154,6 +154,9 @@ int csr_from_keys_launch(const int* keys, int n, int S, int* rowptr, int* perm, 
   }
   CGAT_HIP(hipMemsetAsync(count, 0, ((size_t)S + 1) * 4, s));
   CGAT_HIP(hipMemsetAsync(cursor, 0, ((size_t)S + 1) * 4, s));
+  // keys outside [0, S) leave the tail of perm unfilled; the gathers that consume it before the caller has looked at
+  // rowptr[S] must still read valid indices
+  if (n > 0) CGAT_HIP(hipMemsetAsync(perm, 0, (size_t)n * 4, s));
   if (n > 0) {
     hipLaunchKernelGGL(hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, keys, n, S, count);
     CGAT_LAUNCH_CHECK();

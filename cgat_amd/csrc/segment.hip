@@ -223,3 +223,185 @@ int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, c
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Softmax-weighted segment sum in ONE pass per direction ("attention pooling"):
+//     out[s, f] = sum_{r in seg s} alpha[r, f / fw] * m[r, f],
+//     alpha[r, c] = mult[r] * exp(a[r, c] - max_seg a[., c]) / (sum_seg mult * exp(...) + eps)
+// The three places of the reference that compute it as softmax -> multiply -> scatter_add over [rows, F] tensors:
+//   * GATConvNodes with vector attention (CGAT.py:323-329: one logit per head AND channel, aF = F, fw = 1),
+//   * MHAttention, the per-crystal pooling (CGAT.py:59-61: aF = heads, fw = C, or aF = F for global_vector_attention),
+//   * Roost's WeightedAttention (roost_message.py:305-317: aF = 1, fw = C, mult = weights ** pow, eps = 1e-13).
+// Forward keeps per (segment, logit column) the maximum and 1 / (sum + eps) instead of alpha[rows, aF]; backward
+// recomputes alpha from them:  g_m = alpha * g_out,  g_a[r, c] = sum_{f in c} alpha * g_out * (m - out),
+// g_mult[r] = g_a[r, 0] / mult[r]  (aF == 1).  One workgroup per segment, four consecutive features per thread, rows
+// in CSR order (row r of the segment is ridx[r] of the operands when ridx is given, so callers whose rows are not
+// grouped pass the plan's permutation instead of gathering), U of them in flight; no atomics, fixed summation order.
+// ---------------------------------------------------------------------------------------
+#define AP_U 4
+template <bool PER_F>   // PER_F: one logit column per feature (fw == 1); else fw % 4 == 0
+__global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __restrict__ a, int aF, int fw,
+                                                                const float* __restrict__ mult,
+                                                                const float* __restrict__ m, long ldm,
+                                                                const int* __restrict__ rowptr,
+                                                                const int* __restrict__ ridx, int F, float eps,
+                                                                float* __restrict__ out, float* __restrict__ mx_out,
+                                                                float* __restrict__ inv_out) {
+  const int s = blockIdx.x;
+  const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
+    const int ac = PER_F ? f : f / fw;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = r0; r < r1; ++r) {
+      const long row = ridx ? (long)ridx[r] : (long)r;
+      if (PER_F) {
+        const float4 v = *reinterpret_cast<const float4*>(a + row * aF + ac);
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+      } else {
+        mx.x = fmaxf(mx.x, a[row * aF + ac]);
+      }
+    }
+    if (!PER_F) mx.y = mx.z = mx.w = mx.x;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f), acc = z;
+    for (int r = r0; r < r1; r += AP_U) {
+      float4 av[AP_U], mv[AP_U];
+      float wv[AP_U];
+#pragma unroll
+      for (int u = 0; u < AP_U; ++u) {
+        const int rs = r + u < r1 ? r + u : r1 - 1;
+        const long rr = ridx ? (long)ridx[rs] : (long)rs;
+        if (PER_F) av[u] = *reinterpret_cast<const float4*>(a + rr * aF + ac);
+        else av[u].x = a[rr * aF + ac];
+        mv[u] = *reinterpret_cast<const float4*>(m + rr * ldm + f);
+        wv[u] = mult ? mult[rr] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < AP_U; ++u) {
+        if (r + u < r1) {
+          float4 e;
+          e.x = expf(av[u].x - mx.x) * wv[u];
+          if (PER_F) { e.y = expf(av[u].y - mx.y) * wv[u]; e.z = expf(av[u].z - mx.z) * wv[u]; e.w = expf(av[u].w - mx.w) * wv[u]; }
+          else e.y = e.z = e.w = e.x;
+          z.x += e.x; z.y += e.y; z.z += e.z; z.w += e.w;
+          acc.x += e.x * mv[u].x; acc.y += e.y * mv[u].y; acc.z += e.z * mv[u].z; acc.w += e.w * mv[u].w;
+        }
+      }
+    }
+    const float4 inv = make_float4(1.f / (z.x + eps), 1.f / (z.y + eps), 1.f / (z.z + eps), 1.f / (z.w + eps));
+    *reinterpret_cast<float4*>(out + (long)s * F + f) = make_float4(acc.x * inv.x, acc.y * inv.y, acc.z * inv.z, acc.w * inv.w);
+    if (PER_F) {
+      *reinterpret_cast<float4*>(mx_out + (long)s * aF + ac) = mx;
+      *reinterpret_cast<float4*>(inv_out + (long)s * aF + ac) = inv;
+    } else if (f % fw == 0) {
+      mx_out[(long)s * aF + ac] = mx.x;
+      inv_out[(long)s * aF + ac] = inv.x;
+    }
+  }
+}
+
+// PER_F as above; otherwise the fw / 4 threads of a logit column are `grp` consecutive lanes of one wave (grp a power of
+// two <= 64) and their partial sums of g_a meet in a shuffle reduction
+template <bool PER_F>
+__global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __restrict__ a, int aF, int fw, int grp,
+                                                                const float* __restrict__ mult,
+                                                                const float* __restrict__ m, long ldm,
+                                                                const int* __restrict__ rowptr,
+                                                                const int* __restrict__ ridx, int F,
+                                                                const float* __restrict__ out,
+                                                                const float* __restrict__ mxs,
+                                                                const float* __restrict__ invs,
+                                                                const float* __restrict__ g_out,
+                                                                float* __restrict__ g_a, float* __restrict__ g_m,
+                                                                long ldgm, float* __restrict__ g_mult) {
+  const int s = blockIdx.x;
+  const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  // every thread of a wave runs the same number of iterations (F rounded up to whole groups by the launch), so the
+  // shuffles below are executed by all lanes
+  for (int f0 = 4 * threadIdx.x; f0 < ((F + 255) / 256) * 256; f0 += 4 * blockDim.x) {
+    const bool live = f0 < F;
+    const int f = live ? f0 : 0;
+    const int ac = PER_F ? f : f / fw;
+    float4 mx, inv;
+    if (PER_F) {
+      mx = *reinterpret_cast<const float4*>(mxs + (long)s * aF + ac);
+      inv = *reinterpret_cast<const float4*>(invs + (long)s * aF + ac);
+    } else {
+      mx.x = mxs[(long)s * aF + ac]; inv.x = invs[(long)s * aF + ac];
+      mx.y = mx.z = mx.w = mx.x; inv.y = inv.z = inv.w = inv.x;
+    }
+    const float4 o4 = *reinterpret_cast<const float4*>(out + (long)s * F + f);
+    const float4 go = *reinterpret_cast<const float4*>(g_out + (long)s * F + f);
+    for (int rs = r0; rs < r1; ++rs) {
+      const long r = ridx ? (long)ridx[rs] : (long)rs;
+      const float w = mult ? mult[r] : 1.f;
+      float4 av;
+      if (PER_F) av = *reinterpret_cast<const float4*>(a + r * aF + ac);
+      else { av.x = a[r * aF + ac]; av.y = av.z = av.w = av.x; }
+      const float4 mv = *reinterpret_cast<const float4*>(m + r * ldm + f);
+      float4 al;
+      al.x = expf(av.x - mx.x) * w * inv.x;
+      if (PER_F) { al.y = expf(av.y - mx.y) * w * inv.y; al.z = expf(av.z - mx.z) * w * inv.z; al.w = expf(av.w - mx.w) * w * inv.w; }
+      else al.y = al.z = al.w = al.x;
+      const float4 gm = make_float4(al.x * go.x, al.y * go.y, al.z * go.z, al.w * go.w);
+      const float4 t = make_float4(gm.x * (mv.x - o4.x), gm.y * (mv.y - o4.y), gm.z * (mv.z - o4.z), gm.w * (mv.w - o4.w));
+      if (live && g_m) *reinterpret_cast<float4*>(g_m + r * ldgm + f) = gm;
+      if (PER_F) {
+        if (live) *reinterpret_cast<float4*>(g_a + r * aF + ac) = t;
+      } else {
+        float p = live ? (t.x + t.y) + (t.z + t.w) : 0.f;
+        for (int o = grp >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (live && (threadIdx.x & (grp - 1)) == 0) {
+          g_a[r * aF + ac] = p;
+          if (g_mult) g_mult[r] = w != 0.f ? p / w : 0.f;
+        }
+      }
+    }
+  }
+}
+
+static bool attnpool_ok(int aF, int F, long ldm, const void* a, const void* m, const void* out) {
+  if (F <= 0 || aF <= 0 || F % aF != 0 || F % 4 != 0 || ldm % 4 != 0) return false;
+  if (((((uintptr_t)m) | ((uintptr_t)out)) & 15) != 0) return false;
+  const int fw = F / aF;
+  if (fw == 1) return (aF % 4) == 0 && (((uintptr_t)a) & 15) == 0;
+  const int grp = fw / 4;
+  return fw % 4 == 0 && grp <= 64 && (grp & (grp - 1)) == 0;
+}
+bool seg_attnpool_fast(int aF, int F, long ldm, const void* a, const void* m, const void* out) {
+  return attnpool_ok(aF, F, ldm, a, m, out);
+}
+static int attnpool_threads(int F) {
+  int t = ((F / 4 + 63) / 64) * 64;
+  return t > 1024 ? 1024 : t;
+}
+int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
+                            const int* ridx, int S, int F, float eps, float* out, float* mx, float* inv, hipStream_t s) {
+  if (S <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out), "segment_attention_pool: unsupported shape (F=%d, aF=%d)", F, aF);
+  const int fw = F / aF;
+  if (fw == 1)
+    hipLaunchKernelGGL(seg_attnpool_fwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, mult, m, ldm,
+                       rowptr, ridx, F, eps, out, mx, inv);
+  else
+    hipLaunchKernelGGL(seg_attnpool_fwd_kernel<false>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, mult, m, ldm,
+                       rowptr, ridx, F, eps, out, mx, inv);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+int seg_attnpool_bwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
+                            const int* ridx, int S, int F, const float* out, const float* mx, const float* inv, const float* g_out, float* g_a,
+                            float* g_m, long ldgm, float* g_mult, hipStream_t s) {
+  if (S <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out) && ldgm % 4 == 0 && (!g_m || (((uintptr_t)g_m) & 15) == 0),
+                 "segment_attention_pool backward: unsupported shape (F=%d, aF=%d)", F, aF);
+  CGAT_CHECK_ARG(!g_mult || aF == 1, "segment_attention_pool backward: gradient of the multiplier needs one logit column");
+  const int fw = F / aF;
+  if (fw == 1)
+    hipLaunchKernelGGL(seg_attnpool_bwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, 1, mult, m, ldm,
+                       rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult);
+  else
+    hipLaunchKernelGGL(seg_attnpool_bwd_kernel<false>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, fw / 4, mult, m,
+                       ldm, rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}

@@ -113,7 +113,7 @@ def synthetic_dataset_dict(num_graphs, atoms_per_graph=20, stored_nbrs=24, seed=
     G, A, K = int(num_graphs), int(atoms_per_graph), int(stored_nbrs)
     z = rs.randint(0, N_ELEMENTS, size=(G, 1)) + rs.randint(0, 4, size=(G, A)) * 17
     z %= N_ELEMENTS
-    shell = (1 + np.cumsum(rs.rand(G, A, K) < 0.4, axis=2)).astype(np.int64)
+    shell = np.minimum(1 + np.cumsum(rs.rand(G, A, K) < 0.4, axis=2), 12).astype(np.int64)   # shell ids clamped as prepare_data.py:163-169
     centre = np.broadcast_to(np.arange(A)[None, :, None], (G, A, K)).astype(np.int64)
     nbr = rs.randint(0, A, size=(G, A, K)).astype(np.int64)
     inp = np.empty((3, G), dtype=object)
@@ -138,7 +138,7 @@ def _ragged_dataset_dict(rs, G, a_lo, a_hi, K):
     for g in range(G):
         A = int(rs.randint(a_lo, a_hi + 1))
         z = (rs.randint(0, N_ELEMENTS) + rs.randint(0, 4, size=A) * 17) % N_ELEMENTS
-        inp[0][g] = (1 + np.cumsum(rs.rand(A, K) < 0.4, axis=1)).astype(np.int64)
+        inp[0][g] = np.minimum(1 + np.cumsum(rs.rand(A, K) < 0.4, axis=1), 12).astype(np.int64)
         inp[1][g] = np.broadcast_to(np.arange(A)[:, None], (A, K)).astype(np.int64)
         inp[2][g] = rs.randint(0, A, size=(A, K)).astype(np.int64)
         syms = [ELEMENT_SYMBOLS[k] for k in z]

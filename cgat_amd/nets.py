@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib, chunked
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
+from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -71,9 +71,7 @@ class MHAttention(nn.Module):
         m = self.MH_M(fea)                                                         # [N,H,C]
         pair = torch.cat([fea, gather_rows(cry_fea, index, plan)], dim=1)          # == stack+transpose+reshape, 55-58
         alpha = self.MH_A(pair)                                                    # [N,H,1|C]
-        n = alpha.shape[0]
-        alpha = segment_softmax(alpha.reshape(n, -1), plan, eps=1e-16).reshape(alpha.shape)
-        return segment_sum((alpha * m).reshape(n, self.heads * self.out_channels), plan, index)
+        return attention_pool(alpha, m, plan, index, eps=1e-16)                    # softmax over the crystal, x m, summed
 
 
 def _edge_hidden(in_channels, nbr_channels):
@@ -188,9 +186,14 @@ class GATConvNodes(nn.Module):
 
         # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
         sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co)
-        alpha = SegmentSoftmaxFn.apply(sa.reshape(E, -1), None, plan.dst_rowptr, 1e-16)
-        msg = sm.reshape(E, -1) * alpha
-        agg = SegmentSumFn.apply(msg, plan.dst_rowptr, plan.dst_sorted.long())
+        sa2, sm2 = sa.reshape(E, -1), sm.reshape(E, -1)
+        if E > 0 and AttentionPoolFn.supported(sa2, sm2):
+            # channel-wise softmax over each atom's incoming edges, times the message, summed per atom: one kernel per
+            # direction (csrc/segment.hip), no alpha / alpha*message tensors of [E, H*C]
+            agg = AttentionPoolFn.apply(sa2, None, sm2, plan.dst_rowptr, None, 1e-16)
+        else:
+            alpha = SegmentSoftmaxFn.apply(sa2, None, plan.dst_rowptr, 1e-16)
+            agg = SegmentSumFn.apply(sm2 * alpha, plan.dst_rowptr, plan.dst_sorted.long())
         return agg.reshape(plan.N, H, Co).mean(dim=1)
 
     # -- MessagePassing-style surface (subclasses overriding message) --

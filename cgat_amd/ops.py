@@ -640,6 +640,73 @@ class SegmentSumFn(torch.autograd.Function):
         return g.index_select(0, seg_of_row), None, None
 
 
+class AttentionPoolFn(torch.autograd.Function):
+    """out[s, f] = sum_{r in seg s} alpha[r, f // fw] * m[r, f] with alpha = mult * exp(a - segmax) / (segsum + eps) -- the
+    reference's softmax -> multiply -> scatter_add (CGAT.py:323-329, 59-61; roost_message.py:305-317) as one kernel per
+    direction.  `a` [R, aF], `m` [R, F] (fw = F // aF), `mult` [R] or None; `perm` = rows of each segment in CSR order
+    (None: the rows already are), so nothing is gathered or permuted."""
+
+    @staticmethod
+    def supported(a, m):
+        aF, F = a.shape[1], m.shape[1]
+        if F % 4 or F % aF or not (a.is_cuda and a.dtype == torch.float32 and m.dtype == torch.float32):
+            return False
+        fw = F // aF
+        return (fw == 1 and aF % 4 == 0) or (fw % 4 == 0 and fw // 4 <= 64 and (fw // 4) & (fw // 4 - 1) == 0)
+
+    @staticmethod
+    def forward(ctx, a, mult, m, rowptr, perm, eps):
+        _require_gpu(a, m, rowptr)
+        a, m = _f32c(a), _f32c(m)
+        mu = None if mult is None else _f32c(mult.reshape(-1))
+        R, aF = a.shape
+        F = m.shape[1]
+        S = rowptr.numel() - 1
+        dev = a.device
+        out = torch.empty(S, F, dtype=torch.float32, device=dev)
+        mx = torch.empty(S, aF, dtype=torch.float32, device=dev)
+        inv = torch.empty(S, aF, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_segment_attention_pool_forward(_ptr(a), aF, _ptr(mu), _ptr(m), F, _ptr(rowptr), _ptr(perm), S, F,
+                                                          eps, _ptr(out), _ptr(mx), _ptr(inv), _stream()),
+                  "cgat_segment_attention_pool_forward")
+        ctx.has_mu, ctx.has_perm, ctx.mshape = mu is not None, perm is not None, None if mult is None else mult.shape
+        ctx.save_for_backward(a, m, out, mx, inv, rowptr, *([mu] if mu is not None else []), *([perm] if perm is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        a, m, out, mx, inv, rowptr, *rest = ctx.saved_tensors
+        mu = rest.pop(0) if ctx.has_mu else None
+        perm = rest.pop(0) if ctx.has_perm else None
+        g_out = _f32c(g_out)
+        R, aF = a.shape
+        F = m.shape[1]
+        S = rowptr.numel() - 1
+        g_a = torch.empty_like(a)
+        g_m = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        g_mu = torch.empty_like(mu) if (mu is not None and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device(a.device):
+            check(lib.cgat_segment_attention_pool_backward(_ptr(a), aF, _ptr(mu), _ptr(m), F, _ptr(rowptr), _ptr(perm), S, F,
+                                                           _ptr(out), _ptr(mx), _ptr(inv), _ptr(g_out), _ptr(g_a), _ptr(g_m),
+                                                           F, _ptr(g_mu), _stream()),
+                  "cgat_segment_attention_pool_backward")
+        return g_a, (None if g_mu is None else g_mu.reshape(ctx.mshape)), g_m, None, None, None
+
+
+def attention_pool(a, m, index_plan, index, mult=None, eps=1e-16):
+    """softmax(a over the segments of index) * m, summed per segment: rows in their ORIGINAL order, `index_plan` the
+    SegmentPlan of `index`.  One launch per direction when the shape allows, the generic three-step path otherwise."""
+    n = a.shape[0]
+    a2, m2 = a.reshape(n, -1), m.reshape(n, -1)
+    if n > 0 and AttentionPoolFn.supported(a2, m2) and (mult is None or a2.shape[1] == 1):
+        return AttentionPoolFn.apply(a2, mult, m2, index_plan.rowptr, index_plan.perm, eps)
+    alpha = segment_softmax(a2, index_plan, mult=mult, eps=eps)
+    fw = m2.shape[1] // a2.shape[1]
+    w = alpha if fw == 1 else alpha.repeat_interleave(fw, dim=1)
+    return segment_sum(w * m2, index_plan, index)
+
+
 class GatherRowsFn(torch.autograd.Function):
     """x[index] whose backward is an atomics-free segment sum over the index's CSR plan
     (deterministic, unlike index_add)."""

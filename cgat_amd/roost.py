@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .mlp import SimpleNetwork
-from .ops import SegmentPlan, gather_rows, segment_softmax, segment_sum
+from .ops import SegmentPlan, attention_pool, gather_rows
 
 
 class WeightedAttention(nn.Module):
@@ -22,9 +22,9 @@ class WeightedAttention(nn.Module):
             n = int(index.max()) + 1 if dim_size is None else dim_size   # reference: scatter's implicit size
             plan = SegmentPlan(index, n)
         gate = self.gate_nn(fea)                                                       # [M,1]
-        gate = segment_softmax(gate, plan, mult=weights ** self.pow, eps=1e-13)        # 307-311
         fea = self.message_nn(fea)
-        return segment_sum(gate * fea, plan, index)                                    # 315
+        # (weights ** pow) * exp(gate - segmax) / (segsum + 1e-13), times the message, summed per segment (305-317)
+        return attention_pool(gate, fea, plan, index, mult=weights ** self.pow, eps=1e-13)
 
     def __repr__(self):
         return '{}(gate_nn={})'.format(self.__class__.__name__, self.gate_nn)

@@ -254,6 +254,23 @@ int cgat_segment_softmax_backward(const float* alpha, const float* g_alpha, cons
 int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx, const int32_t* rowptr, int32_t S, int32_t F,
                      float* out, int64_t ldo, void* stream);
 
+/* Softmax-weighted segment sum ("attention pooling") in one pass per direction, rows in CSR order:
+ *   out[s,f] = sum_{r in seg s} alpha[r, f/fw] * m[r,f],  fw = F / aF,
+ *   alpha[r,c] = mult[r] * exp(a[r,c] - max_seg a[.,c]) / (sum_seg mult * exp(..) + eps)      (mult may be NULL)
+ * = torch_geometric softmax (+1e-16) -> multiply -> scatter_add of reference CGAT.py:323-329 (vector attention:
+ * aF = F), CGAT.py:59-61 (MHAttention: aF = heads) and roost_message.py:305-317 (WeightedAttention: aF = 1,
+ * mult = weights ** pow, eps = 1e-13).  mx / inv [S, aF] (segment maximum, 1 / (sum + eps)) are what backward needs
+ * instead of alpha.  Row r of a segment is row ridx[r] of a / mult / m (and of the gradients) when ridx != NULL.  Needs F % 4 == 0 and aF == F (aF % 4 == 0) or F / aF in {4, 8, .., 256} (a power of two). */
+int cgat_segment_attention_pool_forward(const float* a, int32_t aF, const float* mult, const float* m, int64_t ldm,
+                                        const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F, float eps, float* out, float* mx,
+                                        float* inv, void* stream);
+/* g_m[r,f] = alpha * g_out[s,f];  g_a[r,c] = sum_{f in c} alpha * g_out * (m - out);  g_mult[r] = g_a[r,0] / mult[r]
+ * (aF == 1; g_m / g_mult may be NULL) */
+int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float* mult, const float* m, int64_t ldm,
+                                         const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F, const float* out, const float* mx,
+                                         const float* inv, const float* g_out, float* g_a, float* g_m, int64_t ldgm,
+                                         float* g_mult, void* stream);
+
 /* ---- kernel-level primitives (what the layer entry points above are composed of) --------- */
 /* C = act(alpha * A.B + bias + add1[add1_idx[m]] + add2[add2_idx[m]]) + beta * C on the fp32 matrix
  * cores.  A(m,k) = A[row(m)*lda + k] (a_kmajor=0, row(m)=a_rgather?a_rgather[m]:m) or A[k*lda + m]

@@ -119,7 +119,9 @@ def test_config5_chunked_equals_unchunked_at_1m_edges():
     assert float((y1 - y2).abs().max()) <= 1e-5 * float(y1.abs().max())
     scale = max(float(a.abs().max()) for a in g1)
     for k, (a, c) in enumerate(zip(g1, g2)):
-        assert float((a - c).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3 * scale), k
+        # 1e-5 of the tensor, or fp32 resolution of the layer's largest gradient (MH_A.fc_out.bias is zero by softmax
+        # shift invariance: its value is rounding noise at that scale in any summation order)
+        assert float((a - c).abs().max()) <= max(1e-5 * float(a.abs().max()), 1e-6 * scale), k
 
 
 @pytest.mark.gpu

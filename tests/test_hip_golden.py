@@ -190,6 +190,46 @@ def test_ragged_graphs_fast_widths_vs_oracle():
                          lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
 
 
+def _ragged_k24(n_crystals, seed):
+    rs = np.random.RandomState(seed)
+    sizes = rs.randint(2, 41, size=n_crystals).tolist()
+    return recipe.build_graphs(sizes, K=24, species_per_graph=rs.randint(1, 5, size=n_crystals).tolist(), seed=seed + 1)
+
+
+def test_lightning_default_layer_vs_oracle():
+    """The layer shape the reference harness ships by default (lightning_module.py:427-593): C = Ce = 128, msg_heads = 5,
+    max_nbr = 24, vector_attention = True, on ragged crystals (2..40 atoms) -- at width 128, i.e. on the fast routes
+    (operand-split first layer, per-head second layers, one-kernel channel-wise softmax + weighted sum)."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = _ragged_k24(14, 51)
+    g = torch.Generator().manual_seed(52)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 5, concat=True, vector_attention=True),
+                         lambda: O.GATConvNodes(128, 128, 128, 5, concat=True, vector_attention=True), inputs, call)
+
+
+def test_lightning_default_stack_vs_oracle():
+    """The whole network as the reference harness builds it by default (lightning_module.py:165-176 with the argparse
+    defaults): CGAtNet(200, 128, n_graph=5, rezero=True, mean_pooling=False (concat), neighbor_number=24, msg_heads=5,
+    update_edges=True, vector_attention=True, global_vector_attention=True, n_graph_roost=3), ragged crystals."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, roost = _ragged_k24(8, 61)
+    inputs = {"x": b.x, "edge_index": b.edge_index, "edge_attr": b.edge_attr, "batch": b.batch,
+              "r0": roost[0], "r1": roost[1], "r2": roost[2], "r3": roost[3], "r4": roost[4]}
+
+    def call(m, i):
+        bb = recipe.GraphBatch(i["x"], i["edge_index"], i["edge_attr"], i["batch"])
+        return m(bb, (t for t in (i["r0"], i["r1"], i["r2"], i["r3"], i["r4"])))
+    kw = dict(rezero=True, mean_pooling=False, neighbor_number=24, msg_heads=5, update_edges=True, vector_attention=True,
+              global_vector_attention=True, n_graph_roost=3)
+    _compare_with_oracle(lambda: P.CGAtNet(200, 128, 5, **kw), lambda: O.CGAtNet(200, 128, 5, **kw), inputs, call)
+
+
 def test_full_stack_vs_oracle_random_init():
     """Config 3 shape (msg_heads=3, 4 layers, 200-d embeddings) on 40 crystals, random init."""
     import cgat_amd as P
@@ -293,17 +333,31 @@ def test_dynamic_range_inside_one_batch():
     pm = P.GATConvNodes(128, 128, 128, 3, concat=True)
     pm.load_state_dict({k: v.float() for k, v in om.state_dict().items()})
     pm = pm.to("cuda:0")
-    xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
-    gxo, geo = torch.autograd.grad((om(xo, b.edge_index, eo, x0.double()) * cot.double()).sum(), [xo, eo])
+    def oracle_grads():
+        xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
+        return torch.autograd.grad((om(xo, b.edge_index, eo, x0.double()) * cot.double()).sum(), [xo, eo])
+    gxo, geo = oracle_grads()
+    with O.flip_probe(FLIP_TAU):       # what a LeakyReLU sign flip of a near-zero pre-activation does to each crystal
+        gxf, gef = oracle_grads()
     xp, ep = x.to("cuda:0").requires_grad_(True), e.to("cuda:0").requires_grad_(True)
     gxp, gep = torch.autograd.grad((pm(xp, b.edge_index.to("cuda:0"), ep, x0.to("cuda:0")) * cot.to("cuda:0")).sum(), [xp, ep])
     worst = []
-    for name, got, ref, per in (("grad_x", gxp, gxo, A), ("grad_edge_attr", gep, geo, A * K)):
-        got, ref = got.cpu().double().view(G, per, -1), ref.view(G, per, -1)
-        rel = (got - ref).abs().amax(dim=(1, 2)) / ref.abs().amax(dim=(1, 2))
-        worst.append(f"  {name}: per-crystal rel err max {float(rel.max()):.2e} (smallest-cotangent crystal {float(rel[0]):.2e}, "
-                     f"largest {float(rel[-1]):.2e})")
-        assert float(rel.max()) <= TOL, (name, rel)
+    for name, got, ref, flp, per in (("grad_x", gxp, gxo, gxf, A), ("grad_edge_attr", gep, geo, gef, A * K)):
+        got, ref, flp = got.cpu().double().view(G, per, -1), ref.view(G, per, -1), flp.view(G, per, -1)
+        err = (got - ref).abs().amax(dim=(1, 2))
+        ref_max = ref.abs().amax(dim=(1, 2))
+        flip = (flp - ref).abs().amax(dim=(1, 2))
+        rel = err / ref_max
+        clean = flip <= 1e-6 * ref_max                                    # crystals without a flip candidate
+        worst.append(f"  {name}: per-crystal rel err, crystals without flip candidates ({int(clean.sum())} of {G}): max "
+                     f"{float(rel[clean].max()):.2e}; smallest-cotangent crystal {float(rel[0]):.2e}, largest {float(rel[-1]):.2e}; "
+                     f"with candidates: max {float(rel[~clean].max()) if (~clean).any() else 0.0:.2e}")
+        assert int(clean.sum()) >= G // 2
+        assert bool((err <= torch.maximum(TOL * ref_max, FLIP_MULT * flip)).all()), (name, rel, flip / ref_max)
+        # the crystals with the SMALLEST cotangents (1e-3 .. 1e-2 of a batch whose largest is 1e3) are as accurate as
+        # the largest ones: the per-tensor fp16 scales do not cost them their relative accuracy
+        lo, hi = rel[:G // 6][clean[:G // 6]], rel[-(G // 6):][clean[-(G // 6):]]
+        assert float(lo.max()) <= max(1e-5, 4 * float(hi.max())), (name, lo, hi)
     _report(["[dynamic range 1e6 inside one batch]"] + worst)
 
 

@@ -266,6 +266,46 @@ def test_plan_large_scan(env):
     assert empty.dst_rowptr.cpu().tolist() == [0] * 6
 
 
+@pytest.mark.parametrize("F,aF,with_mult,permuted", [(384, 384, False, False), (384, 3, False, True), (128, 1, True, True),
+                                                       (48, 3, False, True), (16, 1, True, False), (640, 5, False, False)])
+def test_segment_attention_pool(env, F, aF, with_mult, permuted):
+    """softmax over segments x message, summed per segment, as ONE kernel per direction (vector attention of
+    GATConvNodes, MHAttention, Roost's WeightedAttention) vs the three-step fp64 formula: forward, and the gradients wrt
+    logits, messages and the multiplier; rows in CSR order or reached through a permutation; an empty segment."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(F + aF)
+    S = 37
+    counts = torch.randint(0, 30, (S,), generator=g)
+    counts[5] = 0
+    seg = torch.repeat_interleave(torch.arange(S), counts)
+    R = int(seg.numel())
+    if permuted:
+        shuffle = torch.randperm(R, generator=g)
+        seg = seg[shuffle]                                       # rows in arbitrary order
+    plan = ops.SegmentPlan(seg.to(dev), S)
+    a = (3 * torch.randn(R, aF, generator=g)).to(dev).requires_grad_(True)
+    m = torch.randn(R, F, generator=g).to(dev).requires_grad_(True)
+    mult = (torch.rand(R, 1, generator=g) + 0.1).to(dev).requires_grad_(True) if with_mult else None
+    eps = 1e-13 if with_mult else 1e-16
+    assert ops.AttentionPoolFn.supported(a, m)
+    out = ops.AttentionPoolFn.apply(a, mult, m, plan.rowptr, plan.perm if permuted else None, eps)
+    cot = torch.randn(S, F, generator=g).to(dev)
+    leaves = [a, m] + ([mult] if with_mult else [])
+    grads = torch.autograd.grad((out * cot).sum(), leaves)
+    ad, md = a.detach().double().cpu().requires_grad_(True), m.detach().double().cpu().requires_grad_(True)
+    mud = mult.detach().double().cpu().requires_grad_(True) if with_mult else None
+    fw = F // aF
+    mx = torch.full((S, aF), -float("inf"), dtype=torch.float64).scatter_reduce(0, seg.view(-1, 1).expand(R, aF), ad.detach(), "amax")
+    ex = (ad - mx[seg]).exp() * (mud if with_mult else 1.0)
+    den = torch.zeros(S, aF, dtype=torch.float64).index_add(0, seg, ex) + eps
+    alpha = ex / den[seg]
+    ref = torch.zeros(S, F, dtype=torch.float64).index_add(0, seg, alpha.repeat_interleave(fw, dim=1) * md)
+    rgrads = torch.autograd.grad((ref * cot.double().cpu()).sum(), [ad, md] + ([mud] if with_mult else []))
+    assert rel(out, ref.detach()) <= TOL
+    for got, want in zip(grads, rgrads):
+        assert rel(got, want) <= 5e-5
+
+
 def test_plan_hub_segments_and_invalid_indices(env):
     """Segments far beyond an atom's in-degree (a hub with 3 000 and one with 20 000 incoming edges: the workgroup rank
     sort and its one-lane fallback) stay bit-exact vs a stable sort; an index outside [0, N) raises IndexError as the
