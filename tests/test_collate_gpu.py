@@ -121,8 +121,12 @@ def test_training_step_matches_plain_torch_composition():
         assert abs(float(loss) - float(want.detach())) <= 1e-5 * max(1.0, abs(float(want.detach())))
     # AdamW divides by sqrt(v): where a gradient element is ~0 the two runs' 1e-6-level gradient differences decide the
     # direction of an lr-sized update, so the bound is a small fraction of the largest possible update (lr per step)
+    # (MH_A.fc_out.bias of scalar attention has an exactly-zero gradient by softmax shift invariance: what arrives is
+    # rounding noise whose SIGN decides a full lr-sized AdamW step -- not comparable between two summation orders)
     for (n, p), q in zip(net.named_parameters(), ref.parameters()):
-        d = float((p - q).abs().max())
+        if n.endswith("MH_A.fc_out.bias"):
+            continue
+        d = float((p.detach() - q.detach()).abs().max())
         assert d <= 0.05 * 1e-3 * 2, (n, d)
     # gradient accumulation over two micro-batches == one step on their union (same mean loss: equal sizes)
     tr2 = P.DataParallelTrainer(copy.deepcopy(ref), ds, lr=1e-3, weight_decay=1e-2, normalizer=norm, accumulate_grad_batches=2)
@@ -131,5 +135,7 @@ def test_training_step_matches_plain_torch_composition():
     tr2.step([ids[:12], ids[12:]])
     tr1.step(ids)
     for (n, p), q in zip(tr2.model.named_parameters(), tr1.model.parameters()):
-        d = float((p - q).abs().max())
+        if n.endswith("MH_A.fc_out.bias"):
+            continue
+        d = float((p.detach() - q.detach()).abs().max())
         assert d <= 0.05 * 1e-3, (n, d)

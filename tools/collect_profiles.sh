@@ -1,15 +1,22 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the bench line, the rocprofv3 kernel statistics of the same command and the two PMC
-# passes for HBM traffic.  Outputs under gpurun_out/final/; tools/pmc_summary.py + a copy into profiles/ happen on
-# the authoring side.
+# Runs on the GPU box (gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the PMC passes for
+# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes), the matrix-core counters (SQ_VALU_MFMA_BUSY_CYCLES with
+# GRBM_GUI_ACTIVE for the clock) and the K = 64 stress workload's statistics.  Outputs under gpurun_out/<dir>/;
+# tools/pmc_summary.py, tools/counter_summary.py and a copy into profiles/ happen on the authoring side.
+# Every rocprofv3 command has the program directly after `--`.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final
+O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass > $O/stats.log 2>&1
+Q="--no-cpu-baseline --no-exclusive-pass --no-extra-legs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 $Q > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-pass > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 $Q > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_GRBM_GUI_ACTIVE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exclusive-pass > $O/pmc_clk.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $O/pmc_mfma.log 2>&1
+python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass > $O/bench_stress.json 2> $O/bench_stress.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stress_stats -- python3 $R/bench.py --workload stress --graphs 12500 --steps 1 --warmup 1 --no-exclusive-pass > $O/stress_stats.log 2>&1
+python3 $R/bench.py --workload train --steps 5 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
+python3 $R/bench.py --workload stack --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass > $O/bench_stack.json 2> $O/bench_stack.err
 tail -c 600 $O/bench.json

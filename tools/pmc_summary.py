@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(d, counter):
-    f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -37,7 +37,9 @@ N, C = 83340, 128
 # default arithmetic f16x3: the prepared T / r operands are two fp16 planes = 4 bytes per element
 alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           # p, q, init, out + the two planes of T
        "bilinear_rows128_dual_kernel": 7 * N * C * 4 + C ** 3 * 4,             # p, q, zz, init1, out1, init2, out2 + T
-       "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 4 + C ** 3 * 4}  # pT, qT, r planes + out
+       "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 4 + C ** 3 * 4,  # pT, qT, r planes + out
+       # the batched f16x3 launch covers the four predicted layers: 4 x (pT, qT, two fp16 planes of r, out)
+       "bilinear_wgrad128_f16p_kernel": 4 * (2 * N * C * 4 + N * C * 4 + C ** 3 * 4)}
 out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py "
                   "--steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
        "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE halves wide coalesced reads)"}
