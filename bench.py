@@ -462,7 +462,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     ALL_TAGS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
-                "edge_gw", "rows_ge", "rows_gw", "linear128", "rows_dw", "gemm_f32")
+                "edge_gw", "rows_ge", "rows_gw", "linear128", "mlp_chain", "rows_dw", "gemm_f32")
     prof = {t: ops.prof_get(t) for t in ALL_TAGS}          # (launches, total ms) inside the timed region
     # With the weight-gradient contractions on the side stream they and the attention-backward kernels they run
     # beside share the chip, so their timed-region durations are not exclusive.  A short serial pass AFTER the timed

@@ -74,6 +74,20 @@ class GemmDesc(C.Structure):
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+class ChainLayer(C.Structure):
+    """cgat_chain_layer"""
+    _fields_ = [("W", vp), ("w_so", C.c_int64), ("w_sk", C.c_int64), ("bias", vp), ("dact", vp), ("ld_dact", C.c_int64),
+                ("resid", vp), ("ld_resid", C.c_int64), ("out", vp), ("ld_out", C.c_int64), ("act", C.c_int32),
+                ("dact_type", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class ChainDesc(C.Structure):
+    """cgat_chain_desc"""
+    _fields_ = [("n_layers", C.c_int32), ("rows", C.c_int32), ("x", vp), ("ldx", C.c_int64), ("in_dact", vp),
+                ("ld_in_dact", C.c_int64), ("in_dact_type", C.c_int32), ("in_store", vp), ("ld_in_store", C.c_int64),
+                ("layer", ChainLayer * 5)]
+
+
 PROTOTYPES = {
     "cgat_abi_version": (C.c_int, []),
     "cgat_last_error": (C.c_char_p, []),
@@ -114,6 +128,8 @@ PROTOTYPES = {
                                                       vp, vp, vp, vp]),
     "cgat_segment_attention_pool_backward": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, vp,
                                                        vp, vp, vp, C.c_int64, vp, vp]),
+    "cgat_mlp_chain_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "cgat_mlp_chain": (C.c_int, [C.POINTER(ChainDesc), vp, C.c_size_t, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
     "cgat_set_bilinear_mode": (None, [C.c_int32]),

@@ -210,6 +210,43 @@ extern "C" int cgat_segment_attention_pool_backward(const float* a, int32_t aF, 
                                  (hipStream_t)stream);
 }
 
+// ---- dense-layer chain ----
+extern "C" size_t cgat_mlp_chain_workspace_bytes(int32_t n_layers) {
+  return (size_t)(n_layers > 0 ? n_layers : 0) * WPREP_IMAGE_FLOATS * sizeof(float) + 256;
+}
+extern "C" int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(d && d->n_layers >= 1 && d->n_layers <= CHAIN_MAX && d->rows >= 0, "mlp_chain: bad descriptor");
+  if (bilinear_mode() != 2) {
+    cgat_set_error("mlp_chain: only the f16x3 arithmetic mode has the fused chain; run the layers one by one");
+    return CGAT_ERR_UNSUPPORTED;
+  }
+  if (!ws || ws_bytes < cgat_mlp_chain_workspace_bytes(d->n_layers)) {
+    cgat_set_error("mlp_chain: workspace too small");
+    return CGAT_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  WPrepBatch wp;
+  wp.n = d->n_layers;
+  ChainDesc c;
+  memset(&c, 0, sizeof(c));
+  float* images = (float*)ws;
+  for (int l = 0; l < d->n_layers; ++l) {
+    const cgat_chain_layer& L = d->layer[l];
+    wp.src[l] = L.W; wp.sb[l] = L.w_sk; wp.sc[l] = L.w_so;
+    ChainLayer& o = c.layer[l];
+    o.W = (const uint4*)(images + (size_t)l * WPREP_IMAGE_FLOATS);
+    o.bias = L.bias; o.dact = L.dact; o.resid = L.resid; o.out = L.out;
+    o.ld_dact = L.ld_dact; o.ld_resid = L.ld_resid; o.ld_out = L.ld_out;
+    o.act = L.act; o.dact_type = L.dact_type; o.accumulate = L.accumulate;
+  }
+  c.n_layers = d->n_layers; c.rows = d->rows; c.x = d->x; c.ldx = d->ldx;
+  c.in_dact = d->in_dact; c.ld_in_dact = d->ld_in_dact; c.in_dact_type = d->in_dact_type;
+  c.in_store = d->in_store; c.ld_in_store = d->ld_in_store;
+  CGAT_CHECK_ARG(mlp_chain128_fast(c), "mlp_chain: rows must be 16-byte aligned with leading dimensions that are multiples of 4");
+  CGAT_TRY(prepare_W_f16_batch_launch(wp, images, s));
+  return mlp_chain128_launch(c, s);
+}
+
 // ---- kernel-level primitives ----
 static GemmParams from_desc(const cgat_gemm_desc* d) {
   GemmParams g = gemm_params(d->M, d->N, d->K, d->A, d->lda, d->B, d->ldb, d->C, d->ldc);

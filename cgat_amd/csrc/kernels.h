@@ -122,6 +122,32 @@ size_t linear128_ws_bytes(int n_out = 128);
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
                      float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out = 128,
                      const void* prepared = nullptr);   // prepared: image from prepare_W_f16_batch_launch (f16x3, n_out 128)
+// ---- a chain of width-128 dense layers in one launch (f16x3 mode), chain.hip ----
+#define CHAIN_MAX 5
+struct ChainLayer {
+  const uint4* W;        // prepared image (prepare_W_f16_batch_launch: 8 chunks of 8 KB, its scale behind them)
+  const float* bias;     // [128] or null
+  const float* dact;     // null, or saved activation values y [rows,128]: the layer's result is multiplied by act'(y)
+  const float* resid;    // null, or [rows,128] added to the (activated) result
+  float* out;            // null, or where the result goes
+  long ld_dact, ld_resid, ld_out;
+  int act;               // activation of the layer (CGAT_ACT_*)
+  int dact_type;         // activation whose derivative `dact` stands for
+  int accumulate;        // out += result
+};
+struct ChainDesc {
+  ChainLayer layer[CHAIN_MAX];
+  int n_layers, rows;
+  const float* x;        // input rows [rows,128]
+  long ldx;
+  const float* in_dact;  // null, or the input rows are multiplied by act'(in_dact) first (backward of an activation)
+  long ld_in_dact;
+  int in_dact_type;
+  float* in_store;       // null, or where the (multiplied) input rows are stored
+  long ld_in_store;
+};
+bool mlp_chain128_fast(const ChainDesc& d);
+int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
 // operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);

@@ -799,18 +799,45 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
   const float* vin = v;
   for (int l = 0; l < p->n_hyper; ++l) {
     const cgat_hyperlinear_params& L = p->layer[l];
-    const float* t = hin;
-    for (int s = 0; s < p->n_fc; ++s) {  // trunk: Linear + Tanh
-      GemmParams g = gemm_params(rows, W, W, t, W, L.fc_w[s], W, c.dry ? nullptr : sv.act(l, s), W);
-      g.bias = L.fc_b[s];
-      g.act = CGAT_ACT_TANH;
-      CGAT_TRY(c.gemm(g));
-      t = c.dry ? nullptr : sv.act(l, s);
-    }
-    const float* z = t;
     float* u = c.dry ? nullptr : ((l == p->n_hyper - 1) ? y : sv.u(l));
-    // bias-row terms of the head:  u = vin @ Bm^T + z @ U^T + b0,  Bm = head_b[:W*W] as [o,i], U = head_w[W*W:]
-    {
+    const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
+    // The trunk (n_fc x [Linear + Tanh]) and the trunk-side linear term of the head, u = z @ U^T + b0, as ONE chain
+    // launch (chain.hip) when the weights of the pass have been prepared in a batch (f16x3 mode, width 128, <= 4 trunk
+    // layers); the remaining linear term u += vin @ Bm^T follows.  Bm = head_b[:W*W] as [o,i], U = head_w[W*W:]
+    bool chained = false;
+    if (batch_w && !c.dry && bilinear_mode() == 2 && p->n_fc + 1 <= CHAIN_MAX) {
+      ChainDesc cd;
+      memset(&cd, 0, sizeof(cd));
+      cd.n_layers = p->n_fc + 1; cd.rows = rows; cd.x = hin; cd.ldx = W;
+      bool ok = true;
+      for (int s = 0; s < p->n_fc; ++s) {
+        ChainLayer& cl = cd.layer[s];
+        cl.W = (const uint4*)c.wprep_find(L.fc_w[s], W, 1);
+        cl.bias = L.fc_b[s]; cl.act = CGAT_ACT_TANH; cl.out = sv.act(l, s); cl.ld_out = W;
+        ok = ok && cl.W;
+      }
+      ChainLayer& cu = cd.layer[p->n_fc];
+      cu.W = (const uint4*)c.wprep_find(L.head_w + WW * W, W, 1);
+      cu.bias = L.head_b + WW; cu.act = CGAT_ACT_NONE; cu.out = u; cu.ld_out = W;
+      ok = ok && cu.W && mlp_chain128_fast(cd);
+      if (ok) {
+        CGAT_TRY(mlp_chain128_launch(cd, c.s));
+        GemmParams g = gemm_params(rows, W, W, vin, W, L.head_b, W, u, W);
+        g.beta = 1.f;
+        CGAT_TRY(c.gemm(g));
+        chained = true;
+      }
+    }
+    if (!chained) {
+      const float* t = hin;
+      for (int s = 0; s < p->n_fc; ++s) {  // trunk: Linear + Tanh
+        GemmParams g = gemm_params(rows, W, W, t, W, L.fc_w[s], W, c.dry ? nullptr : sv.act(l, s), W);
+        g.bias = L.fc_b[s];
+        g.act = CGAT_ACT_TANH;
+        CGAT_TRY(c.gemm(g));
+        t = c.dry ? nullptr : sv.act(l, s);
+      }
+      // bias-row terms of the head:  u = vin @ Bm^T + z @ U^T + b0
       GemmParams g = gemm_params(rows, W, W, vin, W, L.head_b, W, u, W);
       CGAT_TRY(c.gemm(g));
       g = gemm_params(rows, W, W, z, W, L.head_w + WW * W, W, u, W);
@@ -855,7 +882,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   float* g_u = c.take<float>((size_t)p->n_hyper * rw);   // one per predicted layer: all dT run in ONE launch at the end
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
   float* g_t = c.take<float>(rw);
-  float* g_pre = c.take<float>(rw);
+  float* g_pre = c.take<float>((size_t)(p->n_fc > 0 ? p->n_fc : 1) * rw);   // one per trunk layer: the chain writes them all
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
   if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
   c.seal();
@@ -923,7 +950,50 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       CGAT_TRY(c.bilinear(gu, W, z, W, Tp, g_vin, W, g_vin, W, rows, W, W, W));
     }
     // ---- trunk backward (g_t holds the gradient wrt the trunk output z) ----
-    for (int s = p->n_fc - 1; s >= 0; --s) {
+    // One chain launch on the transposed weights (chain.hip): rows = g_t * tanh'(t_last) = the last layer's
+    // pre-activation gradient, layer i multiplies by W_(n_fc-1-i) and by tanh' of the activation below it, every
+    // pre-activation gradient is stored for the weight-gradient kernel, the last product is added to g_hin.
+    bool chained = false;
+    if (batch_w && !c.dry && bilinear_mode() == 2 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX) {
+      ChainDesc cd;
+      memset(&cd, 0, sizeof(cd));
+      const int nf = p->n_fc;
+      cd.n_layers = nf; cd.rows = rows; cd.x = g_t; cd.ldx = W;
+      cd.in_dact = sv.act(l, nf - 1); cd.ld_in_dact = W; cd.in_dact_type = CGAT_ACT_TANH;
+      cd.in_store = g_pre + (size_t)(nf - 1) * rw; cd.ld_in_store = W;
+      bool ok = true;
+      for (int i = 0; i < nf; ++i) {
+        const int sl = nf - 1 - i;                      // trunk layer whose weight this chain layer multiplies by
+        ChainLayer& cl = cd.layer[i];
+        cl.W = (const uint4*)c.wprep_find(L.fc_w[sl], 1, W);
+        cl.act = CGAT_ACT_NONE;
+        if (sl > 0) {
+          cl.dact = sv.act(l, sl - 1); cl.ld_dact = W; cl.dact_type = CGAT_ACT_TANH;
+          cl.out = g_pre + (size_t)(sl - 1) * rw; cl.ld_out = W;
+        } else {
+          cl.out = g_hin; cl.ld_out = W; cl.accumulate = 1;   // every predicted layer's trunk reads the same hyper input
+        }
+        ok = ok && cl.W;
+      }
+      ok = ok && mlp_chain128_fast(cd);
+      if (ok) {
+        CGAT_TRY(mlp_chain128_launch(cd, c.s));
+        for (int s2 = nf - 1; s2 >= 0; --s2) {
+          const float* tin = (s2 == 0) ? hin : sv.act(l, s2 - 1);
+          const float* gp = g_pre + (size_t)s2 * rw;
+          int fz = W == 128 ? c.dw128(gp, W, tin, W, G.fc_w[s2], W, nullptr, 0, nullptr, 0, G.fc_b[s2], rows) : -1;
+          if (fz > 0) return fz;
+          if (fz < 0) {
+            GemmParams g = gemm_params(W, W, rows, gp, W, tin, W, G.fc_w[s2], W);
+            g.a_kmajor = 1; g.b_kmajor = 1;
+            CGAT_TRY(c.gemm(g, true));
+            CGAT_TRY(c.colsum(gp, W, rows, W, G.fc_b[s2], 1.f));
+          }
+        }
+        chained = true;
+      }
+    }
+    for (int s = p->n_fc - 1; s >= 0 && !chained; --s) {
       const float* tout = c.dry ? nullptr : sv.act(l, s);
       const float* tin = (s == 0) ? hin : (c.dry ? nullptr : sv.act(l, s - 1));
       RUN(act_bwd_launch(tout, g_t, g_pre, (long)rw, CGAT_ACT_TANH, c.s));
@@ -1012,8 +1082,15 @@ extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_param
   }
   Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
   c.scratch_need = dry.scratch_need;
-  // half of the chip stays free for the main stream's HBM-bound kernels
-  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, 128};
+  // half of the chip stays free for the main stream's HBM-bound kernels (CGAT_SIDE_WGRAD_WGS: tuning knob, any value
+  // gives the same results up to the summation order of the row splits)
+  static int side_wgs = -1;
+  if (side_wgs < 0) {
+    const char* e = getenv("CGAT_SIDE_WGRAD_WGS");
+    side_wgs = e ? atoi(e) : 128;
+    if (side_wgs < 8 || side_wgs > 256) side_wgs = 128;
+  }
+  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_wgs};
   return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);
 }
 extern "C" int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,

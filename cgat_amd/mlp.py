@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import linear
+from .ops import ChainMLPFn, linear
 
 
 class SimpleNetwork(nn.Module):
@@ -18,10 +18,20 @@ class SimpleNetwork(nn.Module):
         self.acts = nn.ModuleList([nn.LeakyReLU() for _ in range(len(dims) - 1)])
         self.fc_out = nn.Linear(dims[-1], output_dim)
 
-    def forward(self, fea):
+    def forward(self, fea, residual=None):
+        """`residual` (optional, same shape as the output) is added to the result: CGAtNet's `edge_attr + Edge(...)`."""
+        ws = [fc.weight for fc in self.fcs] + [self.fc_out.weight]
+        bs = [fc.bias for fc in self.fcs] + [self.fc_out.bias]
+        x2 = fea.reshape(-1, fea.shape[-1])
+        if all(b is not None for b in bs) and ChainMLPFn.eligible(x2, ws, None if residual is None else residual.reshape(x2.shape)):
+            # all layers of width 128: one launch per direction, hidden rows never leave the registers (csrc/chain.hip)
+            r2 = None if residual is None else residual.reshape(x2.shape)
+            out = ChainMLPFn.apply(x2, r2, _lib.ACT_LEAKY, *ws, *bs)
+            return out.reshape(*fea.shape[:-1], 128)
         for fc in self.fcs:
             fea = linear(fea, fc.weight, fc.bias, _lib.ACT_LEAKY)
-        return linear(fea, self.fc_out.weight, self.fc_out.bias)
+        out = linear(fea, self.fc_out.weight, self.fc_out.bias)
+        return out if residual is None else out + residual
 
     def __repr__(self):
         return self.__class__.__name__

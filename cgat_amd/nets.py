@@ -321,7 +321,13 @@ class CGAtNet(nn.Module):
         edge_attr_0 = edge_attr
         for graph_func in self.graphs:
             node_update = graph_func['Node'](elem_fea, edge_index, edge_attr, elem_fea_0)
-            edge_attr = edge_attr + graph_func['Edge'](elem_fea, edge_index, edge_attr, edge_attr_0)
+            edge = graph_func['Edge']
+            if edge.no_hyper and type(edge).forward is GATConvEdges.forward and not edge.dropout:
+                # shipped form: Edge(...) = Pooling_NN(edge_attr) (its attention is dead code, CGAT.py:224-225); the
+                # residual add of CGAT.py:582 rides in the same launch
+                edge_attr = edge.Pooling_NN(edge_attr, residual=edge_attr)
+            else:
+                edge_attr = edge_attr + edge(elem_fea, edge_index, edge_attr, edge_attr_0)
             elem_fea = elem_fea + node_update
         roost = tuple(roost)                                                    # the harness passes a generator
         crys_fea = self.roost(*roost, num_crystals=G)

@@ -640,6 +640,104 @@ class SegmentSumFn(torch.autograd.Function):
         return g.index_select(0, seg_of_row), None, None
 
 
+def _chain_desc(rows, x, layers, in_dact=None, in_dact_type=0, in_store=None):
+    """cgat_chain_desc from python values; `layers` = dicts with W, transposed, bias, act, dact, dact_type, resid, out,
+    accumulate (tensors are 2-D row-major [rows,128] / [128,128])."""
+    d = _lib.ChainDesc()
+    d.n_layers, d.rows = len(layers), rows
+    d.x, d.ldx = x.data_ptr(), x.stride(0)
+    if in_dact is not None:
+        d.in_dact, d.ld_in_dact, d.in_dact_type = in_dact.data_ptr(), in_dact.stride(0), in_dact_type
+    if in_store is not None:
+        d.in_store, d.ld_in_store = in_store.data_ptr(), in_store.stride(0)
+    for i, L in enumerate(layers):
+        c = d.layer[i]
+        W = L["W"]
+        c.W = W.data_ptr()
+        c.w_so, c.w_sk = (1, W.stride(0)) if L.get("transposed") else (W.stride(0), 1)
+        for k in ("dact", "resid", "out"):
+            if L.get(k) is not None:
+                setattr(c, k, L[k].data_ptr())
+                setattr(c, "ld_" + k, L[k].stride(0))
+        if L.get("bias") is not None:
+            c.bias = L["bias"].data_ptr()
+        c.act, c.dact_type, c.accumulate = L.get("act", 0), L.get("dact_type", 0), int(L.get("accumulate", False))
+    return d
+
+
+def _run_chain(d, device):
+    ws = workspace(lib.cgat_mlp_chain_workspace_bytes(d.n_layers), device)
+    with torch.cuda.device(device):
+        check(lib.cgat_mlp_chain(C.byref(d), _ptr(ws), ws.numel(), _stream()), "cgat_mlp_chain")
+
+
+class ChainMLPFn(torch.autograd.Function):
+    """out = resid + W_n act(... act(W_1 x + b_1) ...) + b_n for width-128 layers in ONE launch per direction
+    (csrc/chain.hip): SimpleNetwork (message_changed.py:36-63) on [rows,128] inputs, with the residual of CGAtNet's
+    `edge_attr + Edge(...)` (CGAT.py:580-585) folded in.  Hidden activations are kept for backward; the backward chain
+    runs on the transposed weights with the activation derivatives folded in and leaves every pre-activation gradient
+    for the one-pass weight + bias gradient kernel."""
+
+    @staticmethod
+    def eligible(x, weights, resid=None):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 128 and x.shape[0] > 0):
+            return False
+        if get_bilinear_mode() != "f16x3" or not (1 <= len(weights) <= 5):
+            return False
+        if resid is not None and (resid.shape != x.shape or resid.dtype != torch.float32):
+            return False
+        return all(tuple(w.shape) == (128, 128) and w.dtype == torch.float32 for w in weights)
+
+    @staticmethod
+    def forward(ctx, x, resid, act, *wb):
+        n = len(wb) // 2
+        ws_, bs_ = [_f32c(w.detach()) for w in wb[:n]], [_f32c(b.detach()) for b in wb[n:]]
+        ctx.same = resid is x                            # x + f(x): the backward chain then adds g_out in its last layer
+        x = _f32c(x)
+        r = None if resid is None else (x if ctx.same else _f32c(resid))
+        rows, dev = x.shape[0], x.device
+        hid = [torch.empty(rows, 128, dtype=torch.float32, device=dev) for _ in range(n - 1)]
+        out = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+        layers = [dict(W=ws_[i], bias=bs_[i], act=act, out=hid[i]) for i in range(n - 1)]
+        layers.append(dict(W=ws_[-1], bias=bs_[-1], act=_lib.ACT_NONE, resid=r, out=out))
+        _run_chain(_chain_desc(rows, x, layers), dev)
+        ctx.act, ctx.n, ctx.has_r = act, n, resid is not None
+        ctx.save_for_backward(x, *hid, *ws_)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        n, act = ctx.n, ctx.act
+        x, *rest = ctx.saved_tensors
+        hid, ws_ = rest[:n - 1], rest[n - 1:]
+        g_out = _f32c(g_out)
+        rows, dev = x.shape[0], x.device
+        gpre = [torch.empty(rows, 128, dtype=torch.float32, device=dev) for _ in range(n - 1)] + [g_out]
+        g_x = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+        layers = []
+        for i in range(n):                               # chain layer i multiplies by W_(n-1-i)
+            sl = n - 1 - i
+            L = dict(W=ws_[sl], transposed=True)
+            if sl > 0:
+                L.update(dact=hid[sl - 1], dact_type=act, out=gpre[sl - 1])
+            else:
+                L.update(out=g_x, resid=g_out if ctx.same else None)
+            layers.append(L)
+        _run_chain(_chain_desc(rows, g_out, layers), dev)
+        g_w, g_b = [], []
+        wsz = workspace(lib.cgat_linear_backward_workspace_bytes(rows, 128, 128), dev)
+        with torch.cuda.device(dev):
+            for sl in range(n):                          # dW_sl = gpre_sl^T input_sl, db_sl = column sums of gpre_sl
+                xin = x if sl == 0 else hid[sl - 1]
+                gw = torch.empty(128, 128, dtype=torch.float32, device=dev)
+                gb = torch.empty(128, dtype=torch.float32, device=dev)
+                check(lib.cgat_linear_backward(_ptr(xin), 128, _ptr(ws_[sl]), 128, None, 128, _ptr(gpre[sl]), 128, None,
+                                               None, 128, 0, _ptr(gw), 128, _ptr(gb), rows, 128, 128, _lib.ACT_NONE,
+                                               _ptr(wsz), wsz.numel(), _stream()), "cgat_linear_backward")
+                g_w.append(gw); g_b.append(gb)
+        return (g_x, g_out if (ctx.has_r and not ctx.same) else None, None, *g_w, *g_b)
+
+
 class AttentionPoolFn(torch.autograd.Function):
     """out[s, f] = sum_{r in seg s} alpha[r, f // fw] * m[r, f] with alpha = mult * exp(a - segmax) / (segsum + eps) -- the
     reference's softmax -> multiply -> scatter_add (CGAT.py:323-329, 59-61; roost_message.py:305-317) as one kernel per

@@ -271,6 +271,42 @@ int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float
                                          const float* inv, const float* g_out, float* g_a, float* g_m, int64_t ldgm,
                                          float* g_mult, void* stream);
 
+/* A chain of up to 5 dense layers of width 128 in ONE launch (f16x3 arithmetic mode; CGAT_ERR_UNSUPPORTED otherwise):
+ *   r_0 = x                      (times act'(in_dact) if in_dact != NULL; stored to in_store if != NULL)
+ *   r_(l+1) = act_l(r_l W_l^T + bias_l) (+ resid_l) (* dact_type_l'(dact_l)),   W_l(o,k) = W[o*w_so + k*w_sk]
+ * every r_(l+1) is written to out_l when out_l != NULL (+= when accumulate).  Forward of the hypernetwork trunks
+ * (reference Hypernetworksmp.py:36-83: four Linear+Tanh, then the linear terms of the predicted layer), their backward
+ * (the same chain on the transposed weights with the tanh derivatives as in_dact / dact), and the edge update's
+ * two-layer network with its residual (CGAT.py:226-229, 580-585).  Rows stay in registers between layers; only the
+ * requested outputs touch HBM.  All row pointers 16-byte aligned, leading dimensions multiples of 4. */
+typedef struct cgat_chain_layer {
+  const float* W;
+  int64_t w_so, w_sk;
+  const float* bias;      /* [128] or NULL */
+  const float* dact;      /* NULL, or saved activation values [rows,128]: result *= act'(dact) with act = dact_type */
+  int64_t ld_dact;
+  const float* resid;     /* NULL, or [rows,128] added to the activated result */
+  int64_t ld_resid;
+  float* out;             /* NULL, or destination [rows,128] */
+  int64_t ld_out;
+  int32_t act;            /* 0 none, 1 tanh, 2 LeakyReLU(0.01), 3 ReLU */
+  int32_t dact_type;
+  int32_t accumulate;
+} cgat_chain_layer;
+typedef struct cgat_chain_desc {
+  int32_t n_layers, rows;
+  const float* x;
+  int64_t ldx;
+  const float* in_dact;
+  int64_t ld_in_dact;
+  int32_t in_dact_type;
+  float* in_store;
+  int64_t ld_in_store;
+  cgat_chain_layer layer[5];
+} cgat_chain_desc;
+size_t cgat_mlp_chain_workspace_bytes(int32_t n_layers);
+int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- kernel-level primitives (what the layer entry points above are composed of) --------- */
 /* C = act(alpha * A.B + bias + add1[add1_idx[m]] + add2[add2_idx[m]]) + beta * C on the fp32 matrix
  * cores.  A(m,k) = A[row(m)*lda + k] (a_kmajor=0, row(m)=a_rgather?a_rgather[m]:m) or A[k*lda + m]

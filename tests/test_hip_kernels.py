@@ -306,6 +306,101 @@ def test_segment_attention_pool(env, F, aF, with_mult, permuted):
         assert rel(got, want) <= 5e-5
 
 
+def _chain(env, rows, x, layers, in_dact=None, in_dact_type=0, in_store=None):
+    """layers: list of dicts(W [128,128] (out,in) or its transpose flag, bias, act, dact, dact_type, resid, out, accumulate)"""
+    _, _lib, ops, dev = env
+    d = _lib.ChainDesc()
+    d.n_layers, d.rows = len(layers), rows
+    d.x, d.ldx = x.data_ptr(), x.stride(0)
+    if in_dact is not None:
+        d.in_dact, d.ld_in_dact, d.in_dact_type = in_dact.data_ptr(), in_dact.stride(0), in_dact_type
+    if in_store is not None:
+        d.in_store, d.ld_in_store = in_store.data_ptr(), in_store.stride(0)
+    for i, L in enumerate(layers):
+        c = d.layer[i]
+        W = L["W"]
+        c.W = W.data_ptr()
+        c.w_so, c.w_sk = (1, W.stride(0)) if L.get("transposed") else (W.stride(0), 1)
+        for k in ("bias", "dact", "resid", "out"):
+            if L.get(k) is not None:
+                setattr(c, k, L[k].data_ptr())
+                if k != "bias":
+                    setattr(c, "ld_" + k, L[k].stride(0))
+        c.act, c.dact_type, c.accumulate = L.get("act", 0), L.get("dact_type", 0), int(L.get("accumulate", False))
+    ws = torch.empty(_lib.lib.cgat_mlp_chain_workspace_bytes(len(layers)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.cgat_mlp_chain(C.byref(d), ws.data_ptr(), ws.numel(), None), "cgat_mlp_chain")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows", [1, 127, 128, 1000, 20001])
+def test_mlp_chain_trunk_forward_and_backward(env, rows):
+    """The fused dense-layer chain (csrc/chain.hip) in the two forms the hypernetwork uses: forward = four Linear+Tanh
+    and a final Linear with every activation stored; backward = the same chain on the transposed weights with the
+    tanh derivatives folded in, every pre-activation gradient stored and the last product accumulated -- each against
+    the layer-by-layer fp64 computation; rows from 1 to 20 001 (partial last tile, rows of very different magnitude)."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(rows)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    # per-row scales 1e-3 .. 3: every row keeps its own 22 bits (per-row power-of-two scale).  Larger rows would only test
+    # fp32 itself: a pre-activation of magnitude 1e3 carries 1e-4 of absolute rounding error in ANY fp32 evaluation,
+    # which tanh passes through wherever it is not saturated
+    x = (rnd(rows, 128) * torch.logspace(-3, 0.5, rows).view(-1, 1)).to(dev)
+    Ws = [(rnd(128, 128) / 128 ** 0.5).to(dev) for _ in range(5)]
+    bs = [rnd(128).to(dev) for _ in range(5)]
+    outs = [torch.full((rows, 128), float("nan"), device=dev) for _ in range(5)]
+    _chain(env, rows, x, [dict(W=Ws[i], bias=bs[i], act=_lib.ACT_TANH if i < 4 else _lib.ACT_NONE, out=outs[i]) for i in range(5)])
+    t = x.double().cpu()
+    refs = []
+    for i in range(5):
+        t = t @ Ws[i].double().cpu().t() + bs[i].double().cpu()
+        if i < 4:
+            t = torch.tanh(t)
+        refs.append(t)
+    for i in range(5):
+        assert rel(outs[i], refs[i]) <= TOL, i
+    # backward form
+    gz = rnd(rows, 128).to(dev)
+    acts = [r.float().to(dev) for r in refs[:4]]
+    gpre = [torch.full((rows, 128), float("nan"), device=dev) for _ in range(4)]
+    ghin0 = rnd(rows, 128).to(dev)
+    ghin = ghin0.clone()
+    layers = []
+    for i in range(4):
+        sl = 3 - i
+        L = dict(W=Ws[sl], transposed=True)
+        if sl > 0:
+            L.update(dact=acts[sl - 1], dact_type=_lib.ACT_TANH, out=gpre[sl - 1])
+        else:
+            L.update(out=ghin, accumulate=True)
+        layers.append(L)
+    _chain(env, rows, gz, layers, in_dact=acts[3], in_dact_type=_lib.ACT_TANH, in_store=gpre[3])
+    gt = gz.double().cpu()
+    a64 = [a.double().cpu() for a in acts]
+    want = [None] * 4
+    for sl in (3, 2, 1, 0):
+        want[sl] = gt * (1 - a64[sl] ** 2)
+        gt = want[sl] @ Ws[sl].double().cpu()
+    for sl in range(4):
+        assert rel(gpre[sl], want[sl]) <= TOL, sl
+    assert rel(ghin, ghin0.double().cpu() + gt) <= TOL
+
+
+def test_mlp_chain_residual_leaky(env):
+    """The edge update's form: out = x + fc_out(LeakyReLU(fcs0(x))) in one launch, hidden activations stored."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(77)
+    rows = 777
+    x = torch.randn(rows, 128, generator=g).to(dev)
+    W0, W1 = (torch.randn(128, 128, generator=g) / 11).to(dev), (torch.randn(128, 128, generator=g) / 11).to(dev)
+    b0, b1 = torch.randn(128, generator=g).to(dev), torch.randn(128, generator=g).to(dev)
+    hid, out = torch.empty(rows, 128, device=dev), torch.empty(rows, 128, device=dev)
+    _chain(env, rows, x, [dict(W=W0, bias=b0, act=_lib.ACT_LEAKY, out=hid), dict(W=W1, bias=b1, resid=x, out=out)])
+    xd = x.double().cpu()
+    h = torch.nn.functional.leaky_relu(xd @ W0.double().cpu().t() + b0.double().cpu(), 0.01)
+    assert rel(hid, h) <= TOL
+    assert rel(out, xd + h @ W1.double().cpu().t() + b1.double().cpu()) <= TOL
+
+
 def test_plan_hub_segments_and_invalid_indices(env):
     """Segments far beyond an atom's in-degree (a hub with 3 000 and one with 20 000 incoming edges: the workgroup rank
     sort and its one-lane fallback) stay bit-exact vs a stable sort; an index outside [0, N) raises IndexError as the
