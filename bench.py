@@ -407,6 +407,9 @@ def main():
                     help="skip the untimed-for-`value` legs after the timed region (other arithmetic modes, full stack)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="--workload train: per-rank or total batch fixed")
     ap.add_argument("--nbrs", type=int, default=None, help="neighbours per atom (default 12; --workload stress: 64)")
+    ap.add_argument("--edge-storage", choices=["f32", "bf16"], default="f32",
+                    help="storage of the per-edge intermediates Z / gZ (bf16 = the 'bf16 activations' of configs[4]; "
+                         "tolerance 1e-2 instead of 1e-4: never the default, reported in the line)")
     ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
@@ -435,6 +438,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
         cpu = cpu_baseline()
 
+    P.set_edge_storage(args.edge_storage)
     stress = args.workload == "stress"
     K_used = args.nbrs or (64 if stress else K_NBR)
     if stress:
@@ -573,12 +577,13 @@ def main():
                 roof["mfma_utilisation_from_counters"] = json.load(open(counters_file))
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
-        W2b = 2 * HEADS * 256 * 4
+        W2b = 2 * HEADS * 256 * (2 if args.edge_storage == "bf16" else 4)
         # f16x3: the per-edge forward kernel computes the x_j projection itself (edge_zx_kernel): Z written, e and
         # x[src] rows read, Pi rows once; other modes: Z written, Pj gathered (W2b per edge), e read, Pi rows once
-        ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2b if mode == "f16x3" else E * (2 * W2b + C_FEA * 4) + N * W2b
+        W2f = 2 * HEADS * 256 * 4                          # per-node rows (Pi, Gi, gS) are fp32 in either storage mode
+        ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2f if mode == "f16x3" else E * (2 * W2b + C_FEA * 4) + N * W2f
         hbm_alg = {"edge_z": ez_bytes,
-                   "edge_seg_bwd": E * 2 * W2b + N * (W2b + W2b // 2),       # Z read, gZ written, Gi written, gS read
+                   "edge_seg_bwd": E * 2 * W2b + N * (W2f + W2f // 2),       # Z read, gZ written, Gi written, gS read
                    "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
                    "edge_gw": E * (W2b + C_FEA * (4 if mode == "f16x3" else 6))}   # gZ read, fp16x2 / bf16x3 planes of e read
         if stress:
@@ -629,7 +634,9 @@ def main():
             "metric": metric,
             "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "bilinear_mode": mode,
+            "vs_baseline": None, "dtype": dtype + ("; Z / gZ of the edge phase stored as bf16 (tolerance 1e-2)"
+                                                   if args.edge_storage == "bf16" else ""),
+            "data": "synthetic", "bilinear_mode": mode, "edge_storage": args.edge_storage,
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
                                     f"{K_used} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention" +
                                     (f", closed chunks of <= {P.chunked.max_edges_per_pass()} edges with per-chunk "

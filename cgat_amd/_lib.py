@@ -132,6 +132,8 @@ PROTOTYPES = {
     "cgat_mlp_chain": (C.c_int, [C.POINTER(ChainDesc), vp, C.c_size_t, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
+    "cgat_set_edge_storage": (None, [C.c_int32]),
+    "cgat_get_edge_storage": (C.c_int32, []),
     "cgat_set_bilinear_mode": (None, [C.c_int32]),
     "cgat_get_bilinear_mode": (C.c_int32, []),
     "cgat_bilinear_rows_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -1128,14 +1128,17 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
       if (bilinear_mode() == 6)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<6>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
                            (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
-      else if (bilinear_mode() == 2 && getenv("CGAT_RING_ABL")) {   // timing-only ablations (wrong results): dev knob
+#ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/ring_ablation.py
+      else if (bilinear_mode() == 2 && getenv("CGAT_RING_ABL")) {
 #define RG_ABL(A_) hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2, A_>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax)
         switch (atoi(getenv("CGAT_RING_ABL"))) {
           case 1: RG_ABL(1); break; case 2: RG_ABL(2); break; case 3: RG_ABL(3); break; case 4: RG_ABL(4); break;
           case 7: RG_ABL(7); break; case 8: RG_ABL(8); break; case 15: RG_ABL(15); break; default: RG_ABL(0); break;
         }
 #undef RG_ABL
-      } else if (bilinear_mode() == 2)
+      }
+#endif
+      else if (bilinear_mode() == 2)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
                            (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
       else
@@ -1148,8 +1151,12 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
         const char* ev = getenv("CGAT_BIL_VARIANT");
         variant = ev ? atoi(ev) : 162;
       }
+#ifdef CGAT_DEV_ABLATIONS
       const char* ev2 = getenv("CGAT_BIL_VARIANT_LIVE");  // re-read on every call (A/B in one process)
       const int v = ev2 ? atoi(ev2) : variant;
+#else
+      const int v = variant >= 900 ? 162 : variant;       // 90x = timing-only ablations: dev builds only
+#endif
 #define BIL_LAUNCH(JS_, FL_)                                                                                     \
   hipLaunchKernelGGL((bilinear_rows128_kernel<JS_, FL_>), dim3(tiles * sp), dim3(256), 0, stream, p, ldp, q, ldq, \
                      T, init, ldi, dst, dld, nrows, NA, tiles, sp, stride)
@@ -2111,8 +2118,12 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     splits = cdiv(np, rps);
     {
       CGAT_PROF("bilinear_wgrad", stream);
+#ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/wgrad_ablation.py
       static int abl = -1;
       if (abl < 0) { const char* e = getenv("CGAT_WGRAD_ABL"); abl = e ? atoi(e) : 0; }
+#else
+      const int abl = 0;
+#endif
 #define WG_GO(A_) hipLaunchKernelGGL((bilinear_wgrad128_bf16_kernel<6, A_>), dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT, (const uint4*)Rq, slab, np, rps, NA, (const float*)mx)
       if (f16)
         hipLaunchKernelGGL(bilinear_wgrad128_bf16_kernel<2>, dim3(cdiv(NA, 2), splits), dim3(512), 0, stream, pT, qT,

@@ -12,7 +12,8 @@
 
 // Wq: prepare_T_bf16 planes of the operand (a = 128-column block of gZ, b = column in block, c = output) =
 // W_e[128 a + b][c]; chunk (a, half, s) = 12 KB at Wq + ((a*2 + half)*4 + s) * 768 uint4.
-template <int PASSES>
+// GB: the operand is stored as bf16 (the "bf16" edge-storage mode; ldg / gzb count elements either way)
+template <int PASSES, bool GB = false>
 __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Wq, int ncb,
                                                          float* __restrict__ out, long ldo,
@@ -34,6 +35,8 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   // column-blocked gZ, (W2, 128) for a plain row-major matrix
   const float* ga = gZ + rca * ldg + 8 * kg;     // + a * gzb + 32 s
   const float* gb = gZ + rcb * ldg + 8 * kg;
+  const __bf16* ga16 = reinterpret_cast<const __bf16*>(gZ) + rca * ldg + 8 * kg;
+  const __bf16* gb16 = reinterpret_cast<const __bf16*>(gZ) + rcb * ldg + 8 * kg;
   const int nk = ncb * 4;
 
   f32x4 acc[16];
@@ -70,9 +73,15 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #define GE_ALOAD(ks_, A0_, A1_, B0_, B1_)                                                                \
   {                                                                                                      \
     const long off = (long)((ks_) >> 2) * gzb + 32 * ((ks_) & 3);                                        \
-    const float4* pa = reinterpret_cast<const float4*>(ga + off);                                        \
-    const float4* pb = reinterpret_cast<const float4*>(gb + off);                                        \
-    A0_ = pa[0]; A1_ = pa[1]; B0_ = pb[0]; B1_ = pb[1];                                                  \
+    if constexpr (GB) {                                                                                  \
+      const uint4 ua = *reinterpret_cast<const uint4*>(ga16 + off), ub = *reinterpret_cast<const uint4*>(gb16 + off); \
+      A0_ = unpack4_bf16(make_uint2(ua.x, ua.y)); A1_ = unpack4_bf16(make_uint2(ua.z, ua.w));            \
+      B0_ = unpack4_bf16(make_uint2(ub.x, ub.y)); B1_ = unpack4_bf16(make_uint2(ub.z, ub.w));            \
+    } else {                                                                                             \
+      const float4* pa = reinterpret_cast<const float4*>(ga + off);                                      \
+      const float4* pb = reinterpret_cast<const float4*>(gb + off);                                      \
+      A0_ = pa[0]; A1_ = pa[1]; B0_ = pb[0]; B1_ = pb[1];                                                \
+    }                                                                                                    \
   }
 #define GE_SPLIT(R0_, R1_, Q1_, Q2_, Q3_)                                                                \
   {                                                                                                      \
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int PASSES>
+template <int PASSES, bool GB = false>   // GB: gZ stored as bf16
 __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Eq, float* __restrict__ slab,
                                                          int E, int ncb, int nsteps, int S,
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   const int ks0 = (int)((long)nsteps * split / S), ks1 = (int)((long)nsteps * (split + 1) / S);
   const int cb128 = pair * 2 + grp;
   const float* gblk = gZ + (long)cb128 * gzb;
+  const __bf16* gblk16 = reinterpret_cast<const __bf16*>(gZ) + (long)cb128 * gzb;
   const int gt = tid & 255;                              // thread within the column block's group
 
   f32x4 acc[16];
@@ -242,8 +252,11 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   {                                                                                                      \
     const int idx = gt + 256 * (i_);                                                                     \
     const long t = (long)(ks_) * 32 + (idx >> 5);                                                        \
-    R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * ldg + 4 * (idx & 31))                       \
-               : make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+    if constexpr (GB)                                                                                    \
+      R_ = t < E ? load4_bf16(gblk16 + t * ldg + 4 * (idx & 31)) : make_float4(0.f, 0.f, 0.f, 0.f);      \
+    else                                                                                                 \
+      R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * ldg + 4 * (idx & 31))                     \
+                 : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
   }
 #define GW_GLOAD(ks_, A_, B_, C_, D_) { GW_G1(ks_, 0, A_) GW_G1(ks_, 1, B_) GW_G1(ks_, 2, C_) GW_G1(ks_, 3, D_) }
   // split one float4 (row idx >> 5, columns 4 (idx & 31) ...) and store 8 bytes per plane into image (b)
@@ -381,7 +394,7 @@ bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, 
 // amax (f16x3 mode only): device pointer to max |gZ|; without it the bf16x6 form runs.
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
-                   hipStream_t stream, const float* amax) {
+                   hipStream_t stream, const float* amax, int g_bf16) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   const bool f16 = bilinear_mode() == 2 && amax && s_out == 1 && (s_col % 4) == 0 && (((uintptr_t)We) & 15) == 0;
@@ -396,7 +409,11 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   }
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);   // the per-edge launch / node-side and dense-layer uses
   const int grid = cdiv(E, 256);
-  if (f16)
+  CGAT_CHECK_ARG(!g_bf16 || f16, "edge_ge: the bf16-stored operand needs the f16x3 form");
+  if (f16 && g_bf16)
+    hipLaunchKernelGGL((edge_ge_kernel<2, true>), dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out,
+                       ldo, scatter, E, accumulate, bias, amax);
+  else if (f16)
     hipLaunchKernelGGL(edge_ge_kernel<2>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
                        scatter, E, accumulate, bias, amax);
   else if (bilinear_mode() != 3)
@@ -427,7 +444,7 @@ size_t edge_gw_ws_floats(int E, int W2) {
 // out[col * ldo + k] = sum_t G[t, col] * e[perm[t] * lde + k],   G[t, 128 a + j] at gZ[t * ldg + a * gzb + j]
 // gmax, emax (f16x3 mode only): device pointers to max |gZ| and max |e|; without them the bf16x6 form runs.
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
-                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax, const float* emax) {
+                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax, const float* emax, int g_bf16) {
   if (E <= 0) {
     GemmParams z = gemm_params(W2, 128, 0, nullptr, 1, nullptr, 1, out, ldo);
     return gemm_launch(z, nullptr, 0, stream);   // K = 0: zero fill
@@ -437,11 +454,15 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
   float* slab = ws + (((size_t)na * 128 * 128 * 3 + 1) / 2 + 15) / 16 * 16;
   // operand (a = slot block, b = slot in block, c = k) = e[perm[128 a + b] * lde + c], zero past E
   const bool f16 = bilinear_mode() == 2 && gmax && emax;
+  CGAT_CHECK_ARG(!g_bf16 || f16, "edge_gw: the bf16-stored operand needs the f16x3 form");
   CGAT_TRY(prepare_T_bf16_rows_launch(e, lde, perm, E, planes, na, stream, f16 ? emax : nullptr));
   {
     CGAT_PROF(perm ? "edge_gw" : "rows_gw", stream);
     const int nsteps = cdiv(E, 32);
-    if (f16)
+    if (f16 && g_bf16)
+      hipLaunchKernelGGL((edge_gw_kernel<2, true>), dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb,
+                         (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax);
+    else if (f16)
       hipLaunchKernelGGL(edge_gw_kernel<2>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
                          slab, E, ncb, nsteps, S, gmax, emax);
     else if (bilinear_mode() != 3)

@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 // Operand: prepare_W2_f16 planes, chunk (a, half, s) = 8 KB at Wq + ((a*2 + half)*8 + s) * 512 uint4, s < 4 the W_e
 // k-steps, s >= 4 the W_j ones, one scale per column block a over both (wmax behind the planes); the row scale is the
 // maximum over the concatenated 256-value row.
-template <int ABL>   // timing-only ablations (wrong results): 1 no Z stores, 2 no Pi loads, 4 no logits
+// ZB: Z is stored as bf16 (the "bf16" edge-storage mode: half the bytes of the store that bounds this kernel; the
+// logits are still taken from the fp32 values in registers)
+template <int ABL, bool ZB = false>   // ABL: timing-only ablations (wrong results): 1 no Z stores, 2 no Pi loads, 4 no logits
 __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict__ e, long lde,
                                                          const int* __restrict__ perm, const float* __restrict__ xn,
                                                          long ldx, const uint4* __restrict__ Wq, int ncb,
@@ -356,6 +358,8 @@ __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict
   const float* pib = Pi + (long)dsti[rcb] * ld_add;
   float* za = Z + (long)rca * ldz;
   float* zb = Z + (long)rcb * ldz;
+  __bf16* za16 = reinterpret_cast<__bf16*>(Z) + (long)rca * ldz;
+  __bf16* zb16 = reinterpret_cast<__bf16*>(Z) + (long)rcb * ldz;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 #define EX_TLOAD(gi_)                                                                          \
@@ -458,8 +462,13 @@ __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict
         // no `row < E` guard: the ring's vmcnt allowances count exactly eight stores per epilogue, and a wave whose
         // second row block lies past the end would skip four of them (lanes past the end hold the clamped row E - 1
         // and rewrite it with identical values)
-        if (!(ABL & 1) || va.x == 1234.5f) *reinterpret_cast<float4*>(za + col) = va;
-        if (!(ABL & 1) || vb.x == 1234.5f) *reinterpret_cast<float4*>(zb + col) = vb;
+        if constexpr (ZB) {
+          store4_bf16(za16 + col, va);
+          store4_bf16(zb16 + col, vb);
+        } else {
+          if (!(ABL & 1) || va.x == 1234.5f) *reinterpret_cast<float4*>(za + col) = va;
+          if (!(ABL & 1) || vb.x == 1234.5f) *reinterpret_cast<float4*>(zb + col) = vb;
+        }
         if (isA && !(ABL & 4)) {
           const float4 w = *reinterpret_cast<const float4*>(wA + col);
           dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
@@ -543,19 +552,24 @@ bool edge_zx_fast(int C, int Ce, int W2, int H, int Hd, long ld_add, long ldz, c
 // We / Wj: the edge_attr and x_j slices of the stacked first-layer weight (row stride ldw); Wq: edge_zx_wq_floats(W2)
 int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, long ldx, const float* We, const float* Wj,
                    long ldw, float* Wq, int W2, const float* Pi, const int* dsti, const int* srci, long ld_add, float* Z,
-                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream) {
+                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int z_bf16) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   hipLaunchKernelGGL(prepare_W2_f16_kernel, dim3(ncb), dim3(256), 0, stream, We, Wj, ldw, (_Float16*)Wq,
                      Wq + (size_t)ncb * 32768);
   CGAT_LAUNCH_CHECK();
   CGAT_PROF("edge_z", stream);
-#define EZX_GO(A_) hipLaunchKernelGGL(edge_zx_kernel<A_>, dim3(cdiv(E, 128)), dim3(256), 0, stream, e, lde, perm, x, ldx, (const uint4*)Wq, ncb, Pi, dsti, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
-  const char* abl = getenv("CGAT_EZX_ABL");   // dev knob, timing only
+#define EZX_GO(A_, ZB_) hipLaunchKernelGGL((edge_zx_kernel<A_, ZB_>), dim3(cdiv(E, 128)), dim3(256), 0, stream, e, lde, perm, x, ldx, (const uint4*)Wq, ncb, Pi, dsti, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
+#ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results) exist only in builds made for tools/edgez_ablation.sh
+  const char* abl = getenv("CGAT_EZX_ABL");
   switch (abl ? atoi(abl) : 0) {
-    case 1: EZX_GO(1); break; case 2: EZX_GO(2); break; case 3: EZX_GO(3); break; case 7: EZX_GO(7); break;
-    default: EZX_GO(0); break;
+    case 1: EZX_GO(1, false); break; case 2: EZX_GO(2, false); break; case 3: EZX_GO(3, false); break; case 7: EZX_GO(7, false); break;
+    default: EZX_GO(0, false); break;
   }
+#else
+  if (z_bf16) EZX_GO(0, true);
+  else EZX_GO(0, false);
+#endif
 #undef EZX_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;

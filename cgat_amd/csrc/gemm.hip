@@ -483,8 +483,12 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   dim3 grid(8 * inner * cdiv(outer, 8));
   {
     CGAT_PROF("gemm_f32", stream);
+#ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/gemm_probe.py
     const char* ab = getenv("CGAT_GEMM_ABL");
     const int abl = ab ? atoi(ab) : 0;
+#else
+    const int abl = 0;
+#endif
     if (abl == 1 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
     else if (abl == 2 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, stream, p);
     else if (abl == 4 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4>), grid, dim3(256), 0, stream, p);

@@ -95,7 +95,8 @@ bool edge_zx_fast(int C, int Ce, int W2, int H, int Hd, long ld_add, long ldz, c
                   const void* Pi, const void* Z, const void* wA);
 int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, long ldx, const float* We, const float* Wj,
                    long ldw, float* Wq, int W2, const float* Pi, const int* dsti, const int* srci, long ld_add, float* Z,
-                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream);
+                   long ldz, int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
+                   int z_bf16 = 0);   // z_bf16: Z stored as bf16 (ldz in elements either way)
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
@@ -154,12 +155,14 @@ bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);
 size_t edge_gw_ws_floats(int E, int W2);
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
                    float* ws, float* out, long ldo, hipStream_t stream, const float* gmax = nullptr,
-                   const float* emax = nullptr);   // device maxima of |gZ| and |e| -> fp16 form in the f16x3 mode
+                   const float* emax = nullptr, int g_bf16 = 0);   // device maxima of |gZ| and |e| -> fp16 form in the
+                                                                   // f16x3 mode; g_bf16: gZ stored as bf16
 bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
                    hipStream_t stream,
-                   const float* amax = nullptr);   // amax: device max |gZ| -> fp16 form in the f16x3 mode
+                   const float* amax = nullptr, int g_bf16 = 0);   // amax: device max |gZ| -> fp16 form in the f16x3 mode;
+                                                                   // g_bf16: gZ stored as bf16 (ldg, gzb in elements)
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);
@@ -193,7 +196,7 @@ int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float*
                            const int* rowptr, int S, int F, float* ga, float* gmult, hipStream_t s);
 // out[s, f] = sum_{r in seg s} w[r, f / fw] * act(x[r or ridx[r], f])      (w nullable, fw = features per weight)
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
-                    int F, int act, float* out, long ldo, hipStream_t s, long xblock = 0);
+                    int F, int act, float* out, long ldo, hipStream_t s, long xblock = 0, int x_bf16 = 0);   // x_bf16: x holds bf16 (ldx, xblock in elements)
 // softmax-weighted segment sum (attention pooling) in one pass per direction, see segment.hip
 bool seg_attnpool_fast(int aF, int F, long ldm, const void* a, const void* m, const void* out);
 int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,

@@ -173,7 +173,8 @@ __device__ __forceinline__ float wave_sum_l(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-template <bool VEC>
+// ZB (with VEC): Z is read and gZ written as bf16 (the "bf16" edge-storage mode; offsets count elements either way)
+template <bool VEC, bool ZB = false>
 __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restrict__ Z, float* __restrict__ gZ,
                                                            long gz_block, const float* __restrict__ alpha,
                                                            const float* __restrict__ gS, const float* __restrict__ gs,
@@ -202,9 +203,10 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
         float part = 0.f;
         if (VEC) {
           const float4* z4 = reinterpret_cast<const float4*>(zM + h * Hd);
+          const __bf16* z16 = reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + HHd + h * Hd;
           const float4* g4 = reinterpret_cast<const float4*>(gSn + h * Hd);
           for (int j = lane; j < Hd / 4; j += 64) {
-            float4 z = z4[j], g = g4[j];
+            float4 z = ZB ? load4_bf16(z16 + 4 * j) : z4[j], g = g4[j];
             part += (z.x > 0.f ? z.x : 0.01f * z.x) * g.x + (z.y > 0.f ? z.y : 0.01f * z.y) * g.y +
                     (z.z > 0.f ? z.z : 0.01f * z.z) * g.z + (z.w > 0.f ? z.w : 0.01f * z.w) * g.w;
           }
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int t = r0 + u < r1 ? r0 + u : r1 - 1;
-          zn[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+          zn[u] = ZB ? load4_bf16(reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + col)
+                     : *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
           cn[u] = coef[(long)t * H + h];
         }
         for (int tb = r0; tb < r1; tb += 4) {
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int t = tb + 4 + u < r1 ? tb + 4 + u : r1 - 1;
-              zn[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+              zn[u] = ZB ? load4_bf16(reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + col)
+                         : *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
               cn[u] = coef[(long)t * H + h];
             }
           }
@@ -287,8 +291,15 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
                 const float al = cf[u];
                 g = make_float4(al * gsv.x * d.x, al * gsv.y * d.y, al * gsv.z * d.z, al * gsv.w * d.w);
               }
-              float* dst = gz_block ? gZ + (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : gZ + (long)t * W2 + col;
-              *reinterpret_cast<float4*>(dst) = g;
+              const long doff = gz_block ? (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : (long)t * W2 + col;
+              if constexpr (ZB) {
+                // the segment sum and the maximum are taken from the ROUNDED values: they must describe the stored operand
+                const uint2 pk = pack4_bf16(g);
+                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(gZ) + doff) = pk;
+                g = unpack4_bf16(pk);
+              } else {
+                *reinterpret_cast<float4*>(gZ + doff) = g;
+              }
               gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
               gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
             }
@@ -354,6 +365,26 @@ static AttnSaved attn_saved(float* saved, const AttnDims& d) {
   return s;
 }
 
+// ---- storage of the per-edge intermediates Z / gZ: 0 = fp32 (default), 1 = bf16 ("bf16 activations", BASELINE
+// configs[4]): halves the bytes that bound the edge phase; softmax statistics, sums and all matrix products stay as
+// they are (fp32 accumulation), stated tolerance 1e-2 (tests/test_chunked.py).  Takes effect on the fused
+// scalar-attention route at the benchmark widths; everything else ignores it.
+static int g_edge_storage = -1;
+static int edge_storage() {
+  if (g_edge_storage < 0) {
+    const char* e = getenv("CGAT_EDGE_STORAGE");
+    g_edge_storage = (e && !strcmp(e, "bf16")) ? 1 : 0;
+  }
+  return g_edge_storage;
+}
+extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = mode == 1 ? 1 : 0; }
+extern "C" int32_t cgat_get_edge_storage(void) { return edge_storage(); }
+static bool attn_bf16(const AttnDims& d) {
+  return edge_storage() == 1 && bilinear_mode() == 2 && d.C == 128 && d.Ce == 128 && d.Hd % 128 == 0 && d.W2 % 256 == 0 &&
+         d.N > 0 && d.E > 0;
+}
+
+// (the saved buffer keeps its fp32 size in either storage mode: bf16 Z uses the first half of its region)
 extern "C" size_t cgat_nodes_attention_saved_floats(int32_t N, int32_t E, int32_t H, int32_t Hd) {
   size_t HHd = (size_t)H * Hd;
   return (size_t)E * 2 * HHd + (size_t)E * H + (size_t)N * HHd + (size_t)N * H;
@@ -406,9 +437,10 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   // and the attention logits a[t,h] = fc_out_A(leaky(zA)): one fused split-bf16 kernel at the benchmark widths,
   // the generic GEMM + row-dot otherwise (and in the f32 arithmetic mode)
   const bool fused_z = !c.dry && edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Pi, Pj, sv.Z, p->A_out_w);
+  const bool zb = zx && attn_bf16(d);     // Z stored as bf16 (edge-storage mode "bf16")
   if (zx) {
     RUN(edge_zx_launch(e, d.Ce, plan->dst_perm, x, d.C, Wcat + d.C, Wcat + d.C + d.Ce, d.D, Wq, d.W2, Pi, plan->dst_sorted,
-                       plan->src_sorted, d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
+                       plan->src_sorted, d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, zb ? 1 : 0));
   } else if (fused_z) {
     RUN(edge_z_launch(e, d.Ce, plan->dst_perm, Wcat + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted,
                       d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
@@ -424,8 +456,9 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
     RUN(rowdot_launch(sv.Z, d.W2, CGAT_ACT_LEAKY, p->A_out_w, 0, nullptr, p->A_out_b, nullptr, d.E, d.H, d.Hd, a, c.s));
   RUN(seg_softmax_fwd_launch(a, nullptr, plan->dst_rowptr, d.N, d.H, 1e-16f, sv.alpha, sv.ssum, c.s));
   // S[n,h,:] = sum_{t -> n} alpha[t,h] leaky(zM[t,h,:])  -- fc_out of MH_M commutes with the weighted sum
-  RUN(seg_wsum_launch(sv.Z + d.HHd, d.W2, nullptr, sv.alpha, d.H, d.Hd, plan->dst_rowptr, d.N, d.HHd, CGAT_ACT_LEAKY,
-                      sv.S, d.HHd, c.s));
+  RUN(seg_wsum_launch(zb ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(sv.Z) + d.HHd) : sv.Z + d.HHd, d.W2,
+                      nullptr, sv.alpha, d.H, d.Hd, plan->dst_rowptr, d.N, d.HHd, CGAT_ACT_LEAKY, sv.S, d.HHd, c.s, 0,
+                      zb ? 1 : 0));
   for (int h = 0; h < d.H; ++h) {
     GemmParams g = gemm_params(d.N, d.C, d.Hd, sv.S + (size_t)h * d.Hd, d.HHd, p->M_out_w + (size_t)h * d.C * d.Hd,
                                d.Hd, aggr, d.C);
@@ -450,13 +483,17 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
 static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* Wcat,
                                           float* gWcat, float* gbcat, const float* gZ, long gz_ld, long gzb, float* Gi,
                                           float* Gj, bool have_Gi, const float* x, const float* e, float* g_x, float* g_e,
-                                          float* Wq, float* gw_ws, const float* scales = nullptr) {
+                                          float* Wq, float* gw_ws, const float* scales = nullptr, bool g_bf16 = false) {
+  // g_bf16: gZ is stored as bf16 (the per-edge launches and the two segment sums read it as such)
   // scales (f16x3 mode, optional): device {max |gZ|, max |e|} -> the per-edge products run on two fp16 planes
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
   // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
+  if (!c.dry && g_bf16)
+    CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && scales,
+                   "nodes_attention_backward: the bf16 edge storage needs the fp16 per-edge kernels");
   if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
     RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
-                       scales));
+                       scales, g_bf16 ? 1 : 0));
   } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = xb;
@@ -467,7 +504,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // grad W_e = gZ^T @ e[perm]
   if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
     RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s, scales,
-                       scales ? scales + 1 : nullptr));
+                       scales ? scales + 1 : nullptr, g_bf16 ? 1 : 0));
   } else {
     GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = xb;
@@ -477,9 +514,10 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   }
   // segment sums of gZ: by destination (x_i side) unless the caller already has them, by source (x_j side)
   if (!have_Gi)
-    RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
+    RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb,
+                        g_bf16 ? 1 : 0));
   RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
-                      c.s, xb));
+                      c.s, xb, g_bf16 ? 1 : 0));
   // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
   // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
@@ -564,7 +602,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   }
   // g_alpha, softmax backward, gZ, the destination-side segment sum Gi and the partial sums for
   // grad fc_out_A, all per whole destination segment in one pass (edge_seg_bwd_kernel)
-  bool have_scales = false;
+  bool have_scales = false, zb = false;
   if (!c.dry && d.N > 0) {
     CGAT_CHECK_ARG(d.H <= 16, "nodes_attention_backward: more than 16 heads");
     CGAT_PROF("edge_seg_bwd", c.s);
@@ -573,7 +611,14 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
                                           ((uintptr_t)p->A_out_w)) & 15) == 0;
     have_scales = vec && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0;
     if (have_scales) CGAT_HIP(hipMemsetAsync(scales, 0, 2 * sizeof(float), c.s));
-    if (vec)
+    // the forward stored Z as bf16 under exactly this predicate (same tensors, same alignment)
+    zb = attn_bf16(d) && edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
+         edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
+    if (zb) {
+      CGAT_CHECK_ARG(vec && have_scales && gzb, "nodes_attention_backward: the bf16 edge storage needs the vector form");
+      hipLaunchKernelGGL((edge_seg_bwd_kernel<true, true>), dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, scales);
+    } else if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
                          plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial,
                          have_scales ? scales : (float*)nullptr);
@@ -586,7 +631,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, gZ, gz_ld, gzb, Gi, Gj, true, x, e, g_x, g_e, Wq,
-                                          gw_ws, have_scales ? scales : nullptr));
+                                          gw_ws, have_scales ? scales : nullptr, zb));
   RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));

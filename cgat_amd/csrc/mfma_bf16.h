@@ -83,6 +83,20 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 STORAGE of activations (the edge phase's Z / gZ in the "bf16" edge-storage mode, BASELINE configs[4]) ----
+// four fp32 -> four bf16 (round to nearest even, two v_cvt_pk_bf16_f32) as 8 bytes, and back (exact)
+__device__ __forceinline__ uint2 pack4_bf16(float4 v) {
+  const bf16x2 a = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+  const bf16x2 b = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+__device__ __forceinline__ float4 unpack4_bf16(uint2 u) {
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 load4_bf16(const __bf16* p) { return unpack4_bf16(*reinterpret_cast<const uint2*>(p)); }
+__device__ __forceinline__ void store4_bf16(__bf16* p, float4 v) { *reinterpret_cast<uint2*>(p) = pack4_bf16(v); }
+
 // at most one atomic per workgroup (thousands of same-address atomics cost more than the pass itself)
 __device__ __forceinline__ void block_absmax_commit(float m, float* out) {
   __shared__ float wm[16];

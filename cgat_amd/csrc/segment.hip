@@ -7,6 +7,7 @@
 // order, so results are bitwise reproducible.
 #include "common.h"
 #include "kernels.h"
+#include "mfma_bf16.h"
 
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -153,9 +154,61 @@ __global__ __launch_bounds__(256) void seg_wsum_vec_kernel(const float* __restri
   }
 }
 
+// the same with x stored as bf16 (the "bf16" edge-storage mode: ldx / xblock count bf16 elements)
+template <int SEG_U>
+__global__ __launch_bounds__(256) void seg_wsum_vec_bf16_kernel(const __bf16* __restrict__ x, long ldx,
+                                                                const int* __restrict__ ridx, const float* __restrict__ w,
+                                                                int wF, int fw, const int* __restrict__ rowptr, int F,
+                                                                int act, float* __restrict__ out, long ldo, long xblock) {
+  const int s = blockIdx.x;
+  const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
+    const int wf = w ? f / fw : 0;
+    const __bf16* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
+    const long pitch = xblock ? 128 : ldx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; r += SEG_U) {
+      float4 v[SEG_U];
+      float wv[SEG_U];
+#pragma unroll
+      for (int u = 0; u < SEG_U; ++u) {
+        const int rr = r + u < r1 ? r + u : r1 - 1;
+        const long row = ridx ? (long)ridx[rr] : (long)rr;
+        v[u] = load4_bf16(xb + row * pitch);
+        wv[u] = w ? w[(long)rr * wF + wf] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SEG_U; ++u) {
+        if (r + u < r1) {
+          acc.x += act_f(v[u].x, act) * wv[u];
+          acc.y += act_f(v[u].y, act) * wv[u];
+          acc.z += act_f(v[u].z, act) * wv[u];
+          acc.w += act_f(v[u].w, act) * wv[u];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + (long)s * ldo + f) = acc;
+  }
+}
+
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
-                    int F, int act, float* out, long ldo, hipStream_t s, long xblock) {
+                    int F, int act, float* out, long ldo, hipStream_t s, long xblock, int x_bf16) {
   if (S <= 0 || F <= 0) return CGAT_OK;
+  if (x_bf16) {
+    CGAT_CHECK_ARG((F % 4) == 0 && (!w || (fw % 4) == 0) && (ldx % 4) == 0 && (ldo % 4) == 0 && (xblock % 4) == 0 &&
+                   (((uintptr_t)x) & 7) == 0 && (((uintptr_t)out) & 15) == 0, "seg_wsum: bf16 input needs the vector shape");
+    int threads = F >= 1024 ? 256 : (F >= 512 ? 192 : 64);
+    if (F / 4 < threads) threads = ((F / 4 + 63) / 64) * 64;
+    const __bf16* xb = reinterpret_cast<const __bf16*>(x);
+    if (ridx)
+      hipLaunchKernelGGL(seg_wsum_vec_bf16_kernel<4>, dim3(S), dim3(threads), 0, s, xb, ldx, ridx, w, wF, fw, rowptr, F, act,
+                         out, ldo, xblock);
+    else
+      hipLaunchKernelGGL(seg_wsum_vec_bf16_kernel<12>, dim3(S), dim3(threads), 0, s, xb, ldx, ridx, w, wF, fw, rowptr, F, act,
+                         out, ldo, xblock);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   const bool vec = (F % 4) == 0 && (!w || (fw % 4) == 0) && (ldx % 4) == 0 && (ldo % 4) == 0 && (xblock % 4) == 0 &&
                    ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
   if (vec) {

@@ -173,7 +173,7 @@ class NodesAttentionFn(torch.autograd.Function):
             check(lib.cgat_nodes_attention_forward(C.byref(plan.c), C.byref(p), _ptr(x), _ptr(edge_attr), _ptr(aggr),
                                                    _ptr(saved), _ptr(ws), ws.numel(), _stream()),
                   "cgat_nodes_attention_forward")
-        ctx.plan, ctx.H = plan, H
+        ctx.plan, ctx.H, ctx.storage = plan, H, lib.cgat_get_edge_storage()
         ctx.save_for_backward(x, edge_attr, saved, *weights)
         return aggr
 
@@ -189,7 +189,7 @@ class NodesAttentionFn(torch.autograd.Function):
         grads = [torch.empty_like(w) for w in weights]
         g = _lib.AttnGrads(*[t.data_ptr() for t in grads])
         ws = workspace(lib.cgat_nodes_attention_backward_workspace_bytes(C.byref(plan.c), C.byref(p)), dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _storage_of(ctx.storage):
             check(lib.cgat_nodes_attention_backward(C.byref(plan.c), C.byref(p), _ptr(x), _ptr(edge_attr), _ptr(saved),
                                                     _ptr(g_aggr), _ptr(g_x), _ptr(g_e), C.byref(g), _ptr(ws),
                                                     ws.numel(), _stream()), "cgat_nodes_attention_backward")
@@ -365,6 +365,7 @@ class NodeLayerFn(torch.autograd.Function):
             check(lib.cgat_hnet_forward(N, C.byref(ph), _ptr(h0), _ptr(aggr), _ptr(y), _ptr(saved_h), _ptr(ws), ws.numel(),
                                         _stream()), "cgat_hnet_forward")
         ctx.plan, ctx.H, ctx.n_fc, ctx.n_hyper, ctx.has_d = plan, H, n_fc, n_hyper, d is not None
+        ctx.storage = lib.cgat_get_edge_storage()
         ctx.save_for_backward(x, edge_attr, h0, aggr, saved_a, saved_h, *([d] if d is not None else []), *attn_w, *flat)
         return y
 
@@ -398,9 +399,10 @@ class NodeLayerFn(torch.autograd.Function):
                                                     main.cuda_stream, _ptr(side_ws), side_ws.numel(), s2.cuda_stream),
                   "cgat_hnet_backward_overlapped")
             ws_a = workspace(lib.cgat_nodes_attention_backward_workspace_bytes(C.byref(plan.c), C.byref(pa)), dev)
-            check(lib.cgat_nodes_attention_backward(C.byref(plan.c), C.byref(pa), _ptr(x), _ptr(edge_attr), _ptr(saved_a),
-                                                    _ptr(g_aggr), _ptr(g_x), _ptr(g_e), C.byref(ga), _ptr(ws_a),
-                                                    ws_a.numel(), main.cuda_stream), "cgat_nodes_attention_backward")
+            with _storage_of(ctx.storage):
+                check(lib.cgat_nodes_attention_backward(C.byref(plan.c), C.byref(pa), _ptr(x), _ptr(edge_attr), _ptr(saved_a),
+                                                        _ptr(g_aggr), _ptr(g_x), _ptr(g_e), C.byref(ga), _ptr(ws_a),
+                                                        ws_a.numel(), main.cuda_stream), "cgat_nodes_attention_backward")
             main.wait_stream(s2)     # every gradient is complete, in stream order, when this node returns
         return (g_x, g_e, g_h0, None, None, g_d, None, None, *g_attn, *g_flat)
 
@@ -865,6 +867,31 @@ def set_bilinear_mode(mode):
 def get_bilinear_mode():
     m = lib.cgat_get_bilinear_mode()
     return {v: k for k, v in _MODES.items()}[m]
+
+
+def set_edge_storage(mode):
+    """Storage of the per-edge intermediates Z / gZ of the fused scalar-attention path: "f32" (default) or "bf16"
+    (BASELINE configs[4]'s "bf16 activations": half the HBM bytes of the edge phase, tolerance 1e-2; logits, softmax
+    statistics and all products unchanged).  Takes effect at C = Ce = 128 in the f16x3 arithmetic mode."""
+    lib.cgat_set_edge_storage({"f32": 0, "bf16": 1}[mode])
+
+
+def get_edge_storage():
+    return "bf16" if lib.cgat_get_edge_storage() == 1 else "f32"
+
+
+class _storage_of:
+    """Run a backward under the edge-storage mode its forward ran under."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib.cgat_get_edge_storage()
+        lib.cgat_set_edge_storage(self.mode)
+
+    def __exit__(self, *a):
+        lib.cgat_set_edge_storage(self.prev)
 
 
 def prof_enable(on=True):

@@ -307,6 +307,15 @@ typedef struct cgat_chain_desc {
 size_t cgat_mlp_chain_workspace_bytes(int32_t n_layers);
 int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_bytes, void* stream);
 
+/* Storage of the per-edge intermediates of cgat_nodes_attention_* (the pre-activations Z saved by forward and their
+ * gradient gZ inside backward): 0 = fp32 (default), 1 = bf16 ("bf16 activations" of BASELINE configs[4]): halves the
+ * bytes that bound the edge phase; attention logits, softmax statistics, sums and every matrix product stay as they
+ * are (fp32 accumulation); tolerance of that mode 1e-2 max-norm relative.  Effective at C = Ce = 128 in the f16x3
+ * arithmetic mode, ignored elsewhere.  A backward call must run under the mode its forward ran under.
+ * Env CGAT_EDGE_STORAGE = bf16 sets the start value. */
+void cgat_set_edge_storage(int32_t mode);
+int32_t cgat_get_edge_storage(void);
+
 /* ---- kernel-level primitives (what the layer entry points above are composed of) --------- */
 /* C = act(alpha * A.B + bias + add1[add1_idx[m]] + add2[add2_idx[m]]) + beta * C on the fp32 matrix
  * cores.  A(m,k) = A[row(m)*lda + k] (a_kmajor=0, row(m)=a_rgather?a_rgather[m]:m) or A[k*lda + m]

@@ -173,3 +173,80 @@ def test_config5_locality_at_8m_edges():
     far = torch.zeros(N, dtype=torch.bool, device=dev)
     far[:1000 * A] = True
     assert torch.equal(y1[far], y2[far]) and torch.equal(gx1[far], gx2[far])
+
+
+@pytest.mark.gpu
+def test_config5_bf16_edge_storage_vs_oracle():
+    """The "bf16 activations" of BASELINE configs[4]: Z / gZ of the per-edge phase stored as bf16 (logits, softmax
+    statistics, sums and products unchanged).  K = 64 layer on 6 crystals against the oracle's fp64 run: stated
+    tolerance of the mode 1e-2 max-norm relative for outputs and all gradients (fp32 storage: 1e-4); and the mode is
+    really on (results differ from the fp32-storage run by more than 1e-6)."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    dev = "cuda:0"
+    b, _ = P.synthetic_batch(6, 20, 64, seed=47)
+    g = torch.Generator().manual_seed(48)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0, cot = (torch.randn(n, 128, generator=g) for n in (N, E, N, N))
+    torch.manual_seed(1)
+    om = O.GATConvNodes(128, 128, 128, 3, concat=True).double()
+    pm = P.GATConvNodes(128, 128, 128, 3, concat=True)
+    pm.load_state_dict({k: v.float() for k, v in om.state_dict().items()})
+    pm = pm.to(dev)
+    xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
+    yo = om(xo, b.edge_index, eo, x0.double())
+    go = torch.autograd.grad((yo * cot.double()).sum(), [xo, eo] + list(om.parameters()))
+
+    def run():
+        xp, ep = x.to(dev).requires_grad_(True), e.to(dev).requires_grad_(True)
+        y = pm(xp, b.edge_index.to(dev), ep, x0.to(dev))
+        return y.detach(), torch.autograd.grad((y * cot.to(dev)).sum(), [xp, ep] + list(pm.parameters()))
+    assert P.get_edge_storage() == "f32"
+    y32, g32 = run()
+    P.set_edge_storage("bf16")
+    try:
+        y16, g16 = run()
+    finally:
+        P.set_edge_storage("f32")
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max())
+    assert rel(y16, yo.detach()) <= 1e-2
+    scale = max(float(r.abs().max()) for r in go)
+    worst = 0.0
+    for a, r in zip(g16, go):
+        err = float((a.double().cpu() - r).abs().max())
+        worst = max(worst, err / max(float(r.abs().max()), 1e-3 * scale))
+    assert worst <= 1e-2, worst
+    assert rel(y16, y32.double().cpu()) > 1e-6          # the mode is on
+    assert rel(y32, yo.detach()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_edge_storage_at_1m_edges_matches_fp32_storage():
+    """E = 1 000 080 (the benchmark batch): outputs and gradients in the bf16 edge-storage mode stay within 2e-2 of the
+    fp32-storage run, per tensor in max-norm."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    b, _ = P.synthetic_batch(4167, 20, 12, seed=0)
+    g = torch.Generator().manual_seed(50)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    x, e, x0, cot = (torch.randn(n, 128, generator=g).to(dev) for n in (N, E, N, N))
+    ei = b.edge_index.to(dev)
+    torch.manual_seed(1)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+
+    def run():
+        xx, ee = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+        y = layer(xx, ei, ee, x0)
+        return [y.detach()] + list(torch.autograd.grad((y * cot).sum(), [xx, ee] + list(layer.parameters())))
+    a = run()
+    P.set_edge_storage("bf16")
+    try:
+        c = run()
+    finally:
+        P.set_edge_storage("f32")
+    # per tensor, relative to its own largest entry (gradients: or 1 % of the layer's largest gradient, whichever is
+    # larger -- `damping`'s single-element gradient is a cancellation-dominated sum over all atoms and moves by 1.7 %)
+    scale = max(float(t.abs().max()) for t in a[1:])
+    for k, (u, v) in enumerate(zip(a, c)):
+        den = float(u.abs().max()) if k == 0 else max(float(u.abs().max()), 1e-2 * scale)
+        assert float((u - v).abs().max()) <= 2e-2 * den, (k, float((u - v).abs().max()), den)

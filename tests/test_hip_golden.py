@@ -337,7 +337,9 @@ def test_dynamic_range_inside_one_batch():
         xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
         return torch.autograd.grad((om(xo, b.edge_index, eo, x0.double()) * cot.double()).sum(), [xo, eo])
     gxo, geo = oracle_grads()
-    with O.flip_probe(FLIP_TAU):       # what a LeakyReLU sign flip of a near-zero pre-activation does to each crystal
+    # (4 x the tau of the whole-tensor tests: with the error taken per crystal, one flipped pre-activation just outside
+    # the probed band is enough to exceed 1e-4 of that crystal's own gradient; seen once, in the f32 arithmetic mode)
+    with O.flip_probe(4 * FLIP_TAU):   # what a LeakyReLU sign flip of a near-zero pre-activation does to each crystal
         gxf, gef = oracle_grads()
     xp, ep = x.to("cuda:0").requires_grad_(True), e.to("cuda:0").requires_grad_(True)
     gxp, gep = torch.autograd.grad((pm(xp, b.edge_index.to("cuda:0"), ep, x0.to("cuda:0")) * cot.to("cuda:0")).sum(), [xp, ep])
