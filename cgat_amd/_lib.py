@@ -130,6 +130,9 @@ PROTOTYPES = {
                                                        vp, vp, vp, C.c_int64, vp, vp]),
     "cgat_mlp_chain_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgat_mlp_chain": (C.c_int, [C.POINTER(ChainDesc), vp, C.c_size_t, vp]),
+    "cgat_dense_wgrad_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "cgat_dense_wgrad_batch": (C.c_int, [C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp,
+                                          C.c_size_t, vp]),
     "cgat_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "cgat_gemm": (C.c_int, [C.POINTER(GemmDesc), vp, C.c_size_t, vp]),
     "cgat_set_edge_storage": (None, [C.c_int32]),

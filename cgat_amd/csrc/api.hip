@@ -247,6 +247,32 @@ extern "C" int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_byte
   return mlp_chain128_launch(c, s);
 }
 
+// ---- batched dense-layer weight gradients ----
+extern "C" size_t cgat_dense_wgrad_batch_workspace_bytes(int32_t n, int32_t rows) {
+  return rows_dw128_batch_ws_bytes(n > 0 ? n : 1, rows > 0 ? rows : 1) + 256;
+}
+extern "C" int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const float* const* X, int64_t ldx,
+                                      float* const* out, int64_t ldo, float* const* bsum, int32_t rows, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(n >= 0 && n <= DW_BATCH_MAX && rows >= 0 && G && X && out, "dense_wgrad_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return CGAT_OK;
+  if (rows == 0) {   // empty sums
+    for (int i = 0; i < n; ++i) {
+      for (int o = 0; o < 128; ++o)
+        if (hipMemsetAsync(out[i] + o * ldo, 0, 512, s) != hipSuccess) return CGAT_ERR_HIP;
+      if (bsum && bsum[i] && hipMemsetAsync(bsum[i], 0, 512, s) != hipSuccess) return CGAT_ERR_HIP;
+    }
+    return CGAT_OK;
+  }
+  DwBatchDesc d;
+  memset(&d, 0, sizeof(d));
+  d.n = n; d.rows = rows; d.ldg = ldg; d.ldx = ldx; d.ldo = ldo;
+  for (int i = 0; i < n; ++i) d.it[i] = {G[i], X[i], out[i], bsum ? bsum[i] : nullptr};
+  CGAT_CHECK_ARG(rows_dw128_batch_fast(d), "dense_wgrad_batch: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  return rows_dw128_batch_launch(d, ws, ws_bytes, s);
+}
+
 // ---- kernel-level primitives ----
 static GemmParams from_desc(const cgat_gemm_desc* d) {
   GemmParams g = gemm_params(d->M, d->N, d->K, d->A, d->lda, d->B, d->ldb, d->C, d->ldc);

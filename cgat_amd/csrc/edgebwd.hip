@@ -12,14 +12,16 @@
 
 // Wq: prepare_T_bf16 planes of the operand (a = 128-column block of gZ, b = column in block, c = output) =
 // W_e[128 a + b][c]; chunk (a, half, s) = 12 KB at Wq + ((a*2 + half)*4 + s) * 768 uint4.
-// GB: the operand is stored as bf16 (the "bf16" edge-storage mode; ldg / gzb count elements either way)
-template <int PASSES, bool GB = false>
+// RC: the operand is not read but rebuilt from its ingredients (struct EdgeRC, kernels.h): per k-step and row one mask
+// word, one coefficient and 8 floats of a per-node row (or of the constant wA) instead of 8 floats of gZ
+__device__ __forceinline__ float rc_d(unsigned m, int bit) { return ((m >> bit) & 1u) ? 1.f : 0.01f; }
+template <int PASSES, bool RC = false>
 __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Wq, int ncb,
                                                          float* __restrict__ out, long ldo,
                                                          const int* __restrict__ scatter, int E, int accumulate,
                                                          const float* __restrict__ bias,
-                                                         const float* __restrict__ amax) {
+                                                         const float* __restrict__ amax, const EdgeRC rc) {
   // PASSES == 2: two fp16 planes, three passes (mfma_bf16.h).  The rows of gZ are consumed k-step by k-step, so their
   // scale is per tensor: amax[0] = max |gZ| from the kernel that produced it; the weight's max sits behind its planes.
   constexpr bool F16 = PASSES == 2;
@@ -35,9 +37,16 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   // column-blocked gZ, (W2, 128) for a plain row-major matrix
   const float* ga = gZ + rca * ldg + 8 * kg;     // + a * gzb + 32 s
   const float* gb = gZ + rcb * ldg + 8 * kg;
-  const __bf16* ga16 = reinterpret_cast<const __bf16*>(gZ) + rca * ldg + 8 * kg;
-  const __bf16* gb16 = reinterpret_cast<const __bf16*>(gZ) + rcb * ldg + 8 * kg;
   const int nk = ncb * 4;
+  // RC: per-row bases of the ingredients
+  const unsigned* mka = nullptr; const unsigned* mkb = nullptr;
+  const float *gsa = nullptr, *gsb = nullptr, *caA = nullptr, *cbA = nullptr, *caM = nullptr, *cbM = nullptr;
+  if constexpr (RC) {
+    mka = rc.mask + rca * rc.nw; mkb = rc.mask + rcb * rc.nw;
+    gsa = rc.gS + (long)rc.dst[rca] * rc.HHd + 8 * kg; gsb = rc.gS + (long)rc.dst[rcb] * rc.HHd + 8 * kg;
+    caA = rc.ga + rca * rc.H; cbA = rc.ga + rcb * rc.H;
+    caM = rc.alpha + rca * rc.H; cbM = rc.alpha + rcb * rc.H;
+  }
 
   f32x4 acc[16];
 #pragma unroll
@@ -70,39 +79,52 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   // raw gZ (rows a/b, 8 columns each) of the next k-step (ra*, rb*) and of the one after (sa*, sb*): loads are
   // issued two k-steps (~3 us) before their values are split, enough bytes in flight per CU to cover HBM latency
   float4 ra0, ra1, rb0, rb1, sa0, sa1, sb0_, sb1_;
-#define GE_ALOAD(ks_, A0_, A1_, B0_, B1_)                                                                \
+  // RC: coefficient and mask word of rows a / b for the k-step in r* (rc*) and in s* (sc*)
+  float rca_c = 0.f, rcb_c = 0.f, sca_c = 0.f, scb_c = 0.f;
+  unsigned rca_m = 0, rcb_m = 0, sca_m = 0, scb_m = 0;
+#define GE_ALOAD(ks_, A0_, A1_, B0_, B1_, CA_, CB_, MA_, MB_)                                            \
   {                                                                                                      \
-    const long off = (long)((ks_) >> 2) * gzb + 32 * ((ks_) & 3);                                        \
-    if constexpr (GB) {                                                                                  \
-      const uint4 ua = *reinterpret_cast<const uint4*>(ga16 + off), ub = *reinterpret_cast<const uint4*>(gb16 + off); \
-      A0_ = unpack4_bf16(make_uint2(ua.x, ua.y)); A1_ = unpack4_bf16(make_uint2(ua.z, ua.w));            \
-      B0_ = unpack4_bf16(make_uint2(ub.x, ub.y)); B1_ = unpack4_bf16(make_uint2(ub.z, ub.w));            \
+    if constexpr (RC) {                                                                                  \
+      const int c0_ = 32 * (ks_);                      /* first column of the k-step (uniform) */           \
+      const bool isA_ = c0_ < rc.HHd;                                                                    \
+      const int cc_ = isA_ ? c0_ : c0_ - rc.HHd, h_ = cc_ / rc.Hd;                                       \
+      const float4* pa = reinterpret_cast<const float4*>(isA_ ? rc.wA + cc_ + 8 * kg : gsa + cc_);      \
+      const float4* pb = reinterpret_cast<const float4*>(isA_ ? rc.wA + cc_ + 8 * kg : gsb + cc_);      \
+      A0_ = pa[0]; A1_ = pa[1]; B0_ = pb[0]; B1_ = pb[1];                                                \
+      CA_ = (isA_ ? caA : caM)[h_]; CB_ = (isA_ ? cbA : cbM)[h_];                                        \
+      MA_ = mka[ks_]; MB_ = mkb[ks_];                                                                    \
     } else {                                                                                             \
+      const long off = (long)((ks_) >> 2) * gzb + 32 * ((ks_) & 3);                                      \
       const float4* pa = reinterpret_cast<const float4*>(ga + off);                                      \
       const float4* pb = reinterpret_cast<const float4*>(gb + off);                                      \
       A0_ = pa[0]; A1_ = pa[1]; B0_ = pb[0]; B1_ = pb[1];                                                \
     }                                                                                                    \
   }
-#define GE_SPLIT(R0_, R1_, Q1_, Q2_, Q3_)                                                                \
+  // RC: the stored value was (coefficient * vector) * d, rebuilt in the same order
+#define GE_SPLIT(R0_, R1_, C_, M_, Q1_, Q2_, Q3_)                                                        \
   {                                                                                                      \
+    float g_[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                              \
+    if constexpr (RC) {                                                                                  \
+      const unsigned mb_ = (M_) >> (8 * kg);                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_[i_] = ((C_) * g_[i_]) * rc_d(mb_, i_);         \
+    }                                                                                                    \
     if constexpr (F16) {                                                                                 \
-      const float v[8] = {R0_.x * sA, R0_.y * sA, R0_.z * sA, R0_.w * sA,                                \
-                          R1_.x * sA, R1_.y * sA, R1_.z * sA, R1_.w * sA};                               \
+      const float v[8] = {g_[0] * sA, g_[1] * sA, g_[2] * sA, g_[3] * sA,                                \
+                          g_[4] * sA, g_[5] * sA, g_[6] * sA, g_[7] * sA};                               \
       split2_x8_f16(v, Q1_, Q2_);                                                                        \
     } else {                                                                                             \
-      const float v[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                       \
-      split3_x8(v, Q1_, Q2_, Q3_);                                                                       \
+      split3_x8(g_, Q1_, Q2_, Q3_);                                                                      \
     }                                                                                                    \
   }
   bf16x8 qa1, qa2, qa3, qb1, qb2, qb3;           // current k-step's gZ fragments (rows a, b)
   bf16x8 na1, na2, na3, nb1, nb2, nb3;           // next k-step's
-  GE_ALOAD(0, ra0, ra1, rb0, rb1);
+  GE_ALOAD(0, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
   GE_BLOAD(0);
-  GE_SPLIT(ra0, ra1, qa1, qa2, qa3);
-  GE_SPLIT(rb0, rb1, qb1, qb2, qb3);
+  GE_SPLIT(ra0, ra1, rca_c, rca_m, qa1, qa2, qa3);
+  GE_SPLIT(rb0, rb1, rcb_c, rcb_m, qb1, qb2, qb3);
   GE_BSTORE(0);
   ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nk > 1) GE_ALOAD(1, ra0, ra1, rb0, rb1);
+  if (nk > 1) GE_ALOAD(1, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
   __syncthreads();
 
 #define GE_MFMA1(F1_, F2_, F3_, Q1_, Q2_, Q3_, P_)                                                       \
@@ -120,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     const int buf = ks & 1;
     const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Bs[buf][lane]);
     if (ks + 1 < nk) GE_BLOAD(ks + 1);
-    if (ks + 2 < nk) GE_ALOAD(ks + 2, sa0, sa1, sb0_, sb1_);
+    if (ks + 2 < nk) GE_ALOAD(ks + 2, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m);
     // the raw values in ra/rb belong to k-step ks + 1: split them while this step's MFMAs run
     bf16x8 f1 = bs[0], f2 = bs[256], f3;
     if (PASSES >= 6) f3 = bs[512];
@@ -133,15 +155,16 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
         if (PASSES >= 6) n3 = bs[o + 512];
       }
       GE_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);
-      if (g == 1 && ks + 1 < nk) GE_SPLIT(ra0, ra1, na1, na2, na3);
+      if (g == 1 && ks + 1 < nk) GE_SPLIT(ra0, ra1, rca_c, rca_m, na1, na2, na3);
       GE_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);
-      if (g == 4 && ks + 1 < nk) GE_SPLIT(rb0, rb1, nb1, nb2, nb3);
+      if (g == 4 && ks + 1 < nk) GE_SPLIT(rb0, rb1, rcb_c, rcb_m, nb1, nb2, nb3);
       if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }
     }
     if (ks + 1 < nk) GE_BSTORE(buf ^ 1);
     __syncthreads();
     qa1 = na1; qa2 = na2; qa3 = na3; qb1 = nb1; qb2 = nb2; qb3 = nb3;
     ra0 = sa0; ra1 = sa1; rb0 = sb0_; rb1 = sb1_;
+    rca_c = sca_c; rcb_c = scb_c; rca_m = sca_m; rcb_m = scb_m;
   }
 #undef GE_BLOAD
 #undef GE_BSTORE
@@ -195,11 +218,12 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int PASSES, bool GB = false>   // GB: gZ stored as bf16
+template <int PASSES, bool RC = false>   // RC: the gZ tile is rebuilt from its ingredients (struct EdgeRC), not read
 __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Eq, float* __restrict__ slab,
                                                          int E, int ncb, int nsteps, int S,
-                                                         const float* __restrict__ gmax, const float* __restrict__ emax) {
+                                                         const float* __restrict__ gmax, const float* __restrict__ emax,
+                                                         const EdgeRC rc) {
   // PASSES == 2: two fp16 planes, three passes; both operands are indexed by the reduction index (the edge slot), so
   // both scales are per tensor: gmax[0] = max |gZ| (from its producer), emax[0] = max |e| (the planes carry 2^k e)
   constexpr bool F16 = PASSES == 2;
@@ -223,8 +247,17 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   const int ks0 = (int)((long)nsteps * split / S), ks1 = (int)((long)nsteps * (split + 1) / S);
   const int cb128 = pair * 2 + grp;
   const float* gblk = gZ + (long)cb128 * gzb;
-  const __bf16* gblk16 = reinterpret_cast<const __bf16*>(gZ) + (long)cb128 * gzb;
   const int gt = tid & 255;                              // thread within the column block's group
+  // RC: this thread's four columns 128 cb128 + 4 (gt & 31) never change: head, half, mask word and bit offset are fixed
+  const int rc_col = 128 * cb128 + 4 * (gt & 31);
+  const bool rc_isA = RC && rc_col < rc.HHd;
+  const int rc_cc = rc_isA ? rc_col : rc_col - rc.HHd;
+  const int rc_h = RC ? rc_cc / rc.Hd : 0;
+  const int rc_word = rc_col >> 5, rc_bit = rc_col & 31;
+  const float* rc_coef = RC ? (rc_isA ? rc.ga : rc.alpha) + rc_h : nullptr;
+  // (attention half: the "row" is the constant wA, fetched through the same load as a gS row -- selecting between a
+  // register copy and a global pointer makes the compiler spill the copy and load it back through flat memory)
+  const int last_row = E - 1;
 
   f32x4 acc[16];
 #pragma unroll
@@ -248,31 +281,58 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   }
   // raw gZ tile pieces: float4 number gt + 256 i of the k-step's contiguous [32][128] tile, i < 4
   float4 r0, r1, r2, r3, s0, s1, s2, s3;
-#define GW_G1(ks_, i_, R_)                                                                               \
+  // RC: (coefficient, mask word) of the four rows in r* / s*, and the destination nodes of the rows one k-step further
+  // (the row of gS is a dependent load: its index is fetched a k-step before the row itself)
+  float rk0 = 0.f, rk1 = 0.f, rk2 = 0.f, rk3 = 0.f, sk0 = 0.f, sk1 = 0.f, sk2 = 0.f, sk3 = 0.f;
+  unsigned rm0 = 0, rm1 = 0, rm2 = 0, rm3 = 0, sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;
+  int dn0 = 0, dn1 = 0, dn2 = 0, dn3 = 0;
+#define GW_D1(ks_, i_, D_)                                                                               \
+  {                                                                                                      \
+    const long t = (long)(ks_) * 32 + ((gt + 256 * (i_)) >> 5);                                          \
+    D_ = rc.dst[t < E ? t : last_row];                                                                   \
+  }
+#define GW_DLOAD(ks_) { if constexpr (RC) { if (!rc_isA) { GW_D1(ks_, 0, dn0) GW_D1(ks_, 1, dn1) GW_D1(ks_, 2, dn2) GW_D1(ks_, 3, dn3) } } }
+#define GW_G1(ks_, i_, R_, K_, M_, D_)                                                                   \
   {                                                                                                      \
     const int idx = gt + 256 * (i_);                                                                     \
     const long t = (long)(ks_) * 32 + (idx >> 5);                                                        \
-    if constexpr (GB)                                                                                    \
-      R_ = t < E ? load4_bf16(gblk16 + t * ldg + 4 * (idx & 31)) : make_float4(0.f, 0.f, 0.f, 0.f);      \
-    else                                                                                                 \
+    if constexpr (RC) {                                                                                  \
+      const long tc = t < E ? t : last_row;                                                              \
+      R_ = *reinterpret_cast<const float4*>(rc_isA ? rc.wA + rc_cc : rc.gS + (long)(D_) * rc.HHd + rc_cc); \
+      K_ = t < E ? rc_coef[tc * rc.H] : 0.f;                                                             \
+      M_ = rc.mask[tc * rc.nw + rc_word];                                                                \
+    } else {                                                                                             \
       R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * ldg + 4 * (idx & 31))                     \
                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+    }                                                                                                    \
   }
-#define GW_GLOAD(ks_, A_, B_, C_, D_) { GW_G1(ks_, 0, A_) GW_G1(ks_, 1, B_) GW_G1(ks_, 2, C_) GW_G1(ks_, 3, D_) }
+  // (RC: the dn* used here were loaded for exactly this k-step; the next k-step's are fetched right after)
+#define GW_GLOAD(ks_, A_, B_, C_, D_, KA_, KB_, KC_, KD_, MA_, MB_, MC_, MD_)                            \
+  {                                                                                                      \
+    GW_G1(ks_, 0, A_, KA_, MA_, dn0) GW_G1(ks_, 1, B_, KB_, MB_, dn1)                                    \
+    GW_G1(ks_, 2, C_, KC_, MC_, dn2) GW_G1(ks_, 3, D_, KD_, MD_, dn3)                                    \
+    GW_DLOAD((ks_) + 1)                                                                                  \
+  }
   // split one float4 (row idx >> 5, columns 4 (idx & 31) ...) and store 8 bytes per plane into image (b)
-#define GW_S1(i_, R_, buf_, sg_)                                                                         \
+#define GW_S1(i_, R_, K_, M_, buf_, sg_)                                                                 \
   {                                                                                                      \
     const int idx = gt + 256 * (i_);                                                                     \
     const int row = idx >> 5, c4 = idx & 31;                                                             \
     const int off = 256 * row + 16 * ((c4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (c4 & 1); \
     uint2 x1, x2, x3;                                                                                    \
+    float4 g_ = R_;                                                                                      \
+    if constexpr (RC) {               /* the stored value was (coefficient * vector) * d */                 \
+      const unsigned mb_ = (M_) >> rc_bit;                                                               \
+      g_.x = ((K_) * g_.x) * rc_d(mb_, 0); g_.y = ((K_) * g_.y) * rc_d(mb_, 1);                          \
+      g_.z = ((K_) * g_.z) * rc_d(mb_, 2); g_.w = ((K_) * g_.w) * rc_d(mb_, 3);                          \
+    }                                                                                                    \
     if constexpr (F16) {                                                                                 \
       const float m_ = (sg_) * sG;                                                                       \
-      split2_pair_f16(R_.x * m_, R_.y * m_, x1.x, x2.x);                                                 \
-      split2_pair_f16(R_.z * m_, R_.w * m_, x1.y, x2.y);                                                 \
+      split2_pair_f16(g_.x * m_, g_.y * m_, x1.x, x2.x);                                                 \
+      split2_pair_f16(g_.z * m_, g_.w * m_, x1.y, x2.y);                                                 \
     } else {                                                                                             \
-      split3_pair(R_.x * sg_, R_.y * sg_, x1.x, x2.x, x3.x);                                             \
-      split3_pair(R_.z * sg_, R_.w * sg_, x1.y, x2.y, x3.y);                                             \
+      split3_pair(g_.x * sg_, g_.y * sg_, x1.x, x2.x, x3.x);                                             \
+      split3_pair(g_.z * sg_, g_.w * sg_, x1.y, x2.y, x3.y);                                             \
     }                                                                                                    \
     *reinterpret_cast<uint2*>(&Gs[buf_][grp][0][off]) = x1;                                              \
     *reinterpret_cast<uint2*>(&Gs[buf_][grp][1][off]) = x2;                                              \
@@ -326,11 +386,13 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     return;
   }
   GW_ELOAD(ks0);
-  GW_GLOAD(ks0, r0, r1, r2, r3);
+  GW_DLOAD(ks0);
+  GW_GLOAD(ks0, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
   GW_ESTORE(0);
-  GW_S1(0, r0, 0, 1.f) GW_S1(1, r1, 0, 1.f) GW_S1(2, r2, 0, 1.f) GW_S1(3, r3, 0, 1.f)
+  GW_S1(0, r0, rk0, rm0, 0, 1.f) GW_S1(1, r1, rk1, rm1, 0, 1.f) GW_S1(2, r2, rk2, rm2, 0, 1.f) GW_S1(3, r3, rk3, rm3, 0, 1.f)
   r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ks0 + 1 < ks1) GW_GLOAD(ks0 + 1, r0, r1, r2, r3);
+  rk0 = rk1 = rk2 = rk3 = 0.f;
+  if (ks0 + 1 < ks1) GW_GLOAD(ks0 + 1, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
   __syncthreads();
   bool first = true;
   for (int ks = ks0; ks < ks1; ++ks) {
@@ -338,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     // sign of the flush group the NEXT k-step belongs to (its tile is split during this iteration)
     const float sgn_next = (((rel + 1) / FLUSH) & 1) ? -1.f : 1.f;
     if (ks + 1 < ks1) GW_ELOAD(ks + 1);
-    if (ks + 2 < ks1) GW_GLOAD(ks + 2, s0, s1, s2, s3);
+    if (ks + 2 < ks1) GW_GLOAD(ks + 2, s0, s1, s2, s3, sk0, sk1, sk2, sk3, sm0, sm1, sm2, sm3);
     const bf16x8* es = reinterpret_cast<const bf16x8*>(&Es[buf][lane]);
     // this wave's two transposed gZ fragments (32 columns x 32 slots), three planes each
     bf16x8 qa1 = GW_TRREAD(buf, 0, tr00, tr01), qa2 = GW_TRREAD(buf, 1, tr00, tr01), qa3;
@@ -356,10 +418,10 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
       }
       GW_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);
       if (ks + 1 < ks1) {
-        if (g == 0) GW_S1(0, r0, buf ^ 1, sgn_next)
-        if (g == 2) GW_S1(1, r1, buf ^ 1, sgn_next)
-        if (g == 4) GW_S1(2, r2, buf ^ 1, sgn_next)
-        if (g == 6) GW_S1(3, r3, buf ^ 1, sgn_next)
+        if (g == 0) GW_S1(0, r0, rk0, rm0, buf ^ 1, sgn_next)
+        if (g == 2) GW_S1(1, r1, rk1, rm1, buf ^ 1, sgn_next)
+        if (g == 4) GW_S1(2, r2, rk2, rm2, buf ^ 1, sgn_next)
+        if (g == 6) GW_S1(3, r3, rk3, rm3, buf ^ 1, sgn_next)
       }
       GW_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);
       if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }
@@ -372,10 +434,13 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     }
     __syncthreads();
     r0 = s0; r1 = s1; r2 = s2; r3 = s3;
+    rk0 = sk0; rk1 = sk1; rk2 = sk2; rk3 = sk3; rm0 = sm0; rm1 = sm1; rm2 = sm2; rm3 = sm3;
   }
 #undef GW_ELOAD
 #undef GW_ESTORE
 #undef GW_G1
+#undef GW_D1
+#undef GW_DLOAD
 #undef GW_GLOAD
 #undef GW_S1
 #undef GW_TRADDR
@@ -394,7 +459,7 @@ bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, 
 // amax (f16x3 mode only): device pointer to max |gZ|; without it the bf16x6 form runs.
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
-                   hipStream_t stream, const float* amax, int g_bf16) {
+                   hipStream_t stream, const float* amax, const EdgeRC* rc) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   const bool f16 = bilinear_mode() == 2 && amax && s_out == 1 && (s_col % 4) == 0 && (((uintptr_t)We) & 15) == 0;
@@ -409,19 +474,13 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   }
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);   // the per-edge launch / node-side and dense-layer uses
   const int grid = cdiv(E, 256);
-  CGAT_CHECK_ARG(!g_bf16 || f16, "edge_ge: the bf16-stored operand needs the f16x3 form");
-  if (f16 && g_bf16)
-    hipLaunchKernelGGL((edge_ge_kernel<2, true>), dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out,
-                       ldo, scatter, E, accumulate, bias, amax);
-  else if (f16)
-    hipLaunchKernelGGL(edge_ge_kernel<2>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate, bias, amax);
-  else if (bilinear_mode() != 3)
-    hipLaunchKernelGGL(edge_ge_kernel<6>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate, bias, amax);
-  else
-    hipLaunchKernelGGL(edge_ge_kernel<3>, dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, out, ldo,
-                       scatter, E, accumulate, bias, amax);
+  const EdgeRC none = {};
+#define GE_GO(P_, R_)                                                                                                 \
+  hipLaunchKernelGGL((edge_ge_kernel<P_, R_>), dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, \
+                     out, ldo, scatter, E, accumulate, bias, amax, R_ ? *rc : none)
+  if (rc) { if (f16) GE_GO(2, true); else if (bilinear_mode() != 3) GE_GO(6, true); else GE_GO(3, true); }
+  else { if (f16) GE_GO(2, false); else if (bilinear_mode() != 3) GE_GO(6, false); else GE_GO(3, false); }
+#undef GE_GO
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -444,7 +503,8 @@ size_t edge_gw_ws_floats(int E, int W2) {
 // out[col * ldo + k] = sum_t G[t, col] * e[perm[t] * lde + k],   G[t, 128 a + j] at gZ[t * ldg + a * gzb + j]
 // gmax, emax (f16x3 mode only): device pointers to max |gZ| and max |e|; without them the bf16x6 form runs.
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
-                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax, const float* emax, int g_bf16) {
+                   float* ws, float* out, long ldo, hipStream_t stream, const float* gmax, const float* emax,
+                   const EdgeRC* rc) {
   if (E <= 0) {
     GemmParams z = gemm_params(W2, 128, 0, nullptr, 1, nullptr, 1, out, ldo);
     return gemm_launch(z, nullptr, 0, stream);   // K = 0: zero fill
@@ -454,24 +514,76 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
   float* slab = ws + (((size_t)na * 128 * 128 * 3 + 1) / 2 + 15) / 16 * 16;
   // operand (a = slot block, b = slot in block, c = k) = e[perm[128 a + b] * lde + c], zero past E
   const bool f16 = bilinear_mode() == 2 && gmax && emax;
-  CGAT_CHECK_ARG(!g_bf16 || f16, "edge_gw: the bf16-stored operand needs the f16x3 form");
   CGAT_TRY(prepare_T_bf16_rows_launch(e, lde, perm, E, planes, na, stream, f16 ? emax : nullptr));
   {
     CGAT_PROF(perm ? "edge_gw" : "rows_gw", stream);
     const int nsteps = cdiv(E, 32);
-    if (f16 && g_bf16)
-      hipLaunchKernelGGL((edge_gw_kernel<2, true>), dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb,
-                         (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax);
-    else if (f16)
-      hipLaunchKernelGGL(edge_gw_kernel<2>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
-                         slab, E, ncb, nsteps, S, gmax, emax);
-    else if (bilinear_mode() != 3)
-      hipLaunchKernelGGL(edge_gw_kernel<6>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
-                         slab, E, ncb, nsteps, S, gmax, emax);
-    else
-      hipLaunchKernelGGL(edge_gw_kernel<3>, dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)planes,
-                         slab, E, ncb, nsteps, S, gmax, emax);
+    const EdgeRC none = {};
+#define GW_GO(P_, R_)                                                                                                  \
+  hipLaunchKernelGGL((edge_gw_kernel<P_, R_>), dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb,                \
+                     (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax, R_ ? *rc : none)
+    if (rc) { if (f16) GW_GO(2, true); else if (bilinear_mode() != 3) GW_GO(6, true); else GW_GO(3, true); }
+    else { if (f16) GW_GO(2, false); else if (bilinear_mode() != 3) GW_GO(6, false); else GW_GO(3, false); }
+#undef GW_GO
     CGAT_LAUNCH_CHECK();
   }
   return splitk_reduce_launch(slab, S, W2, 128, out, ldo, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+//     Gj[n, :] = sum_{edges leaving n} gZ[t, :]          (edge_gj_kernel: the x_j-side segment sum of the rebuilt rows)
+// One workgroup per GJ_NODES source nodes, one thread per four columns (W2 / 4 threads); per edge a thread fetches its
+// mask word, its coefficient and -- message half -- four floats of the destination's gS row (the destinations of a
+// node's edges are its neighbours in the same crystal: those rows stay in L2), instead of 16 bytes of a 6-KB gZ row
+// gathered from HBM.  Edges four at a time so that the dependent chain slot -> destination -> row overlaps.
+// ---------------------------------------------------------------------------------------
+#define GJ_NODES 4
+__global__ __launch_bounds__(512) void edge_gj_kernel(const EdgeRC rc, const int* __restrict__ src_rowptr,
+                                                      const int* __restrict__ src_pos, int N, int W2,
+                                                      float* __restrict__ Gj, long ldo) {
+  const int q = threadIdx.x;
+  if (4 * q >= W2) return;
+  const int col = 4 * q;
+  const bool isA = col < rc.HHd;
+  const int cc = isA ? col : col - rc.HHd, h = cc / rc.Hd;
+  const int word = col >> 5, bit = col & 31;
+  const float* coef = (isA ? rc.ga : rc.alpha) + h;
+  const int n0 = blockIdx.x * GJ_NODES, n1 = min(N, n0 + GJ_NODES);
+  for (int n = n0; n < n1; ++n) {
+    const int r0 = src_rowptr[n], r1 = src_rowptr[n + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rb = r0; rb < r1; rb += 4) {
+      long t[4];
+      float k[4];
+      unsigned m[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = src_pos[rb + u < r1 ? rb + u : r1 - 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        k[u] = rb + u < r1 ? coef[t[u] * rc.H] : 0.f;
+        m[u] = rc.mask[t[u] * rc.nw + word];
+        // (attention half: the constant wA through the same load -- see edge_gw_kernel)
+        v[u] = *reinterpret_cast<const float4*>(isA ? rc.wA + cc : rc.gS + (long)rc.dst[t[u]] * rc.HHd + cc);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned mb = m[u] >> bit;
+        acc.x += (k[u] * v[u].x) * rc_d(mb, 0); acc.y += (k[u] * v[u].y) * rc_d(mb, 1);
+        acc.z += (k[u] * v[u].z) * rc_d(mb, 2); acc.w += (k[u] * v[u].w) * rc_d(mb, 3);
+      }
+    }
+    *reinterpret_cast<float4*>(Gj + (long)n * ldo + col) = acc;
+  }
+}
+int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, int N, int W2, float* Gj, long ldo,
+                   hipStream_t stream) {
+  if (N <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG(W2 % 4 == 0 && W2 / 4 <= 512 && (ldo % 4) == 0 && (((uintptr_t)Gj) & 15) == 0,
+                 "edge_gj: W2 = %d must be a multiple of 4 up to 2048 with a 16-byte aligned output", W2);
+  CGAT_PROF("edge_gj", stream);
+  hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(N, GJ_NODES)), dim3(cdiv(W2 / 4, 64) * 64), 0, stream, rc, src_rowptr, src_pos,
+                     N, W2, Gj, ldo);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
 }

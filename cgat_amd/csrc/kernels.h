@@ -150,19 +150,40 @@ struct ChainDesc {
 bool mlp_chain128_fast(const ChainDesc& d);
 int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
-// operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major
+// The pre-activation gradient of the scalar-attention layer is never stored when its consumers can rebuild it
+// (edge_seg_bwd_kernel step 3, layers.hip): for destination-sorted slot t and column col of the stacked hidden layer
+//     gZ[t, col] = (ga[t,h]    * wA[col])                 * d      col <  HHd  (attention network, h = col / Hd)
+//                = (alpha[t,h] * gS[dst[t], col - HHd])   * d      col >= HHd  (message network,  h = (col-HHd) / Hd)
+// with d = 1 if Z[t,col] > 0 else 0.01 (LeakyReLU').  Per edge that is 2 H scalars, one bit per column and a row of a
+// per-NODE matrix shared by all edges of the destination: 216 bytes + cache hits instead of 6 KB of HBM per read.
+struct EdgeRC {
+  const unsigned* mask;   // [E][W2 / 32]: bit (col & 31) of word (col >> 5) = (Z[t, col] > 0)
+  const float* ga;        // [E][H]
+  const float* alpha;     // [E][H]
+  const float* gS;        // [N][HHd]
+  const float* wA;        // [HHd]
+  const int* dst;         // [E] destination node of slot t
+  int H, Hd, HHd, nw;     // nw = W2 / 32
+};
+// shapes the rebuilding kernels take: whole 128-column blocks inside one head, 256-column groups in the mask writer
+static inline bool edge_rc_shape(int Ce, int H, int Hd) { return Ce == 128 && H > 0 && Hd > 0 && Hd % 128 == 0; }
+// operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major;
+// with rc != null the operand is rebuilt from *rc instead (gZ, ldg, gzb unused)
 bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ);
 size_t edge_gw_ws_floats(int E, int W2);
 int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde, const int* perm, int E, int W2,
                    float* ws, float* out, long ldo, hipStream_t stream, const float* gmax = nullptr,
-                   const float* emax = nullptr, int g_bf16 = 0);   // device maxima of |gZ| and |e| -> fp16 form in the
-                                                                   // f16x3 mode; g_bf16: gZ stored as bf16
+                   const float* emax = nullptr,            // device maxima of |gZ| and |e| -> fp16 form in the f16x3 mode
+                   const EdgeRC* rc = nullptr);
 bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
                    hipStream_t stream,
-                   const float* amax = nullptr, int g_bf16 = 0);   // amax: device max |gZ| -> fp16 form in the f16x3 mode;
-                                                                   // g_bf16: gZ stored as bf16 (ldg, gzb in elements)
+                   const float* amax = nullptr,            // amax: device max |gZ| -> fp16 form in the f16x3 mode
+                   const EdgeRC* rc = nullptr);
+// Gj[n, :] = sum over the edges leaving n of the rebuilt gZ rows (src_rowptr / src_pos: slots grouped by source)
+int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, int N, int W2, float* Gj, long ldo,
+                   hipStream_t stream);
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);
@@ -173,6 +194,22 @@ size_t rows_dw128_ws_bytes(int rows, int nx);
 int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, float* out1, long ldo1, const float* X2,
                       long ldx2, float* out2, long ldo2, float* bsum, int rows, void* ws, size_t ws_bytes,
                       hipStream_t stream);
+// many such products in one launch (every item: one right operand; common row count and leading dimensions)
+#define DW_BATCH_MAX 32
+struct DwBatchItem {
+  const float* G;    // [rows, 128], row stride ldg
+  const float* X;    // [rows, 128], row stride ldx
+  float* out;        // [128][ldo]: G^T X
+  float* bsum;       // [128] column sums of G, or null
+};
+struct DwBatchDesc {
+  int n, rows, splits, rows_per_unit;   // splits / rows_per_unit are set by the launch
+  long ldg, ldx, ldo;
+  DwBatchItem it[DW_BATCH_MAX];
+};
+size_t rows_dw128_batch_ws_bytes(int n_items, int rows);
+bool rows_dw128_batch_fast(const DwBatchDesc& d);
+int rows_dw128_batch_launch(DwBatchDesc d, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // ---- elementwise / row kernels, rowops.hip ----
 int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float eps, hipStream_t s);
@@ -185,6 +222,7 @@ size_t colsum_ws_bytes(int rows, int cols);
 int mix_launch(const float* a, const float* b, const float* d, float* out, long n, hipStream_t s);  // out = d*a + (1-d)*b
 int mix_bwd_launch(const float* g, const float* a, const float* b, const float* d, float* ga, float* gb_accum,
                    float* gd, long n, void* ws, size_t ws_bytes, hipStream_t s);
+int scale_launch(const float* x, float alpha, float* out, long n, hipStream_t s);   // out = alpha * x
 int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s);  // y += alpha*x
 int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t s);
 int fill_launch(float* p, float v, long n, hipStream_t s);

@@ -55,15 +55,15 @@ struct Ctx {
     if (auto_split) p.splits = gemm_pick_splits(p.M, p.N, p.K);
     if (p.splits > 1) need(ws_round((size_t)p.splits * p.M * p.N, 4));
     // [rows,128] x [128,128] dense layers (trunks, linear terms of the predicted layers): the split-bf16 kernel
-    const bool dense128 = p.K == 128 && p.N == 128 && !p.a_kmajor && !p.a_rgather && !p.a_block && !p.b_kgather &&
+    const bool dense128 = p.K == 128 && p.N >= 128 && p.N % 128 == 0 && !p.a_kmajor && !p.a_rgather && !p.a_block && !p.b_kgather &&
                           !p.c_scatter && !p.add1 && !p.add2 && p.splits <= 1 && p.alpha == 1.f &&
                           (p.beta == 0.f || p.beta == 1.f) && (p.act == CGAT_ACT_NONE || p.act == CGAT_ACT_TANH);
-    if (dense128) need(linear128_ws_bytes());
+    if (dense128) need(linear128_ws_bytes(p.N));
     if (dry) return CGAT_OK;
-    if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes()) {
+    if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes(p.N)) {
       const long so = p.b_kmajor ? 1 : p.ldb, sk = p.b_kmajor ? p.ldb : 1;
-      return linear128_launch(p.A, p.lda, p.B, so, sk, p.bias, p.act, p.beta == 1.f, p.C, p.ldc, p.M, scratch, s, 128,
-                              wprep_find(p.B, so, sk));
+      return linear128_launch(p.A, p.lda, p.B, so, sk, p.bias, p.act, p.beta == 1.f, p.C, p.ldc, p.M, scratch, s, p.N,
+                              p.N == 128 ? wprep_find(p.B, so, sk) : nullptr);
     }
     return gemm_launch(p, scratch, scratch_bytes, s);
   }
@@ -173,7 +173,7 @@ __device__ __forceinline__ float wave_sum_l(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// ZB (with VEC): Z is read and gZ written as bf16 (the "bf16" edge-storage mode; offsets count elements either way)
+// ZB (with VEC and mask): Z is read as bf16 (the "bf16" edge-storage mode; offsets count elements either way)
 template <bool VEC, bool ZB = false>
 __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restrict__ Z, float* __restrict__ gZ,
                                                            long gz_block, const float* __restrict__ alpha,
@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
                                                            const float* __restrict__ wA_out, int N, int H, int Hd,
                                                            float* __restrict__ tt, float* __restrict__ ga,
                                                            float* __restrict__ Gi, float* __restrict__ partialW,
-                                                           float* __restrict__ gzmax) {
+                                                           float* __restrict__ gzmax, unsigned* __restrict__ mask) {
+  // mask (optional, VEC path, W2 % 256 == 0): gZ is NOT written; instead bit (col & 31) of mask[t][col >> 5] records
+  // Z[t, col] > 0, from which -- with ga, alpha, gS, wA -- the consumers rebuild the row (struct EdgeRC, kernels.h)
   // gzmax (optional, VEC path): max |gZ| is folded into gzmax[0] (zeroed before) -- the per-tensor scale the fp16
   // forms of the two kernels that consume gZ need (edgebwd.hip); a maximum does not depend on the order it is taken in
   extern __shared__ float pw[];  // [HHd] per-column partial sums of g_a * leaky(zA)
@@ -291,13 +293,17 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
                 const float al = cf[u];
                 g = make_float4(al * gsv.x * d.x, al * gsv.y * d.y, al * gsv.z * d.z, al * gsv.w * d.w);
               }
-              const long doff = gz_block ? (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : (long)t * W2 + col;
-              if constexpr (ZB) {
-                // the segment sum and the maximum are taken from the ROUNDED values: they must describe the stored operand
-                const uint2 pk = pack4_bf16(g);
-                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(gZ) + doff) = pk;
-                g = unpack4_bf16(pk);
+              if (mask) {
+                // four sign bits per lane, eight lanes per 32-column word: OR across the eight lanes (two quad
+                // permutations and the half-row mirror), lane 0 of each group stores the word
+                unsigned w = ((z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u))
+                             << (4 * (lane & 7));
+                w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x141, 0xF, 0xF, true);   // row_half_mirror
+                if ((lane & 7) == 0) mask[(long)t * (W2 >> 5) + (col >> 5)] = w;
               } else {
+                const long doff = gz_block ? (long)(col >> 7) * gz_block + (long)t * 128 + (col & 127) : (long)t * W2 + col;
                 *reinterpret_cast<float4*>(gZ + doff) = g;
               }
               gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
@@ -483,17 +489,18 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
 static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* Wcat,
                                           float* gWcat, float* gbcat, const float* gZ, long gz_ld, long gzb, float* Gi,
                                           float* Gj, bool have_Gi, const float* x, const float* e, float* g_x, float* g_e,
-                                          float* Wq, float* gw_ws, const float* scales = nullptr, bool g_bf16 = false) {
-  // g_bf16: gZ is stored as bf16 (the per-edge launches and the two segment sums read it as such)
+                                          float* Wq, float* gw_ws, const float* scales = nullptr,
+                                          const EdgeRC* rc = nullptr) {
+  // rc: gZ was not stored; the per-edge launches and the source-side sum rebuild its rows (struct EdgeRC, kernels.h)
   // scales (f16x3 mode, optional): device {max |gZ|, max |e|} -> the per-edge products run on two fp16 planes
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
   // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
-  if (!c.dry && g_bf16)
-    CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && scales,
-                   "nodes_attention_backward: the bf16 edge storage needs the fp16 per-edge kernels");
+  if (!c.dry && rc)
+    CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && have_Gi,
+                   "nodes_attention_backward: the rebuilt-gZ path needs the split per-edge kernels");
   if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
     RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
-                       scales, g_bf16 ? 1 : 0));
+                       scales, rc));
   } else {
     GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
     g.a_block = xb;
@@ -504,7 +511,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // grad W_e = gZ^T @ e[perm]
   if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
     RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s, scales,
-                       scales ? scales + 1 : nullptr, g_bf16 ? 1 : 0));
+                       scales ? scales + 1 : nullptr, rc));
   } else {
     GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
     g.a_block = xb;
@@ -514,10 +521,13 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   }
   // segment sums of gZ: by destination (x_i side) unless the caller already has them, by source (x_j side)
   if (!have_Gi)
-    RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb,
-                        g_bf16 ? 1 : 0));
-  RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
-                      c.s, xb, g_bf16 ? 1 : 0));
+    RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
+  if (rc) {
+    RUN(edge_gj_launch(*rc, plan->src_rowptr, plan->src_pos, d.N, d.W2, Gj, d.W2, c.s));
+  } else {
+    RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
+                        c.s, xb));
+  }
   // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
   // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
@@ -556,9 +566,13 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   float* gbcat = c.take<float>((size_t)d.W2);
   float* gS = c.take<float>((size_t)d.N * d.HHd);
   float* gs = c.take<float>((size_t)d.N * d.H);
+  float* gas = bilinear_mode() != 0 ? c.take<float>((size_t)d.N * d.C) : nullptr;   // g_aggr / H (fast fc_out path)
   float* tt = c.take<float>((size_t)d.E * d.H);
   float* ga = c.take<float>((size_t)d.E * d.H);
-  float* gZ = c.take<float>((size_t)d.E * d.W2);
+  // At the benchmark widths gZ [E, W2] is never stored: edge_seg_bwd_kernel leaves one bit per element behind and the
+  // three consumers rebuild the rows (struct EdgeRC, kernels.h) -- E * W2 / 8 bytes of workspace instead of 4 E * W2
+  const bool rc_shape = bilinear_mode() != 0 && edge_rc_shape(d.Ce, d.H, d.Hd) && d.W2 % 256 == 0 && d.N > 0 && d.E > 0;
+  float* gZ = c.take<float>(rc_shape ? (size_t)d.E * (d.W2 / 32) : (size_t)d.E * d.W2);
   float* partial = c.take<float>((size_t)chunks * d.HHd);
   float* Gi = c.take<float>((size_t)d.N * d.W2);
   float* Gj = c.take<float>((size_t)d.N * d.W2);
@@ -574,7 +588,36 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   const long gz_ld = gzb ? 128 : d.W2;
 
   CGAT_TRY(stack_in_weights(c, p, d, Wcat, nullptr));
-  for (int h = 0; h < d.H; ++h) {
+  // The per-head second layer of the message network at the benchmark widths (C = 128, Hd a multiple of 128): the input
+  // gradients on the dense-layer kernel (K = 128 -> Hd outputs per head), the H * Hd / 128 weight-gradient blocks in one
+  // batched launch of the rows kernel (rowsdw.hip); 1/H is folded into one scaled copy of g_aggr.
+  const bool out_fast = bilinear_mode() != 0 && d.C == 128 && d.Hd % 128 == 0 && d.H * (d.Hd / 128) <= DW_BATCH_MAX;
+  bool out_done = false;
+  if (out_fast) {
+    c.need(rows_dw128_batch_ws_bytes(d.H * (d.Hd / 128), d.N));
+    c.need(linear128_ws_bytes(d.Hd));
+    DwBatchDesc b;
+    memset(&b, 0, sizeof(b));
+    b.rows = d.N; b.ldg = d.C; b.ldx = d.HHd; b.ldo = d.Hd;
+    if (!c.dry) {
+      for (int h = 0; h < d.H; ++h)
+        for (int j = 0; j < d.Hd / 128; ++j)
+          b.it[b.n++] = {gas, sv.S + (size_t)h * d.Hd + 128 * j, gr->M_out_w + (size_t)h * d.C * d.Hd + 128 * j, nullptr};
+    }
+    if (c.dry || (d.N > 0 && linear128_fast(d.C, d.Hd, d.C, d.HHd, gas, gS) && rows_dw128_batch_fast(b) &&
+                  c.scratch_bytes >= rows_dw128_batch_ws_bytes(b.n, d.N))) {
+      RUN(scale_launch(g_aggr, invH, gas, (long)d.N * d.C, c.s));
+      for (int h = 0; h < d.H; ++h) {   // gS[:,h,:] = gas @ fc_out_M[h]
+        GemmParams g = gemm_params(d.N, d.Hd, d.C, gas, d.C, p->M_out_w + (size_t)h * d.C * d.Hd, d.Hd,
+                                   gS + (size_t)h * d.Hd, d.HHd);
+        g.b_kmajor = 1;
+        CGAT_TRY(c.gemm(g));
+      }
+      RUN(rows_dw128_batch_launch(b, c.scratch, c.scratch_bytes, c.s));   // grad fc_out_M[h] = gas^T S[:,h,:]
+      out_done = true;
+    }
+  }
+  for (int h = 0; h < d.H && !out_done; ++h) {
     const float* Wo = p->M_out_w + (size_t)h * d.C * d.Hd;
     {  // gS[:,h,:] = (1/H) g_aggr @ fc_out_M[h]
       GemmParams g = gemm_params(d.N, d.Hd, d.C, g_aggr, d.C, Wo, d.Hd, gS + (size_t)h * d.Hd, d.HHd);
@@ -614,24 +657,35 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     // the forward stored Z as bf16 under exactly this predicate (same tensors, same alignment)
     zb = attn_bf16(d) && edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
          edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
+    if (rc_shape)
+      CGAT_CHECK_ARG(vec && (((uintptr_t)e) & 15) == 0,
+                     "nodes_attention_backward: saved, edge_attr and MH_A.fc_out.weight must be 16-byte aligned at these widths");
+    unsigned* mask = rc_shape ? reinterpret_cast<unsigned*>(gZ) : nullptr;
+    float* gzmax = have_scales ? scales : (float*)nullptr;
     if (zb) {
-      CGAT_CHECK_ARG(vec && have_scales && gzb, "nodes_attention_backward: the bf16 edge storage needs the vector form");
+      CGAT_CHECK_ARG(rc_shape && have_scales, "nodes_attention_backward: the bf16 edge storage needs the vector form");
       hipLaunchKernelGGL((edge_seg_bwd_kernel<true, true>), dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, scales);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask);
     } else if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial,
-                         have_scales ? scales : (float*)nullptr);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask);
     else
       hipLaunchKernelGGL(edge_seg_bwd_kernel<false>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, (float*)nullptr);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, (float*)nullptr,
+                         (unsigned*)nullptr);
     CGAT_LAUNCH_CHECK();
+  }
+  EdgeRC rc = {};
+  if (rc_shape && !c.dry) {
+    rc.mask = reinterpret_cast<const unsigned*>(gZ); rc.ga = ga; rc.alpha = sv.alpha; rc.gS = gS; rc.wA = p->A_out_w;
+    rc.dst = plan->dst_sorted; rc.H = d.H; rc.Hd = d.Hd; rc.HHd = d.HHd; rc.nw = d.W2 / 32;
   }
   if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
-  CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, gZ, gz_ld, gzb, Gi, Gj, true, x, e, g_x, g_e, Wq,
-                                          gw_ws, have_scales ? scales : nullptr, zb));
+  CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, rc_shape ? nullptr : gZ, gz_ld, gzb, Gi, Gj, true,
+                                          x, e, g_x, g_e, Wq, gw_ws, have_scales ? scales : nullptr,
+                                          rc_shape ? &rc : nullptr));
   RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
   RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));
@@ -912,10 +966,20 @@ struct HnetSide {
   size_t bytes;
   int wgrad_wgs;      // workgroups of the dT launch: 0 = one per CU, 128 = half of the chip
 };
-static size_t hnet_side_ws_bytes(int rows, const cgat_hnet_params* p) {
+// side workspace: [g_u of every predicted layer][g_pre of every trunk layer][slabs of the batched dense-layer weight
+// gradients][workspace of the dT launch]
+struct HnetSideLayout { size_t gu, gpre, dw, wgrad, total; };
+static HnetSideLayout hnet_side_layout(int rows, const cgat_hnet_params* p) {
   const size_t rw = (size_t)rows * p->W;
-  return ws_round((size_t)p->n_hyper * rw, 4) + bilinear_wgrad_batch_ws_bytes(p->n_hyper, rows, p->W, p->W, p->W) + 256;
+  HnetSideLayout L;
+  L.gu = 0;
+  L.gpre = L.gu + ws_round((size_t)p->n_hyper * rw, 4);
+  L.dw = L.gpre + ws_round((size_t)p->n_hyper * (p->n_fc > 0 ? p->n_fc : 1) * rw, 4);
+  L.wgrad = L.dw + rows_dw128_batch_ws_bytes(p->n_hyper * (p->n_fc + 2), rows);
+  L.total = L.wgrad + bilinear_wgrad_batch_ws_bytes(p->n_hyper, rows, p->W, p->W, p->W) + 256;
+  return L;
 }
+static size_t hnet_side_ws_bytes(int rows, const cgat_hnet_params* p) { return hnet_side_layout(rows, p).total; }
 static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const float* h0, const float* v,
                               const float* saved, const float* g_y, float* g_h0, float* g_v,
                               const cgat_hnet_grads* gr, const HnetSide* side = nullptr) {
@@ -927,10 +991,28 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   float* g_u = c.take<float>((size_t)p->n_hyper * rw);   // one per predicted layer: all dT run in ONE launch at the end
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
   float* g_t = c.take<float>(rw);
-  float* g_pre = c.take<float>((size_t)(p->n_fc > 0 ? p->n_fc : 1) * rw);   // one per trunk layer: the chain writes them all
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
+  // the fused trunk chain (chain.hip) leaves every trunk layer's pre-activation gradient behind, so the weight
+  // gradients of all dense layers of all predicted layers can wait for ONE batched launch at the end (rowsdw.hip):
+  // they feed nothing else in the backward pass.  g_pre then needs a buffer per predicted layer.
+  const bool chain_ok = batch_w && bilinear_mode() == 2 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX;
+  const bool defer_dw = chain_ok && p->n_hyper * (p->n_fc + 2) <= DW_BATCH_MAX;
+  const int nfc1 = p->n_fc > 0 ? p->n_fc : 1;
+  const HnetSideLayout SL = hnet_side_layout(rows, p);
+  float* g_pre_all = (side && defer_dw) ? (c.dry ? nullptr : (float*)((char*)side->ws + SL.gpre))
+                                        : c.take<float>((size_t)(defer_dw ? p->n_hyper : 1) * nfc1 * rw);
   if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
   c.seal();
+  DwBatchDesc dwb;
+  memset(&dwb, 0, sizeof(dwb));
+  dwb.rows = rows; dwb.ldg = W; dwb.ldx = W; dwb.ldo = W;
+  if (defer_dw && !side) c.need(rows_dw128_batch_ws_bytes(p->n_hyper * (p->n_fc + 2), rows));
+  if (defer_dw) c.need(rows_dw128_ws_bytes(rows, 2));   // an operand off the 16-byte grid takes the per-layer launch
+  auto defer_item = [&](const float* G, const float* X, float* out, float* bsum) -> bool {
+    if (!defer_dw || c.dry || dwb.n >= DW_BATCH_MAX || !rows_dw128_fast(G, W, X, W, nullptr, 0)) return false;
+    dwb.it[dwb.n++] = {G, X, out, bsum};
+    return true;
+  };
   if (batch_w) {   // the same weights in the transposed orientation (g_in = g_out W)
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], 1, W);
@@ -961,7 +1043,11 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     // dT[o][i][k] = sum_n gu[n,o] vin[n,i] z[n,k]: deferred, all predicted layers in one launch (end of this function)
     deferred[n_deferred++] = {gu, vin, z, G.head_w};
     // Bm grad [o][i] = gu^T vin, U grad [o][k] = gu^T z, bias grad = column sums of gu: one pass over the three operands
-    int fused = W == 128 ? c.dw128(gu, W, vin, W, G.head_b, W, z, W, G.head_w + WW * W, W, G.head_b + WW, rows) : -1;
+    int fused = -1;
+    if (c.dry && defer_dw) fused = 0;
+    else if (defer_dw && dwb.n + 2 <= DW_BATCH_MAX && rows_dw128_fast(gu, W, vin, W, z, W) &&
+             defer_item(gu, vin, G.head_b, G.head_b + WW) && defer_item(gu, z, G.head_w + WW * W, nullptr)) fused = 0;
+    else if (W == 128) fused = c.dw128(gu, W, vin, W, G.head_b, W, z, W, G.head_w + WW * W, W, G.head_b + WW, rows);
     if (fused > 0) return fused;
     if (fused < 0) {
       GemmParams g = gemm_params(W, W, rows, gu, W, vin, W, G.head_b, W);  // Bm grad [o][i]
@@ -999,7 +1085,8 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     // pre-activation gradient, layer i multiplies by W_(n_fc-1-i) and by tanh' of the activation below it, every
     // pre-activation gradient is stored for the weight-gradient kernel, the last product is added to g_hin.
     bool chained = false;
-    if (batch_w && !c.dry && bilinear_mode() == 2 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX) {
+    float* g_pre = c.dry ? nullptr : g_pre_all + (defer_dw ? (size_t)l * nfc1 * rw : 0);
+    if (chain_ok && !c.dry) {
       ChainDesc cd;
       memset(&cd, 0, sizeof(cd));
       const int nf = p->n_fc;
@@ -1026,6 +1113,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
         for (int s2 = nf - 1; s2 >= 0; --s2) {
           const float* tin = (s2 == 0) ? hin : sv.act(l, s2 - 1);
           const float* gp = g_pre + (size_t)s2 * rw;
+          if (defer_item(gp, tin, G.fc_w[s2], G.fc_b[s2])) continue;
           int fz = W == 128 ? c.dw128(gp, W, tin, W, G.fc_w[s2], W, nullptr, 0, nullptr, 0, G.fc_b[s2], rows) : -1;
           if (fz > 0) return fz;
           if (fz < 0) {
@@ -1062,6 +1150,17 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   } else {
     RUN(copy2d_launch(g_hin, W, g_h0, W, rows, W, c.s));
   }
+  bool side_waits = false;   // the side stream has been made to wait for everything issued above
+  auto side_wait = [&]() -> int {
+    if (side_waits) return CGAT_OK;
+    hipEvent_t ev;
+    CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CGAT_HIP(hipEventRecord(ev, c.s));
+    CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
+    CGAT_HIP(hipEventDestroy(ev));
+    side_waits = true;
+    return CGAT_OK;
+  };
   if (n_deferred > 0) {
     const float *dp[CGAT_MAX_HYPER], *dq[CGAT_MAX_HYPER], *dr[CGAT_MAX_HYPER];
     float* dout[CGAT_MAX_HYPER];
@@ -1069,16 +1168,22 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     if (side && !c.dry) {
       // On the side stream the dT launch starts when everything above has been issued on the main stream, i.e. together
       // with whatever the caller enqueues next (the HBM-bound attention backward), on `wgrad_wgs` workgroups.
-      hipEvent_t ev;
-      CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      CGAT_HIP(hipEventRecord(ev, c.s));
-      CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
-      CGAT_HIP(hipEventDestroy(ev));
-      const size_t off = ws_round((size_t)p->n_hyper * rw, 4);
-      CGAT_TRY(bilinear_wgrad_batch_launch(n_deferred, dp, W, dq, W, dr, W, dout, rows, W, W, W, (char*)side->ws + off,
-                                           side->bytes - off, side->s, side->wgrad_wgs));
+      CGAT_TRY(side_wait());
+      CGAT_TRY(bilinear_wgrad_batch_launch(n_deferred, dp, W, dq, W, dr, W, dout, rows, W, W, W,
+                                           (char*)side->ws + SL.wgrad, side->bytes - SL.wgrad, side->s, side->wgrad_wgs));
     } else {
       CGAT_TRY(c.wgrad_batch(n_deferred, dp, dq, dr, dout, rows, W));
+    }
+  }
+  if (dwb.n > 0 && !c.dry) {
+    // HBM-bound, 0.7 ms for 24 products at 83 340 rows.  On the side stream it goes BEHIND the dT launch: that launch must
+    // be resident before the caller's next kernel floods the chip with small workgroups (its 132-KB workgroups are not
+    // placed while those keep arriving -- measured: 9.5 ms instead of 6.2 when it started 0.7 ms later)
+    if (side) {
+      CGAT_TRY(side_wait());
+      CGAT_TRY(rows_dw128_batch_launch(dwb, (char*)side->ws + SL.dw, SL.wgrad - SL.dw, side->s));
+    } else {
+      CGAT_TRY(rows_dw128_batch_launch(dwb, c.scratch, c.scratch_bytes, c.s));
     }
   }
   return check_ws(c, "hnet_backward");

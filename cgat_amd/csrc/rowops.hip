@@ -226,6 +226,26 @@ int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s) {
   return CGAT_OK;
 }
 
+// out = alpha * x
+__global__ void scale_kernel(const float* __restrict__ x, float alpha, float* __restrict__ out, long n4, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long j = i; j < n4; j += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[j];
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    reinterpret_cast<float4*>(out)[j] = v;
+  }
+  for (long j = 4 * n4 + i; j < n; j += stride) out[j] = alpha * x[j];
+}
+int scale_launch(const float* x, float alpha, float* out, long n, hipStream_t s) {
+  if (n <= 0) return CGAT_OK;
+  const bool vec = ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
+  const long n4 = vec ? n / 4 : 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n4 > 0 ? n4 : n)), dim3(256), 0, s, x, alpha, out, n4, n);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows,
                               int cols) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -23,21 +23,18 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// the workgroup's slab tile `o` = [NX][128][128] + [128] partial sums over rows nbeg .. nend-1
 template <int NX>
-__global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restrict__ G, long ldg,
-                                                            const float* __restrict__ X1, long ldx1,
-                                                            const float* __restrict__ X2, long ldx2,
-                                                            float* __restrict__ slab, int rows, int rows_per_wg) {
+__device__ __forceinline__ void rows_dw128_body(const float* __restrict__ G, long ldg, const float* __restrict__ X1,
+                                                long ldx1, const float* __restrict__ X2, long ldx2,
+                                                float* __restrict__ o, int nbeg, int nend, float* red) {
   constexpr int U = 4;                                 // k-steps (2 rows each) per register batch; three batches
                                                        // rotate so that two are in flight while one is consumed (one
                                                        // ahead left the waves waiting on HBM latency: 50 us vs 18 us of MFMA)
-  constexpr int SLAB = NX * 128 * 128 + 128;           // floats per workgroup: out_1, (out_2,) bsum
-  extern __shared__ float red[];                       // [NX][128][128] + [128]: the second row half's partial sums
+  // red: [NX][128][128] + [128] floats of LDS, the second row half's partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = wave & 3, h = wave >> 2;
   const int l32 = lane & 31, hi = lane >> 5;
-  const int nbeg = blockIdx.x * rows_per_wg;
-  const int nend = min(rows, nbeg + rows_per_wg);
   // this wave's rows: nbeg + 2 U (2 b + h) + 2 u + hi for batch b (the two halves interleave batch by batch)
   const int nbatch = (nend - nbeg + 4 * U - 1) / (4 * U);
 
@@ -116,7 +113,6 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restr
   }
   __syncthreads();
   if (h == 0) {
-    float* o = slab + (long)blockIdx.x * SLAB;
 #pragma unroll
     for (int k = 0; k < NX; ++k)
 #pragma unroll
@@ -129,6 +125,53 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restr
       }
     if (hi == 0) o[NX * 128 * 128 + 4 * l32 + w] = cs + red[NX * 128 * 128 + 4 * l32 + w];
   }
+}
+
+template <int NX>
+__global__ __launch_bounds__(512, 1) void rows_dw128_kernel(const float* __restrict__ G, long ldg,
+                                                            const float* __restrict__ X1, long ldx1,
+                                                            const float* __restrict__ X2, long ldx2,
+                                                            float* __restrict__ slab, int rows, int rows_per_wg) {
+  constexpr int SLAB = NX * 128 * 128 + 128;           // floats per workgroup: out_1, (out_2,) bsum
+  extern __shared__ float red[];
+  const int nbeg = blockIdx.x * rows_per_wg;
+  rows_dw128_body<NX>(G, ldg, X1, ldx1, X2, ldx2, slab + (long)blockIdx.x * SLAB, nbeg, min(rows, nbeg + rows_per_wg), red);
+}
+
+// Many dense layers' weight gradients in ONE launch (the 4 x (n_fc + 2) products of a hypernetwork backward: 24 launches
+// + 24 reductions of ~40 + 12 us each, with a dispatch gap between every pair, become two launches).  Unit = (item, row
+// split): `splits` workgroups per item, chosen so that all units fit the chip at once; every item has one right operand
+// (a layer with two -- the linear terms B, U of a predicted layer share G -- is two items).
+__global__ __launch_bounds__(512, 1) void rows_dw128_batch_kernel(DwBatchDesc d, float* __restrict__ slab) {
+  extern __shared__ float red[];
+  const int item = blockIdx.x / d.splits, sp = blockIdx.x - item * d.splits;
+  const float* G = d.it[item].G;
+  const float* X = d.it[item].X;
+  const int nbeg = sp * d.rows_per_unit;
+  rows_dw128_body<1>(G, d.ldg, X, d.ldx, X, d.ldx, slab + (long)blockIdx.x * (16384 + 128), nbeg,
+                     min(d.rows, nbeg + d.rows_per_unit), red);
+}
+// out[o][i] = sum_s slab[item][s][o][i], bsum[o] = sum_s slab[item][s][16384 + o]; grid (516, n items)
+__global__ __launch_bounds__(256) void rows_dw128_reduce_batch_kernel(const float* __restrict__ slab, DwBatchDesc d) {
+  __shared__ float part[8][32];
+  const int item = blockIdx.y;
+  const int o = threadIdx.x & 31, zg = threadIdx.x >> 5;
+  const long total = 16384 + 128;
+  const long i = (long)blockIdx.x * 32 + o;
+  const float* sl = slab + (long)item * d.splits * total;
+  const int per = (d.splits + 7) / 8;
+  const int z0 = zg * per, z1 = min(d.splits, z0 + per);
+  float s = 0.f;
+  if (i < total)
+    for (int z = z0; z < z1; ++z) s += sl[(long)z * total + i];
+  part[zg][o] = s;
+  __syncthreads();
+  if (zg != 0 || i >= total) return;
+  s = part[0][o];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) s += part[g][o];
+  if (i < 16384) d.it[item].out[(i >> 7) * d.ldo + (i & 127)] = s;
+  else if (d.it[item].bsum) d.it[item].bsum[i - 16384] = s;
 }
 
 // out_k[o][i] = sum_s slab[s][k][o][i], bsum[o] = sum_s slab[s][NX][o]: the slab loop of an output is spread over
@@ -215,6 +258,52 @@ int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, floa
   const long total = (long)nx * 16384 + 128;
   hipLaunchKernelGGL(rows_dw128_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, stream, (const float*)ws, splits, nx,
                      out1, ldo1, out2, ldo2, bsum);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// ---- batched form ----
+static int dw_batch_splits(int n_items, int rows) {
+  int sp = 256 / (n_items > 0 ? n_items : 1);          // all units resident at once (one workgroup per CU)
+  const int most = cdiv(rows, 64);                     // at least 64 rows per unit
+  if (sp > most) sp = most;
+  return sp < 1 ? 1 : sp;
+}
+size_t rows_dw128_batch_ws_bytes(int n_items, int rows) {
+  return ws_round((size_t)n_items * dw_batch_splits(n_items, rows) * (16384 + 128), 4);
+}
+bool rows_dw128_batch_fast(const DwBatchDesc& d) {
+  if (d.n < 1 || d.n > DW_BATCH_MAX || d.rows < 1) return false;
+  for (int i = 0; i < d.n; ++i)
+    if (!rows_dw128_fast(d.it[i].G, d.ldg, d.it[i].X, d.ldx, nullptr, 0)) return false;
+  return true;
+}
+// d.n, d.rows, d.ldg, d.ldx, d.ldo and the items filled in by the caller; splits / rows_per_unit are set here
+int rows_dw128_batch_launch(DwBatchDesc d, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!rows_dw128_batch_fast(d)) {
+    cgat_set_error("rows_dw128_batch: not the fast shape (n = %d, rows = %d)", d.n, d.rows);
+    return CGAT_ERR_UNSUPPORTED;
+  }
+  const size_t need = rows_dw128_batch_ws_bytes(d.n, d.rows);
+  if (!ws || ws_bytes < need) {
+    cgat_set_error("rows_dw128_batch: workspace too small (%zu < %zu)", ws_bytes, need);
+    return CGAT_ERR_WORKSPACE;
+  }
+  d.splits = dw_batch_splits(d.n, d.rows);
+  d.rows_per_unit = cdiv(cdiv(d.rows, d.splits), 16) * 16;   // whole 16-row double batches
+  const size_t lds = (16384 + 128) * sizeof(float);
+  {
+    CGAT_PROF("rows_dw", stream);
+    static bool attr = false;
+    if (!attr) {
+      CGAT_HIP(hipFuncSetAttribute((const void*)rows_dw128_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(rows_dw128_batch_kernel, dim3(d.n * d.splits), dim3(512), lds, stream, d, (float*)ws);
+    CGAT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rows_dw128_reduce_batch_kernel, dim3(cdiv(16384 + 128, 32), d.n), dim3(256), 0, stream,
+                     (const float*)ws, d);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -307,6 +307,16 @@ typedef struct cgat_chain_desc {
 size_t cgat_mlp_chain_workspace_bytes(int32_t n_layers);
 int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight (and bias) gradients of many width-128 dense layers in ONE launch: for item i < n
+ *     out[i][o][k] = sum_r G[i][r,o] X[i][r,k]   (128 x 128, row stride ldo),   bsum[i][o] = sum_r G[i][r,o]  (or NULL)
+ * i.e. what autograd accumulates into nn.Linear.weight / .bias of the hypernetwork's trunk layers and linear terms
+ * (Hypernetworksmp.py:24-60, 77-83) and of the per-head second layers (CGAT.py:103-109): exact fp32 products
+ * (f32-input MFMA), fixed summation order.  All items share rows, ldg, ldx, ldo; n <= 32; G, X 16-byte aligned. */
+size_t cgat_dense_wgrad_batch_workspace_bytes(int32_t n, int32_t rows);
+int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const float* const* X, int64_t ldx,
+                           float* const* out, int64_t ldo, float* const* bsum, int32_t rows, void* ws, size_t ws_bytes,
+                           void* stream);
+
 /* Storage of the per-edge intermediates of cgat_nodes_attention_* (the pre-activations Z saved by forward and their
  * gradient gZ inside backward): 0 = fp32 (default), 1 = bf16 ("bf16 activations" of BASELINE configs[4]): halves the
  * bytes that bound the edge phase; attention logits, softmax statistics, sums and every matrix product stay as they

@@ -334,6 +334,47 @@ def _chain(env, rows, x, layers, in_dact=None, in_dact_type=0, in_store=None):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("rows,n,strided", [(1, 1, False), (63, 3, False), (1000, 24, False), (20001, 6, True),
+                                            (83340, 24, False)])
+def test_dense_wgrad_batch(env, rows, n, strided):
+    """Many nn.Linear weight / bias gradients in one launch (csrc/rowsdw.hip, the batched form): out_i = G_i^T X_i and
+    bsum_i = column sums of G_i against fp64, for 1 .. 24 items (the 24 of a hypernetwork backward), shared and distinct
+    operands, right operands that are 128-column slices of a wider matrix with outputs written into column slices (the
+    per-head second layers), and items without a bias sum; bitwise repeatable."""
+    _, _lib, ops, dev = env
+    g = torch.Generator().manual_seed(rows + n)
+    G = [torch.randn(rows, 128, generator=g).to(dev) for _ in range(min(n, 4))]
+    if strided:
+        wide = torch.randn(rows, 128 * n, generator=g).to(dev)
+        X = [wide[:, 128 * i:128 * (i + 1)] for i in range(n)]
+        outw = torch.zeros(128, 128 * n, device=dev)
+        out = [outw[:, 128 * i:128 * (i + 1)] for i in range(n)]
+        ldx, ldo = wide.stride(0), outw.stride(0)
+    else:
+        X = [torch.randn(rows, 128, generator=g).to(dev) for _ in range(n)]
+        out = [torch.zeros(128, 128, device=dev) for _ in range(n)]
+        ldx, ldo = 128, 128
+    Gs = [G[i % len(G)] for i in range(n)]
+    bs = [torch.zeros(128, device=dev) if i % 3 != 2 else None for i in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    ws = torch.empty(_lib.lib.cgat_dense_wgrad_batch_workspace_bytes(n, rows), dtype=torch.uint8, device=dev)
+
+    def run():
+        _lib.check(_lib.lib.cgat_dense_wgrad_batch(n, arr(Gs), 128, arr(X), ldx, arr(out), ldo, arr(bs), rows, ws.data_ptr(),
+                                                   ws.numel(), None), "cgat_dense_wgrad_batch")
+        torch.cuda.synchronize()
+        return [o.clone() for o in out], [None if b is None else b.clone() for b in bs]
+    o1, b1 = run()
+    o2, b2 = run()
+    for i in range(n):
+        ref = Gs[i].double().T @ X[i].double()
+        assert rel(o1[i], ref) <= TOL, i
+        assert torch.equal(o1[i], o2[i])
+        if bs[i] is not None:
+            assert rel(b1[i], Gs[i].double().sum(0)) <= TOL
+            assert torch.equal(b1[i], b2[i])
+
+
 @pytest.mark.parametrize("rows", [1, 127, 128, 1000, 20001])
 def test_mlp_chain_trunk_forward_and_backward(env, rows):
     """The fused dense-layer chain (csrc/chain.hip) in the two forms the hypernetwork uses: forward = four Linear+Tanh

@@ -14,9 +14,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 $Q > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $O/pmc_mfma.log 2>&1
+CGAT_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $O/pmc_mfma.log 2>&1
 python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass > $O/bench_stress.json 2> $O/bench_stress.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stress_stats -- python3 $R/bench.py --workload stress --graphs 12500 --steps 1 --warmup 1 --no-exclusive-pass > $O/stress_stats.log 2>&1
 python3 $R/bench.py --workload train --steps 5 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
 python3 $R/bench.py --workload stack --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass > $O/bench_stack.json 2> $O/bench_stack.err
+python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass --edge-storage bf16 > $O/bench_stress_bf16.json 2> $O/bench_stress_bf16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stack_stats -- python3 $R/bench.py --workload stack --steps 3 --warmup 1 --no-cpu-baseline --no-exclusive-pass > $O/stack_stats.log 2>&1
 tail -c 600 $O/bench.json

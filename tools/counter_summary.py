@@ -30,7 +30,13 @@ def main():
     for k, row in out.items():
         print(k[:60].ljust(60), " ".join(f"{c}={v:.4g}" for c, v in row.items()))
     if os.environ.get("COUNTER_JSON"):
-        json.dump(out, open(os.environ["COUNTER_JSON"], "w"), indent=1)
+        # compact form for the bench line: the kernels that use the matrix cores, utilisation to 3 digits
+        brief = {"what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per kernel, mean over its "
+                         "launches; rocprofv3 --pmc serialises kernels and the pass runs with CGAT_OVERLAP_WGRAD=0, "
+                         "so every kernel has the whole chip",
+                 "kernels": {k: {"launches": row["launches"], "mfma_util": round(row["mfma_util"], 3)}
+                             for k, row in out.items() if row.get("mfma_util", 0) >= 0.01}}
+        json.dump(brief, open(os.environ["COUNTER_JSON"], "w"), indent=1)
 
 
 if __name__ == "__main__":
