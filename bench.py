@@ -385,11 +385,13 @@ def layer_step_flops(N, E):
 
 def layer_step_bytes(N, E):
     """(compulsory, executed) HBM bytes of one layer step: SURVEY 8(d)'s 4.0 KB per edge, and the Z-sized passes the
-    implementation actually makes (Z written once and read twice, gZ written once and read three times,
-    6 x [N, C] saved per predicted layer, operands of the contractions)."""
+    implementation actually makes (Z written once and read twice -- the weighted sum reads its message
+    half, the backward all of it; the gradient gZ is not stored, one bit per element is written once and read three
+    times; 6 x [N, C] saved per predicted layer, operands of the contractions)."""
     W2b = 2 * HEADS * 256 * 4
     compulsory = 4.0e3 * E
-    executed = E * W2b * 7 + E * C_FEA * 4 * 6 + N * C_FEA * 4 * (4 * 6 * 3 + 4 * 12) + N * W2b * 6
+    executed = (E * W2b * 2.5 + E * (W2b // 32) * 4 + E * C_FEA * 4 * 6 + N * C_FEA * 4 * (4 * 6 * 3 + 4 * 12) +
+                N * W2b * 6)
     return compulsory, executed
 
 
@@ -466,12 +468,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     ALL_TAGS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
-                "edge_gw", "rows_ge", "rows_gw", "linear128", "mlp_chain", "rows_dw", "gemm_f32")
+                "edge_gw", "edge_gj", "rows_ge", "rows_gw", "linear128", "mlp_chain", "rows_dw", "gemm_f32")
     prof = {t: ops.prof_get(t) for t in ALL_TAGS}          # (launches, total ms) inside the timed region
     # With the weight-gradient contractions on the side stream they and the attention-backward kernels they run
     # beside share the chip, so their timed-region durations are not exclusive.  A short serial pass AFTER the timed
     # region (not part of `value`) gives those kernels' exclusive durations; both are reported.
-    concurrent = ("bilinear_wgrad", "edge_seg_bwd", "edge_ge", "edge_gw", "rows_ge", "rows_gw") \
+    concurrent = ("bilinear_wgrad", "edge_seg_bwd", "edge_ge", "edge_gw", "edge_gj", "rows_ge", "rows_gw", "rows_dw") \
         if (ops.overlap_enabled() and not args.no_exclusive_pass) else ()
     prof_x = {}
     if concurrent:
@@ -582,10 +584,13 @@ def main():
         # x[src] rows read, Pi rows once; other modes: Z written, Pj gathered (W2b per edge), e read, Pi rows once
         W2f = 2 * HEADS * 256 * 4                          # per-node rows (Pi, Gi, gS) are fp32 in either storage mode
         ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2f if mode == "f16x3" else E * (2 * W2b + C_FEA * 4) + N * W2f
+        # Backward (split-arithmetic modes at these widths): gZ [E, W2] is never stored -- edge_seg_bwd leaves one bit per
+        # element (W2 / 8 bytes per edge) and its consumers rebuild the rows from the per-node matrix gS (csrc/kernels.h
+        # struct EdgeRC), so only edge_seg_bwd is still bound by a Z-sized pass; edge_ge / edge_gw are priced against the
+        # matrix roof below.  f32 mode: the generic GEMM route with gZ stored (tags edge_ge / edge_gw do not occur).
+        W2cols = 2 * HEADS * 256
         hbm_alg = {"edge_z": ez_bytes,
-                   "edge_seg_bwd": E * 2 * W2b + N * (W2f + W2f // 2),       # Z read, gZ written, Gi written, gS read
-                   "edge_ge": E * (W2b + C_FEA * 4),                         # gZ read, g_e written
-                   "edge_gw": E * (W2b + C_FEA * (4 if mode == "f16x3" else 6))}   # gZ read, fp16x2 / bf16x3 planes of e read
+                   "edge_seg_bwd": E * (W2b + W2cols // 8) + N * (W2f + W2f // 2)}   # Z read, sign bits written, Gi written, gS read
         if stress:
             hbm_alg["edge_z"] *= 2                          # forward + the backward's per-chunk recomputation
         hbm = {}
@@ -594,8 +599,7 @@ def main():
             if n_t:
                 gbs = nbytes / (ms_t / args.steps * 1e-3) / 1e9      # bytes of the step / the tag's time in the step
                 hbm[tag] = {"bound": "hbm", "kernel": {"edge_z": "edge_zx_kernel" if mode == "f16x3" else "edge_z_kernel",
-                                                        "edge_seg_bwd": "edge_seg_bwd_kernel", "edge_ge": "edge_ge_kernel",
-                                                        "edge_gw": "edge_gw_kernel"}[tag],
+                                                        "edge_seg_bwd": "edge_seg_bwd_kernel"}[tag],
                             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(gbs / 8000.0, 4), "traffic": None, "launches_per_step": n_t / args.steps,
                             "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
@@ -606,6 +610,23 @@ def main():
                     hbm[tag]["concurrent"] = "shares the chip with the side-stream contractions in the timed region"
                     hbm[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4), "achieved": round(x_gbs, 1),
                                              "frac": round(x_gbs / 8000.0, 4)}
+        # the two per-edge products over the rebuilt gZ rows: 2 * E * W2 * 128 flop each, against the same matrix roof
+        edge_mfma = {}
+        if mode != "f32":
+            for tag, kname in (("edge_ge", "edge_ge_kernel"), ("edge_gw", "edge_gw_kernel")):
+                n_t, ms_t = prof[tag]
+                if n_t:
+                    fl = 2.0 * E * W2cols * C_FEA / (n_t / args.steps)          # one launch per chunk of the step
+                    ach = fl / (ms_t / n_t * 1e-3) / 1e12
+                    edge_mfma[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1),
+                                      "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches_per_step": n_t / args.steps,
+                                      "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
+                                      "flops_per_launch": fl}
+                    if tag in concurrent and prof_x.get(tag, (0, 0))[0]:
+                        x_ms = prof_x[tag][1] / prof_x[tag][0]
+                        edge_mfma[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4),
+                                                       "achieved": round(fl / (x_ms * 1e-3) / 1e12, 2),
+                                                       "frac": round(fl / (x_ms * 1e-3) / 1e12 / peak, 4)}
         shares = {}
         for tag in ALL_TAGS:
             n_t, ms_t = prof[tag]
@@ -646,6 +667,7 @@ def main():
                         f"N={N}, E={E}"),
                        "edges_per_rank": E, "parallelism": f"dp{world} (graphs sharded, gradient all-reduce)"},
             "roofline": roof, "hbm_bound_kernels": hbm if layer_like else None,
+            "edge_product_kernels": edge_mfma if layer_like else None,
             "kernel_ms_per_step": shares,
         }
         if args.workload == "layer":

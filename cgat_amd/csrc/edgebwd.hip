@@ -60,16 +60,19 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   }
 
   // B staging: thread tid moves 16-byte pieces tid, tid + 512 (, tid + 1024) of the k-step's [half0 | half1] image
-  uint4 sb0, sb1, sb2;
+  // (sb*: the tile stored at the end of this iteration, loaded during the previous one; tb*: the tile after it, loaded
+  // during this iteration -- a tile loaded and stored within one iteration left every wave waiting for its L2 latency
+  // in front of the barrier)
+  uint4 sb0, sb1, sb2, tb0, tb1, tb2;
   const int p1 = tid + 512, p2 = tid + 1024;
-#define GE_BLOAD(ks_)                                                                                    \
+#define GE_BLOAD(ks_, B0_, B1_, B2_)                                                                     \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
     const uint4* h0 = Wq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
     const uint4* h1 = Wq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
-    sb0 = h0[tid];                                                                                       \
-    sb1 = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
-    if (NP == 3) sb2 = h1[p2 - HP];                                                                      \
+    B0_ = h0[tid];                                                                                       \
+    B1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
+    if (NP == 3) B2_ = h1[p2 - HP];                                                                      \
   }
 #define GE_BSTORE(buf_)                                                                                  \
   {                                                                                                      \
@@ -119,12 +122,13 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   bf16x8 qa1, qa2, qa3, qb1, qb2, qb3;           // current k-step's gZ fragments (rows a, b)
   bf16x8 na1, na2, na3, nb1, nb2, nb3;           // next k-step's
   GE_ALOAD(0, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
-  GE_BLOAD(0);
+  GE_BLOAD(0, sb0, sb1, sb2);
   GE_SPLIT(ra0, ra1, rca_c, rca_m, qa1, qa2, qa3);
   GE_SPLIT(rb0, rb1, rcb_c, rcb_m, qb1, qb2, qb3);
   GE_BSTORE(0);
   ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nk > 1) GE_ALOAD(1, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
+  GE_BLOAD(1, sb0, sb1, sb2);               // nk >= 4
+  GE_ALOAD(1, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
   __syncthreads();
 
 #define GE_MFMA1(F1_, F2_, F3_, Q1_, Q2_, Q3_, P_)                                                       \
@@ -138,34 +142,50 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     P_ = mma16<F16>(F1_, Q2_, P_);                                                                       \
     P_ = mma16<F16>(F1_, Q1_, P_);                                                                       \
   }
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Bs[buf][lane]);
-    if (ks + 1 < nk) GE_BLOAD(ks + 1);
-    if (ks + 2 < nk) GE_ALOAD(ks + 2, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m);
-    // the raw values in ra/rb belong to k-step ks + 1: split them while this step's MFMAs run
-    bf16x8 f1 = bs[0], f2 = bs[256], f3;
-    if (PASSES >= 6) f3 = bs[512];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {                // 16-column output block g = (half, cb)
-      bf16x8 n1, n2, n3;
-      if (g < 7) {
-        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;
-        n1 = bs[o]; n2 = bs[o + 256];
-        if (PASSES >= 6) n3 = bs[o + 512];
-      }
-      GE_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);
-      if (g == 1 && ks + 1 < nk) GE_SPLIT(ra0, ra1, rca_c, rca_m, na1, na2, na3);
-      GE_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);
-      if (g == 4 && ks + 1 < nk) GE_SPLIT(rb0, rb1, rcb_c, rcb_m, nb1, nb2, nb3);
-      if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }
-    }
-    if (ks + 1 < nk) GE_BSTORE(buf ^ 1);
-    __syncthreads();
-    qa1 = na1; qa2 = na2; qa3 = na3; qb1 = nb1; qb2 = nb2; qb3 = nb3;
-    ra0 = sa0; ra1 = sa1; rb0 = sb0_; rb1 = sb1_;
-    rca_c = sca_c; rcb_c = scb_c; rca_m = sca_m; rcb_m = scb_m;
+  // One iteration: loads for k-step ks + 2 go into the (S, T) register sets, the (R, SB) sets -- loaded one iteration
+  // ago -- are consumed.  The loop is unrolled by two with the sets swapped instead of copied: a register copy of an
+  // in-flight load is a wait for it, and such copies at the loop end drained vmcnt every k-step.
+#define GE_ITER(ks_, buf_, RA0, RA1, RB0, RB1, RCA, RCB, RMA, RMB, SA0, SA1, SB0, SB1, SCA, SCB, SMA, SMB,           \
+                UB0, UB1, UB2, TB0, TB1, TB2)                                                            \
+  {                                                                                                      \
+    const bf16x8* bs = reinterpret_cast<const bf16x8*>(&Bs[buf_][lane]);                                 \
+    /* no branches in the body (loads past the end re-fetch the last k-step, splits and stores of such tiles are */ \
+    /* harmless): with conditional loads the compiler's wait-count bookkeeping turns conservative at every merge */ \
+    const int kl_ = (ks_) + 2 < nk ? (ks_) + 2 : nk - 1;                                                 \
+    GE_BLOAD(kl_, TB0, TB1, TB2);                                                                        \
+    GE_ALOAD(kl_, SA0, SA1, SB0, SB1, SCA, SCB, SMA, SMB);                                               \
+    __builtin_amdgcn_sched_barrier(0);     /* the loads are ISSUED here, not where the scheduler likes them */ \
+    /* the raw values in the R set belong to k-step ks + 1: split them while this step's MFMAs run */      \
+    bf16x8 f1 = bs[0], f2 = bs[256], f3;                                                                 \
+    if (PASSES >= 6) f3 = bs[512];                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {      /* 16-column output block g = (half, cb) */        \
+      bf16x8 n1, n2, n3;                                                                                 \
+      if (g < 7) {                                                                                       \
+        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;                                          \
+        n1 = bs[o]; n2 = bs[o + 256];                                                                    \
+        if (PASSES >= 6) n3 = bs[o + 512];                                                               \
+      }                                                                                                  \
+      GE_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);                                               \
+      if (g == 1) GE_SPLIT(RA0, RA1, RCA, RMA, na1, na2, na3);                                           \
+      GE_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);                                               \
+      if (g == 4) GE_SPLIT(RB0, RB1, RCB, RMB, nb1, nb2, nb3);                                           \
+      if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }                                                          \
+    }                                                                                                    \
+    Bs[(buf_) ^ 1][tid] = UB0; Bs[(buf_) ^ 1][p1] = UB1; if (NP == 3) Bs[(buf_) ^ 1][p2] = UB2;         \
+    /* LDS writes of this wave done, then the barrier -- NOT __syncthreads(): its fence also drains vmcnt, i.e. the */ \
+    /* operand loads just issued two k-steps ahead */                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");                                                                       \
+    qa1 = na1; qa2 = na2; qa3 = na3; qb1 = nb1; qb2 = nb2; qb3 = nb3;                                    \
   }
+  for (int ks = 0; ks < nk; ks += 2) {       // nk = 4 ncb is even
+    GE_ITER(ks, 0, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m,
+            sb0, sb1, sb2, tb0, tb1, tb2)
+    GE_ITER(ks + 1, 1, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m,
+            tb0, tb1, tb2, sb0, sb1, sb2)
+  }
+#undef GE_ITER
 #undef GE_BLOAD
 #undef GE_BSTORE
 #undef GE_ALOAD
@@ -244,7 +264,10 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   const int grp = wave >> 2, wq = wave & 3;              // column block of the pair, 32-column slice in it
   const int npair = ncb / 2;
   const int pair = blockIdx.x % npair, split = blockIdx.x / npair;
-  const int ks0 = (int)((long)nsteps * split / S), ks1 = (int)((long)nsteps * (split + 1) / S);
+  // ranges in units of two k-steps (the loop is unrolled by two without a tail); a k-step past nsteps holds slots >= E,
+  // which contribute zeros, and its e planes are the zero padding of the last 128-slot block
+  const int npairs = (nsteps + 1) / 2;
+  const int ks0 = 2 * (int)((long)npairs * split / S), ks1 = 2 * (int)((long)npairs * (split + 1) / S);
   const int cb128 = pair * 2 + grp;
   const float* gblk = gZ + (long)cb128 * gzb;
   const int gt = tid & 255;                              // thread within the column block's group
@@ -263,16 +286,17 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 se0, se1, se2;
+  // (se*: the tile stored at the end of this iteration, loaded during the previous one; te*: the one after it)
+  uint4 se0, se1, se2, te0, te1, te2;
   const int p1 = tid + 512, p2 = tid + 1024;
-#define GW_ELOAD(ks_)                                                                                    \
+#define GW_ELOAD(ks_, E0_, E1_, E2_)                                                                     \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
     const uint4* h0 = Eq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
     const uint4* h1 = Eq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
-    se0 = h0[tid];                                                                                       \
-    se1 = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
-    if (NP == 3) se2 = h1[p2 - HP];                                                                      \
+    E0_ = h0[tid];                                                                                       \
+    E1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
+    if (NP == 3) E2_ = h1[p2 - HP];                                                                      \
   }
 #define GW_ESTORE(buf_)                                                                                  \
   {                                                                                                      \
@@ -291,27 +315,48 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     const long t = (long)(ks_) * 32 + ((gt + 256 * (i_)) >> 5);                                          \
     D_ = rc.dst[t < E ? t : last_row];                                                                   \
   }
-#define GW_DLOAD(ks_) { if constexpr (RC) { if (!rc_isA) { GW_D1(ks_, 0, dn0) GW_D1(ks_, 1, dn1) GW_D1(ks_, 2, dn2) GW_D1(ks_, 3, dn3) } } }
-#define GW_G1(ks_, i_, R_, K_, M_, D_)                                                                   \
+  // (also in the attention half, where they are not used: no branches inside the loop body, see GW_ITER)
+#define GW_DLOAD(ks_) { if constexpr (RC) { GW_D1(ks_, 0, dn0) GW_D1(ks_, 1, dn1) GW_D1(ks_, 2, dn2) GW_D1(ks_, 3, dn3) } }
+  // row pointers of k-step ks_ from the dn* loaded for it (attention half: the constant wA -- through the same load,
+  // because selecting between a register copy and a pointer makes the compiler keep the copy in scratch)
+  const float *gp0 = nullptr, *gp1 = nullptr, *gp2 = nullptr, *gp3 = nullptr;
+#define GW_PTRS()                                                                                        \
+  {                                                                                                      \
+    if constexpr (RC) {                                                                                  \
+      gp0 = rc_isA ? rc.wA + rc_cc : rc.gS + (long)dn0 * rc.HHd + rc_cc;                                 \
+      gp1 = rc_isA ? rc.wA + rc_cc : rc.gS + (long)dn1 * rc.HHd + rc_cc;                                 \
+      gp2 = rc_isA ? rc.wA + rc_cc : rc.gS + (long)dn2 * rc.HHd + rc_cc;                                 \
+      gp3 = rc_isA ? rc.wA + rc_cc : rc.gS + (long)dn3 * rc.HHd + rc_cc;                                 \
+    }                                                                                                    \
+  }
+#define GW_G1(ks_, i_, R_, K_, M_, P_)                                                                   \
   {                                                                                                      \
     const int idx = gt + 256 * (i_);                                                                     \
     const long t = (long)(ks_) * 32 + (idx >> 5);                                                        \
     if constexpr (RC) {                                                                                  \
       const long tc = t < E ? t : last_row;                                                              \
-      R_ = *reinterpret_cast<const float4*>(rc_isA ? rc.wA + rc_cc : rc.gS + (long)(D_) * rc.HHd + rc_cc); \
-      K_ = t < E ? rc_coef[tc * rc.H] : 0.f;                                                             \
+      R_ = *reinterpret_cast<const float4*>(P_);                                                         \
+      const float kk_ = rc_coef[tc * rc.H];              /* unconditional load, then the select */        \
+      K_ = t < E ? kk_ : 0.f;                                                                            \
       M_ = rc.mask[tc * rc.nw + rc_word];                                                                \
     } else {                                                                                             \
       R_ = t < E ? *reinterpret_cast<const float4*>(gblk + t * ldg + 4 * (idx & 31))                     \
                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
     }                                                                                                    \
   }
-  // (RC: the dn* used here were loaded for exactly this k-step; the next k-step's are fetched right after)
-#define GW_GLOAD(ks_, A_, B_, C_, D_, KA_, KB_, KC_, KD_, MA_, MB_, MC_, MD_)                            \
+  // Order inside one group of loads (vmcnt retires in order): the row indices of the k-step AFTER this one first --
+  // they are needed (as addresses) at the top of the next iteration, and being the oldest of their group they can be
+  // waited for with everything behind them still in flight --, then the e tile, then the rows themselves.
+#define GW_LOADS(ks_, E0_, E1_, E2_, A_, B_, C_, D_, KA_, KB_, KC_, KD_, MA_, MB_, MC_, MD_)              \
   {                                                                                                      \
-    GW_G1(ks_, 0, A_, KA_, MA_, dn0) GW_G1(ks_, 1, B_, KB_, MB_, dn1)                                    \
-    GW_G1(ks_, 2, C_, KC_, MC_, dn2) GW_G1(ks_, 3, D_, KD_, MD_, dn3)                                    \
+    GW_PTRS()                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
     GW_DLOAD((ks_) + 1)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    GW_ELOAD(ks_, E0_, E1_, E2_);                                                                        \
+    GW_G1(ks_, 0, A_, KA_, MA_, gp0) GW_G1(ks_, 1, B_, KB_, MB_, gp1)                                    \
+    GW_G1(ks_, 2, C_, KC_, MC_, gp2) GW_G1(ks_, 3, D_, KD_, MD_, gp3)                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
   }
   // split one float4 (row idx >> 5, columns 4 (idx & 31) ...) and store 8 bytes per plane into image (b)
 #define GW_S1(i_, R_, K_, M_, buf_, sg_)                                                                 \
@@ -385,63 +430,77 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     GW_FLUSH(true, 1.f);
     return;
   }
-  GW_ELOAD(ks0);
   GW_DLOAD(ks0);
-  GW_GLOAD(ks0, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
-  GW_ESTORE(0);
+  GW_LOADS(ks0, se0, se1, se2, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
+  Es[0][tid] = se0; Es[0][p1] = se1;
+  if (NP == 3) Es[0][p2] = se2;
   GW_S1(0, r0, rk0, rm0, 0, 1.f) GW_S1(1, r1, rk1, rm1, 0, 1.f) GW_S1(2, r2, rk2, rm2, 0, 1.f) GW_S1(3, r3, rk3, rm3, 0, 1.f)
   r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
   rk0 = rk1 = rk2 = rk3 = 0.f;
-  if (ks0 + 1 < ks1) GW_GLOAD(ks0 + 1, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
+  GW_LOADS(ks0 + 1, se0, se1, se2, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);   // ranges are even
   __syncthreads();
   bool first = true;
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const int rel = ks - ks0, buf = rel & 1;
-    // sign of the flush group the NEXT k-step belongs to (its tile is split during this iteration)
-    const float sgn_next = (((rel + 1) / FLUSH) & 1) ? -1.f : 1.f;
-    if (ks + 1 < ks1) GW_ELOAD(ks + 1);
-    if (ks + 2 < ks1) GW_GLOAD(ks + 2, s0, s1, s2, s3, sk0, sk1, sk2, sk3, sm0, sm1, sm2, sm3);
-    const bf16x8* es = reinterpret_cast<const bf16x8*>(&Es[buf][lane]);
-    // this wave's two transposed gZ fragments (32 columns x 32 slots), three planes each
-    bf16x8 qa1 = GW_TRREAD(buf, 0, tr00, tr01), qa2 = GW_TRREAD(buf, 1, tr00, tr01), qa3;
-    bf16x8 qb1 = GW_TRREAD(buf, 0, tr10, tr11), qb2 = GW_TRREAD(buf, 1, tr10, tr11), qb3;
-    if (PASSES >= 6) { qa3 = GW_TRREAD(buf, 2, tr00, tr01); qb3 = GW_TRREAD(buf, 2, tr10, tr11); }
-    bf16x8 f1 = es[0], f2 = es[256], f3;
-    if (PASSES >= 6) f3 = es[512];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {                // 16 outputs k = 16 g ... : e fragment g = (half, cb)
-      bf16x8 n1, n2, n3;
-      if (g < 7) {
-        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;
-        n1 = es[o]; n2 = es[o + 256];
-        if (PASSES >= 6) n3 = es[o + 512];
-      }
-      GW_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);
-      if (ks + 1 < ks1) {
-        if (g == 0) GW_S1(0, r0, rk0, rm0, buf ^ 1, sgn_next)
-        if (g == 2) GW_S1(1, r1, rk1, rm1, buf ^ 1, sgn_next)
-        if (g == 4) GW_S1(2, r2, rk2, rm2, buf ^ 1, sgn_next)
-        if (g == 6) GW_S1(3, r3, rk3, rm3, buf ^ 1, sgn_next)
-      }
-      GW_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);
-      if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }
-    }
-    if (ks + 1 < ks1) GW_ESTORE(buf ^ 1);
-    if ((rel + 1) % FLUSH == 0 || ks + 1 == ks1) {
-      const float sg = ((rel / FLUSH) & 1) ? -1.f : 1.f;
-      GW_FLUSH(first, sg);
-      first = false;
-    }
-    __syncthreads();
-    r0 = s0; r1 = s1; r2 = s2; r3 = s3;
-    rk0 = sk0; rk1 = sk1; rk2 = sk2; rk3 = sk3; rm0 = sm0; rm1 = sm1; rm2 = sm2; rm3 = sm3;
+  // One iteration: the loads of k-step ks + 2 go into the (S, TE) register sets, the (R, UE) sets -- loaded one iteration
+  // ago -- are consumed.  Unrolled by two with the sets swapped instead of copied: a register copy of an in-flight load
+  // is a wait for it, and such copies at the loop end drained vmcnt every k-step.
+#define GW_ITER(ks_, buf_, R0, R1, R2, R3, RK0, RK1, RK2, RK3, RM0, RM1, RM2, RM3,                           \
+                S0, S1, S2, S3, SK0, SK1, SK2, SK3, SM0, SM1, SM2, SM3, UE0, UE1, UE2, TE0, TE1, TE2)    \
+  {                                                                                                      \
+    const int rel = (ks_) - ks0;                                                                         \
+    /* sign of the flush group the NEXT k-step belongs to (its tile is split during this iteration) */     \
+    const float sgn_next = (((rel + 1) / FLUSH) & 1) ? -1.f : 1.f;                                       \
+    /* no branches around the loads (past the range: the last k-step again, never used): with conditional loads */ \
+    /* the compiler's wait-count bookkeeping turns conservative at every merge */                         \
+    const int kl_ = (ks_) + 2 < ks1 ? (ks_) + 2 : ks1 - 1;                                               \
+    GW_LOADS(kl_, TE0, TE1, TE2, S0, S1, S2, S3, SK0, SK1, SK2, SK3, SM0, SM1, SM2, SM3);                \
+    const bf16x8* es = reinterpret_cast<const bf16x8*>(&Es[buf_][lane]);                                 \
+    /* this wave's two transposed gZ fragments (32 columns x 32 slots), three planes each */               \
+    bf16x8 qa1 = GW_TRREAD(buf_, 0, tr00, tr01), qa2 = GW_TRREAD(buf_, 1, tr00, tr01), qa3;              \
+    bf16x8 qb1 = GW_TRREAD(buf_, 0, tr10, tr11), qb2 = GW_TRREAD(buf_, 1, tr10, tr11), qb3;              \
+    if (PASSES >= 6) { qa3 = GW_TRREAD(buf_, 2, tr00, tr01); qb3 = GW_TRREAD(buf_, 2, tr10, tr11); }     \
+    bf16x8 f1 = es[0], f2 = es[256], f3;                                                                 \
+    if (PASSES >= 6) f3 = es[512];                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {      /* 16 outputs k = 16 g ...: e fragment g = (half, cb) */ \
+      bf16x8 n1, n2, n3;                                                                                 \
+      if (g < 7) {                                                                                       \
+        const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;                                          \
+        n1 = es[o]; n2 = es[o + 256];                                                                    \
+        if (PASSES >= 6) n3 = es[o + 512];                                                               \
+      }                                                                                                  \
+      GW_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);                                               \
+      if (g == 0) GW_S1(0, R0, RK0, RM0, (buf_) ^ 1, sgn_next)                                           \
+      if (g == 2) GW_S1(1, R1, RK1, RM1, (buf_) ^ 1, sgn_next)                                           \
+      if (g == 4) GW_S1(2, R2, RK2, RM2, (buf_) ^ 1, sgn_next)                                           \
+      if (g == 6) GW_S1(3, R3, RK3, RM3, (buf_) ^ 1, sgn_next)                                           \
+      GW_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);                                               \
+      if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }                                                          \
+    }                                                                                                    \
+    Es[(buf_) ^ 1][tid] = UE0; Es[(buf_) ^ 1][p1] = UE1; if (NP == 3) Es[(buf_) ^ 1][p2] = UE2;         \
+    if ((rel + 1) % FLUSH == 0 || (ks_) + 1 == ks1) {                                                    \
+      const float sg = ((rel / FLUSH) & 1) ? -1.f : 1.f;                                                 \
+      GW_FLUSH(first, sg);                                                                               \
+      first = false;                                                                                     \
+    }                                                                                                    \
+    /* LDS writes of this wave done, then the barrier -- NOT __syncthreads(): its fence also drains vmcnt, i.e. the */ \
+    /* operand loads just issued two k-steps ahead */                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");                                                                       \
   }
+  for (int ks = ks0; ks < ks1; ks += 2) {
+    GW_ITER(ks, 0, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3,
+            s0, s1, s2, s3, sk0, sk1, sk2, sk3, sm0, sm1, sm2, sm3, se0, se1, se2, te0, te1, te2)
+    GW_ITER(ks + 1, 1, s0, s1, s2, s3, sk0, sk1, sk2, sk3, sm0, sm1, sm2, sm3,
+            r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3, te0, te1, te2, se0, se1, se2)
+  }
+#undef GW_ITER
+#undef GW_LOADS
+#undef GW_PTRS
 #undef GW_ELOAD
 #undef GW_ESTORE
 #undef GW_G1
 #undef GW_D1
 #undef GW_DLOAD
-#undef GW_GLOAD
 #undef GW_S1
 #undef GW_TRADDR
 #undef GW_TRREAD

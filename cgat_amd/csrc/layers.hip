@@ -965,6 +965,7 @@ struct HnetSide {
   void* ws;
   size_t bytes;
   int wgrad_wgs;      // workgroups of the dT launch: 0 = one per CU, 128 = half of the chip
+  int dw_side;        // the batched dense-layer weight gradients: 1 = side stream behind the dT launch, 0 = main stream
 };
 // side workspace: [g_u of every predicted layer][g_pre of every trunk layer][slabs of the batched dense-layer weight
 // gradients][workspace of the dT launch]
@@ -1179,9 +1180,11 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     // HBM-bound, 0.7 ms for 24 products at 83 340 rows.  On the side stream it goes BEHIND the dT launch: that launch must
     // be resident before the caller's next kernel floods the chip with small workgroups (its 132-KB workgroups are not
     // placed while those keep arriving -- measured: 9.5 ms instead of 6.2 when it started 0.7 ms later)
-    if (side) {
+    if (side && side->dw_side) {
       CGAT_TRY(side_wait());
       CGAT_TRY(rows_dw128_batch_launch(dwb, (char*)side->ws + SL.dw, SL.wgrad - SL.dw, side->s));
+    } else if (side) {   // main stream; the operands live in the side workspace either way
+      CGAT_TRY(rows_dw128_batch_launch(dwb, (char*)side->ws + SL.dw, SL.wgrad - SL.dw, c.s));
     } else {
       CGAT_TRY(rows_dw128_batch_launch(dwb, c.scratch, c.scratch_bytes, c.s));
     }
@@ -1240,7 +1243,12 @@ extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_param
     side_wgs = e ? atoi(e) : 128;
     if (side_wgs < 8 || side_wgs > 256) side_wgs = 128;
   }
-  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_wgs};
+  static int dw_side = -1;
+  if (dw_side < 0) {
+    const char* e = getenv("CGAT_SIDE_DW");
+    dw_side = (e && e[0] == '0') ? 0 : 1;
+  }
+  HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_wgs, dw_side};
   return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);
 }
 extern "C" int cgat_hnet_backward(int32_t rows, const cgat_hnet_params* p, const float* h0, const float* v,
