@@ -17,7 +17,7 @@ import os
 
 import torch
 
-_max_edges_per_pass = int(os.environ.get("CGAT_MAX_EDGES_PER_PASS", str(4 << 20)))
+_max_edges_per_pass = int(os.environ.get("CGAT_MAX_EDGES_PER_PASS", str(8 << 20)))
 
 
 def set_max_edges_per_pass(n):
