@@ -36,7 +36,8 @@ ProfScope::ProfScope(const char* tag, hipStream_t s) : slot(-1), stream(s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.tag = tag;
-  if (hipEventCreate(&r.beg) != hipSuccess || hipEventCreate(&r.end) != hipSuccess) return;
+  if (hipEventCreate(&r.beg) != hipSuccess) return;
+  if (hipEventCreate(&r.end) != hipSuccess) { (void)hipEventDestroy(r.beg); return; }
   (void)hipEventRecord(r.beg, s);
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;

@@ -14,7 +14,12 @@
 // W_e[128 a + b][c]; chunk (a, half, s) = 12 KB at Wq + ((a*2 + half)*4 + s) * 768 uint4.
 // RC: the operand is not read but rebuilt from its ingredients (struct EdgeRC, kernels.h): per k-step and row one mask
 // word, one coefficient and 8 floats of a per-node row (or of the constant wA) instead of 8 floats of gZ
-__device__ __forceinline__ float rc_d(unsigned m, int bit) { return ((m >> bit) & 1u) ? 1.f : 0.01f; }
+// LeakyReLU'(z) from the sign bit: 1.0f or 0.01f chosen by a bitwise select of the two bit patterns (v_bfe_i32 +
+// v_bfi_b32: two instructions instead of the and / compare / cndmask a `?:` compiles to)
+__device__ __forceinline__ float rc_d(unsigned m, int bit) {
+  const unsigned s = (unsigned)((int)(m << (31 - bit)) >> 31);
+  return __uint_as_float((s & 0x3F800000u) | (~s & 0x3C23D70Au));
+}
 template <int PASSES, bool RC = false>
 __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict__ gZ, long ldg, long gzb,
                                                          const uint4* __restrict__ Wq, int ncb,
@@ -107,14 +112,17 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #define GE_SPLIT(R0_, R1_, C_, M_, Q1_, Q2_, Q3_)                                                        \
   {                                                                                                      \
     float g_[8] = {R0_.x, R0_.y, R0_.z, R0_.w, R1_.x, R1_.y, R1_.z, R1_.w};                              \
-    if constexpr (RC) {                                                                                  \
+    if constexpr (RC) {           /* the power-of-two scale of the fp16 form rides on the coefficient: exact */ \
       const unsigned mb_ = (M_) >> (8 * kg);                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_[i_] = ((C_) * g_[i_]) * rc_d(mb_, i_);         \
+      const float cs_ = F16 ? (C_) * sA : (C_);                                                          \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_[i_] = (cs_ * g_[i_]) * rc_d(mb_, i_);          \
     }                                                                                                    \
-    if constexpr (F16) {                                                                                 \
+    if constexpr (F16 && !RC) {                                                                          \
       const float v[8] = {g_[0] * sA, g_[1] * sA, g_[2] * sA, g_[3] * sA,                                \
                           g_[4] * sA, g_[5] * sA, g_[6] * sA, g_[7] * sA};                               \
       split2_x8_f16(v, Q1_, Q2_);                                                                        \
+    } else if constexpr (F16) {                                                                          \
+      split2_x8_f16(g_, Q1_, Q2_);                                                                       \
     } else {                                                                                             \
       split3_x8(g_, Q1_, Q2_, Q3_);                                                                      \
     }                                                                                                    \
@@ -366,12 +374,19 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     const int off = 256 * row + 16 * ((c4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (c4 & 1); \
     uint2 x1, x2, x3;                                                                                    \
     float4 g_ = R_;                                                                                      \
-    if constexpr (RC) {               /* the stored value was (coefficient * vector) * d */                 \
-      const unsigned mb_ = (M_) >> rc_bit;                                                               \
-      g_.x = ((K_) * g_.x) * rc_d(mb_, 0); g_.y = ((K_) * g_.y) * rc_d(mb_, 1);                          \
-      g_.z = ((K_) * g_.z) * rc_d(mb_, 2); g_.w = ((K_) * g_.w) * rc_d(mb_, 3);                          \
+    if constexpr (RC) {   /* the stored value was (coefficient * vector) * d; the sign and the power-of-two scale */ \
+      const unsigned mb_ = (M_) >> rc_bit;     /* of the split ride on the coefficient (exact) */           \
+      const float ks_ = (K_) * (F16 ? (sg_) * sG : (sg_));                                                \
+      g_.x = (ks_ * g_.x) * rc_d(mb_, 0); g_.y = (ks_ * g_.y) * rc_d(mb_, 1);                            \
+      g_.z = (ks_ * g_.z) * rc_d(mb_, 2); g_.w = (ks_ * g_.w) * rc_d(mb_, 3);                            \
     }                                                                                                    \
-    if constexpr (F16) {                                                                                 \
+    if constexpr (RC && F16) {                                                                           \
+      split2_pair_f16(g_.x, g_.y, x1.x, x2.x);                                                           \
+      split2_pair_f16(g_.z, g_.w, x1.y, x2.y);                                                           \
+    } else if constexpr (RC) {                                                                           \
+      split3_pair(g_.x, g_.y, x1.x, x2.x, x3.x);                                                         \
+      split3_pair(g_.z, g_.w, x1.y, x2.y, x3.y);                                                         \
+    } else if constexpr (F16) {                                                                          \
       const float m_ = (sg_) * sG;                                                                       \
       split2_pair_f16(g_.x * m_, g_.y * m_, x1.x, x2.x);                                                 \
       split2_pair_f16(g_.z * m_, g_.w * m_, x1.y, x2.y);                                                 \

@@ -195,7 +195,59 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   const int n0 = blockIdx.x * SEGB_NODES, n1 = min(N, n0 + SEGB_NODES);
   // The three steps run over ALL segments of the workgroup before the next one starts: two barriers per workgroup
   // instead of three per node.
+  // With the sign-bit output and Hd = 256 (one float4 of a head per lane) step 1 also produces everything the MESSAGE
+  // half of gZ contributes -- its sign bits, its share of Gi, its maximum: they need alpha only, not the softmax
+  // backward -- so that step 3 reads only the attention half of Z (Z is then read once, not 1.5 times).  A wave owns
+  // head h = wave, wave + 4, ... of EVERY row of a segment, so its lanes accumulate Gi over the rows in the order
+  // step 3 used to (no cross-wave sum).
+  const bool fuse_m = VEC && mask != nullptr && Hd == 256;
   // ---- 1. g_alpha: one wave per edge row, wave-level reductions only ----
+  if (fuse_m) {
+    for (int n = n0; n < n1; ++n) {
+      const int r0 = rowptr[n], r1 = rowptr[n + 1];
+      if (r1 == r0) continue;                    // (step 3 zero-fills the whole Gi row of an empty segment)
+      for (int h = wave; h < H; h += 4) {
+        const int wcol = HHd + h * Hd + 4 * lane;                            // this lane's four columns of the row
+        const float4 g = *reinterpret_cast<const float4*>(gS + (long)n * HHd + h * Hd + 4 * lane);
+        const float gsn = gs[(long)n * H + h];
+        float4 gim = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tb = r0; tb < r1; tb += 4) {
+          float4 zv[4];
+          float al[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + u < r1 ? tb + u : r1 - 1;
+            zv[u] = ZB ? load4_bf16(reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + wcol)
+                       : *reinterpret_cast<const float4*>(Z + (long)t * W2 + wcol);
+            al[u] = alpha[(long)t * H + h];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + u;
+            if (t < r1) {
+              const float4 z = zv[u];
+              float part = (z.x > 0.f ? z.x : 0.01f * z.x) * g.x + (z.y > 0.f ? z.y : 0.01f * z.y) * g.y +
+                           (z.z > 0.f ? z.z : 0.01f * z.z) * g.z + (z.w > 0.f ? z.w : 0.01f * z.w) * g.w;
+              part = wave_sum_l(part);
+              if (lane == 0) tt[(long)t * H + h] = part + gsn;
+              const float a_ = al[u];
+              const float4 gz = make_float4(a_ * g.x * (z.x > 0.f ? 1.f : 0.01f), a_ * g.y * (z.y > 0.f ? 1.f : 0.01f),
+                                            a_ * g.z * (z.z > 0.f ? 1.f : 0.01f), a_ * g.w * (z.w > 0.f ? 1.f : 0.01f));
+              gm = fmaxf(fmaxf(gm, fmaxf(fabsf(gz.x), fabsf(gz.y))), fmaxf(fabsf(gz.z), fabsf(gz.w)));
+              gim.x += gz.x; gim.y += gz.y; gim.z += gz.z; gim.w += gz.w;
+              unsigned w = ((z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u))
+                           << (4 * (lane & 7));
+              w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+              w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+              w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x141, 0xF, 0xF, true);   // row_half_mirror
+              if ((lane & 7) == 0) mask[(long)t * (W2 >> 5) + (wcol >> 5)] = w;
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(Gi + (long)n * W2 + wcol) = gim;
+      }
+    }
+  } else
   for (int n = n0; n < n1; ++n) {
     const int r0 = rowptr[n], r1 = rowptr[n + 1];
     const float* gSn = gS + (long)n * HHd;
@@ -242,7 +294,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
     }
     const float* gSn = gS + (long)n * HHd;
     if (VEC) {  // four consecutive columns per thread (a head boundary is a multiple of 4); rows four at a time
-      for (int c4 = tid; c4 < W2 / 4; c4 += 256) {
+      for (int c4 = tid; c4 < (fuse_m ? HHd : W2) / 4; c4 += 256) {   // (fuse_m: the message half is done)
         const int col = 4 * c4;
         const bool isA = col < HHd;
         const int cc = isA ? col : col - HHd;
@@ -494,31 +546,9 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // rc: gZ was not stored; the per-edge launches and the source-side sum rebuild its rows (struct EdgeRC, kernels.h)
   // scales (f16x3 mode, optional): device {max |gZ|, max |e|} -> the per-edge products run on two fp16 planes
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
-  // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
-  if (!c.dry && rc)
-    CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && have_Gi,
-                   "nodes_attention_backward: the rebuilt-gZ path needs the split per-edge kernels");
-  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
-    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
-                       scales, rc));
-  } else {
-    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
-    g.a_block = xb;
-    g.b_kmajor = 1;
-    g.c_scatter = plan->dst_perm;
-    CGAT_TRY(c.gemm(g));
-  }
-  // grad W_e = gZ^T @ e[perm]
-  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
-    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s, scales,
-                       scales ? scales + 1 : nullptr, rc));
-  } else {
-    GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
-    g.a_block = xb;
-    g.a_kmajor = 1; g.b_kmajor = 1;
-    g.b_kgather = plan->dst_perm;
-    CGAT_TRY(c.gemm(g, true));
-  }
+  // Order: the HBM-bound kernels (segment sums, node-side products over the 0.5-GB Gi / Gj) first, the two matrix-bound
+  // per-edge products last -- the caller's side stream runs the matrix-bound dT launch on half of the chip meanwhile,
+  // and a matrix-bound kernel beside it takes 2.9x as long (edge_ge 1.3 -> 3.7 ms) where an HBM-bound one loses little.
   // segment sums of gZ: by destination (x_i side) unless the caller already has them, by source (x_j side)
   if (!have_Gi)
     RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
@@ -553,6 +583,31 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
     CGAT_TRY(c.gemm(g, true));
   }
   CGAT_TRY(c.colsum(Gi, d.W2, d.N, d.W2, gbcat, 1.f));
+  // grad edge_attr[perm[t]] = gZ[t] @ W_e: split-bf16 kernel at the benchmark widths, generic GEMM otherwise
+  if (!c.dry && rc)
+    CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && have_Gi,
+                   "nodes_attention_backward: the rebuilt-gZ path needs the split per-edge kernels");
+  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
+    RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
+                       scales, rc));
+  } else {
+    GemmParams g = gemm_params(d.E, d.Ce, d.W2, gZ, gz_ld, Wcat + d.C, d.D, g_e, d.Ce);
+    g.a_block = xb;
+    g.b_kmajor = 1;
+    g.c_scatter = plan->dst_perm;
+    CGAT_TRY(c.gemm(g));
+  }
+  // grad W_e = gZ^T @ e[perm]
+  if (!c.dry && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ)) {
+    RUN(edge_gw_launch(gZ, gz_ld, gzb, e, d.Ce, plan->dst_perm, d.E, d.W2, gw_ws, gWcat + d.C, d.D, c.s, scales,
+                       scales ? scales + 1 : nullptr, rc));
+  } else {
+    GemmParams g = gemm_params(d.W2, d.Ce, d.E, gZ, gz_ld, e, d.Ce, gWcat + d.C, d.D);
+    g.a_block = xb;
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.b_kgather = plan->dst_perm;
+    CGAT_TRY(c.gemm(g, true));
+  }
   return CGAT_OK;
 }
 

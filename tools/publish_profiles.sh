@@ -11,6 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do cp $(ls $D/pmc_$c/*/*_counter_collection.csv 
 python3 $R/tools/pmc_summary.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE r02
 COUNTER_JSON=$P/mfma_counters.json python3 $R/tools/counter_summary.py $D/pmc_mfma > $P/r02_final_counters_mfma.txt
 for w in stress train stack; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
+for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
 [ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/r02_bench_stress_bf16.json
 cp $(ls $D/stress_stats/*/*_kernel_stats.csv | head -1) $P/r02_stress_kernel_stats.csv
 [ -d $D/stack_stats ] && cp $(ls $D/stack_stats/*/*_kernel_stats.csv | head -1) $P/r02_stack_kernel_stats.csv
