@@ -385,8 +385,8 @@ def layer_step_flops(N, E):
 
 def layer_step_bytes(N, E):
     """(compulsory, executed) HBM bytes of one layer step: SURVEY 8(d)'s 4.0 KB per edge, and the Z-sized passes the
-    implementation actually makes (Z written once and read twice -- the weighted sum reads its message
-    half, the backward all of it; the gradient gZ is not stored, one bit per element is written once and read three
+    implementation actually makes (Z written once and read 1.5 times -- the weighted sum reads its message
+    half, the backward all of it once; the gradient gZ is not stored, one bit per element is written once and read three
     times; 6 x [N, C] saved per predicted layer, operands of the contractions)."""
     W2b = 2 * HEADS * 256 * 4
     compulsory = 4.0e3 * E

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     if constexpr (RC) {           /* the power-of-two scale of the fp16 form rides on the coefficient: exact */ \
       const unsigned mb_ = (M_) >> (8 * kg);                                                             \
       const float cs_ = F16 ? (C_) * sA : (C_);                                                          \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_[i_] = (cs_ * g_[i_]) * rc_d(mb_, i_);          \
+      /* __fmul_rn: the stored value was ROUNDED; contracted into the split's v - hi it would not be */   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) g_[i_] = __fmul_rn(cs_ * g_[i_], rc_d(mb_, i_));  \
     }                                                                                                    \
     if constexpr (F16 && !RC) {                                                                          \
       const float v[8] = {g_[0] * sA, g_[1] * sA, g_[2] * sA, g_[3] * sA,                                \
@@ -377,8 +378,9 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     if constexpr (RC) {   /* the stored value was (coefficient * vector) * d; the sign and the power-of-two scale */ \
       const unsigned mb_ = (M_) >> rc_bit;     /* of the split ride on the coefficient (exact) */           \
       const float ks_ = (K_) * (F16 ? (sg_) * sG : (sg_));                                                \
-      g_.x = (ks_ * g_.x) * rc_d(mb_, 0); g_.y = (ks_ * g_.y) * rc_d(mb_, 1);                            \
-      g_.z = (ks_ * g_.z) * rc_d(mb_, 2); g_.w = (ks_ * g_.w) * rc_d(mb_, 3);                            \
+      /* __fmul_rn: the stored value was ROUNDED; contracted into the split's v - hi it would not be */   \
+      g_.x = __fmul_rn(ks_ * g_.x, rc_d(mb_, 0)); g_.y = __fmul_rn(ks_ * g_.y, rc_d(mb_, 1));            \
+      g_.z = __fmul_rn(ks_ * g_.z, rc_d(mb_, 2)); g_.w = __fmul_rn(ks_ * g_.w, rc_d(mb_, 3));            \
     }                                                                                                    \
     if constexpr (RC && F16) {                                                                           \
       split2_pair_f16(g_.x, g_.y, x1.x, x2.x);                                                           \
@@ -622,7 +624,12 @@ __global__ __launch_bounds__(512) void edge_gj_kernel(const EdgeRC rc, const int
   const int cc = isA ? col : col - rc.HHd, h = cc / rc.Hd;
   const int word = col >> 5, bit = col & 31;
   const float* coef = (isA ? rc.ga : rc.alpha) + h;
-  const int n0 = blockIdx.x * GJ_NODES, n1 = min(N, n0 + GJ_NODES);
+  // XCD-aware order: consecutive workgroup ids go to different XCDs (own L2 each), but the gS rows a node gathers are
+  // those of its neighbours, i.e. of nearby nodes: give every XCD one contiguous range of nodes, so that a crystal's rows
+  // are fetched into one L2 instead of into five to eight (PMC: 3.1 GB of HBM traffic per launch for a 0.26-GB table)
+  const int per_xcd = gridDim.x / 8;                       // the grid is a multiple of 8
+  const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int n0 = blk * GJ_NODES, n1 = min(N, n0 + GJ_NODES);
   for (int n = n0; n < n1; ++n) {
     const int r0 = src_rowptr[n], r1 = src_rowptr[n + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -656,7 +663,7 @@ int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, 
   CGAT_CHECK_ARG(W2 % 4 == 0 && W2 / 4 <= 512 && (ldo % 4) == 0 && (((uintptr_t)Gj) & 15) == 0,
                  "edge_gj: W2 = %d must be a multiple of 4 up to 2048 with a 16-byte aligned output", W2);
   CGAT_PROF("edge_gj", stream);
-  hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(N, GJ_NODES)), dim3(cdiv(W2 / 4, 64) * 64), 0, stream, rc, src_rowptr, src_pos,
+  hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(cdiv(N, GJ_NODES), 8) * 8), dim3(cdiv(W2 / 4, 64) * 64), 0, stream, rc, src_rowptr, src_pos,
                      N, W2, Gj, ldo);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;

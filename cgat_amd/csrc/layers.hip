@@ -431,11 +431,11 @@ static int g_edge_storage = -1;
 static int edge_storage() {
   if (g_edge_storage < 0) {
     const char* e = getenv("CGAT_EDGE_STORAGE");
-    g_edge_storage = (e && !strcmp(e, "bf16")) ? 1 : 0;
+    g_edge_storage = (e && !strcmp(e, "bf16")) ? 1 : (e && !strcmp(e, "f32+gz")) ? 2 : 0;
   }
   return g_edge_storage;
 }
-extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = mode == 1 ? 1 : 0; }
+extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = (mode == 1 || mode == 2) ? mode : 0; }
 extern "C" int32_t cgat_get_edge_storage(void) { return edge_storage(); }
 static bool attn_bf16(const AttnDims& d) {
   return edge_storage() == 1 && bilinear_mode() == 2 && d.C == 128 && d.Ce == 128 && d.Hd % 128 == 0 && d.W2 % 256 == 0 &&
@@ -626,7 +626,9 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   float* ga = c.take<float>((size_t)d.E * d.H);
   // At the benchmark widths gZ [E, W2] is never stored: edge_seg_bwd_kernel leaves one bit per element behind and the
   // three consumers rebuild the rows (struct EdgeRC, kernels.h) -- E * W2 / 8 bytes of workspace instead of 4 E * W2
-  const bool rc_shape = bilinear_mode() != 0 && edge_rc_shape(d.Ce, d.H, d.Hd) && d.W2 % 256 == 0 && d.N > 0 && d.E > 0;
+  // (edge storage mode 2 keeps the stored-gZ backward of round 1 at these widths too: the A/B reference of the tests)
+  const bool rc_shape = bilinear_mode() != 0 && edge_rc_shape(d.Ce, d.H, d.Hd) && d.W2 % 256 == 0 && d.N > 0 && d.E > 0 &&
+                        edge_storage() != 2;
   float* gZ = c.take<float>(rc_shape ? (size_t)d.E * (d.W2 / 32) : (size_t)d.E * d.W2);
   float* partial = c.take<float>((size_t)chunks * d.HHd);
   float* Gi = c.take<float>((size_t)d.N * d.W2);

@@ -873,11 +873,11 @@ def set_edge_storage(mode):
     """Storage of the per-edge intermediates Z / gZ of the fused scalar-attention path: "f32" (default) or "bf16"
     (BASELINE configs[4]'s "bf16 activations": half the HBM bytes of the edge phase, tolerance 1e-2; logits, softmax
     statistics and all products unchanged).  Takes effect at C = Ce = 128 in the f16x3 arithmetic mode."""
-    lib.cgat_set_edge_storage({"f32": 0, "bf16": 1}[mode])
+    lib.cgat_set_edge_storage({"f32": 0, "bf16": 1, "f32+gz": 2}[mode])
 
 
 def get_edge_storage():
-    return "bf16" if lib.cgat_get_edge_storage() == 1 else "f32"
+    return {0: "f32", 1: "bf16", 2: "f32+gz"}[lib.cgat_get_edge_storage()]
 
 
 class _storage_of:

@@ -317,12 +317,16 @@ int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const 
                            float* const* out, int64_t ldo, float* const* bsum, int32_t rows, void* ws, size_t ws_bytes,
                            void* stream);
 
-/* Storage of the per-edge intermediates of cgat_nodes_attention_* (the pre-activations Z saved by forward and their
- * gradient gZ inside backward): 0 = fp32 (default), 1 = bf16 ("bf16 activations" of BASELINE configs[4]): halves the
- * bytes that bound the edge phase; attention logits, softmax statistics, sums and every matrix product stay as they
- * are (fp32 accumulation); tolerance of that mode 1e-2 max-norm relative.  Effective at C = Ce = 128 in the f16x3
- * arithmetic mode, ignored elsewhere.  A backward call must run under the mode its forward ran under.
- * Env CGAT_EDGE_STORAGE = bf16 sets the start value. */
+/* Storage of the per-edge intermediates of cgat_nodes_attention_*: the pre-activations Z saved by forward, and their
+ * gradient gZ inside backward -- which at the benchmark widths is NOT stored at all but rebuilt by its consumers from
+ * one sign bit per element and per-node rows (same values, bit for bit).
+ *   0 = fp32 Z (default);
+ *   1 = bf16 Z ("bf16 activations" of BASELINE configs[4]): halves the bytes of the Z-sized passes; attention logits,
+ *       softmax statistics, sums and every matrix product stay as they are (fp32 accumulation); tolerance of that mode
+ *       1e-2 max-norm relative.  Effective at C = Ce = 128 in the f16x3 arithmetic mode, ignored elsewhere;
+ *   2 = fp32 Z with gZ stored in backward (round 1's path, 6 KB more workspace per edge): the A/B reference of the tests.
+ * A backward call must run under the mode its forward ran under.  Env CGAT_EDGE_STORAGE = bf16 | f32+gz sets the start
+ * value. */
 void cgat_set_edge_storage(int32_t mode);
 int32_t cgat_get_edge_storage(void);
 

@@ -10,6 +10,15 @@ cp $(ls $D/stats/*/*_kernel_stats.csv | head -1) $P/r02_final_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do cp $(ls $D/pmc_$c/*/*_counter_collection.csv | head -1) $P/r02_final_pmc_${c}_counter_collection.csv; done
 python3 $R/tools/pmc_summary.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE r02
 COUNTER_JSON=$P/mfma_counters.json python3 $R/tools/counter_summary.py $D/pmc_mfma > $P/r02_final_counters_mfma.txt
+# the bench line read profiles/mfma_counters.json as it was on the box (the previous collection); attach this one's
+python3 - <<PY
+import json
+b = "$P/r02_final_bench.json"
+d = json.loads(open(b).read().strip().splitlines()[-1])
+if d.get("roofline"):
+    d["roofline"]["mfma_utilisation_from_counters"] = json.load(open("$P/mfma_counters.json"))
+open(b, "w").write(json.dumps(d) + "\n")
+PY
 for w in stress train stack; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
 for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
 [ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/r02_bench_stress_bf16.json
