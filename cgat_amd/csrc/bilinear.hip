@@ -960,6 +960,34 @@ __global__ void slab_sum_rows_kernel(const float* __restrict__ slab, int splits,
   out[(i >> 7) * ldo + (i & 127)] = s;
 }
 
+// The same sum with the hypernetwork's LayerNorm(no affine) + tanh behind it (reference Hypernetworksmp.py:205-209): one
+// wave per row sums the slabs into u (kept: backward needs the pre-norm values) and normalises what it holds in
+// registers -- the arithmetic of layernorm_tanh_fwd_kernel (rowops.hip) on the same values, one launch and one read of
+// u less per predicted layer.
+__global__ void slab_sum_ln_tanh_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
+                                        float* __restrict__ out, long ldo, float* __restrict__ y, float eps) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  float x0 = 0.f, x1 = 0.f;
+  for (int z = 0; z < splits; ++z) {
+    x0 += slab[(long)z * slab_stride + (long)row * 128 + lane];
+    x1 += slab[(long)z * slab_stride + (long)row * 128 + 64 + lane];
+  }
+  out[(long)row * ldo + lane] = x0;
+  out[(long)row * ldo + 64 + lane] = x1;
+  float s = 0.f;
+  s += x0; s += x1;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / 128;
+  float v = 0.f;
+  { const float d0 = x0 - mean; v += d0 * d0; const float d1 = x1 - mean; v += d1 * d1; }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const float rstd = rsqrtf(v / 128 + eps);
+  y[(long)row * 128 + lane] = tanhf((x0 - mean) * rstd);
+  y[(long)row * 128 + 64 + lane] = tanhf((x1 - mean) * rstd);
+}
+
 // any NA, NB, NC: one thread per output element (used for widths other than 128 and as a
 // cross-check of the MFMA kernel in the tests)
 __global__ void bilinear_rows_generic_kernel(const float* __restrict__ p, long ldp, const float* __restrict__ q,
@@ -1092,10 +1120,12 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
   return CGAT_OK;
 }
 
+// ln_out (optional, NC = 128): y = tanh(LayerNorm(out)) [nrows,128] contiguous, fused into the slab sum when there is one
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
                          long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, float* ln_out, float ln_eps) {
   if (nrows <= 0) return CGAT_OK;
+  bool ln_done = false;
   if (bilinear_T_interleaved(NB, NC)) {
     if (!rows_fast(q, ldq, NB, NC) || (((uintptr_t)T) & 15) != 0) {
       cgat_set_error("bilinear_rows: q and T must be 16-byte aligned with ldq %% 4 == 0 at width 128");
@@ -1174,7 +1204,12 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
 #undef BIL_LAUNCH
     }
     CGAT_LAUNCH_CHECK();
-    if (sp > 1) {
+    if (sp > 1 && ln_out) {
+      hipLaunchKernelGGL(slab_sum_ln_tanh_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, stream, (const float*)ws, sp, stride,
+                         nrows, out, ldo, ln_out, ln_eps);
+      CGAT_LAUNCH_CHECK();
+      ln_done = true;
+    } else if (sp > 1) {
       hipLaunchKernelGGL(slab_sum_rows_kernel, dim3(cdiv((long)nrows * 128, 256)), dim3(256), 0, stream,
                          (const float*)ws, sp, stride, nrows, out, ldo);
       CGAT_LAUNCH_CHECK();
@@ -1184,6 +1219,13 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
     hipLaunchKernelGGL(bilinear_rows_generic_kernel, dim3(cdiv((long)nrows * NC, 256)), dim3(256), 0, stream, p, ldp,
                        q, ldq, T, init, ldi, out, ldo, nrows, NA, NB, NC);
     CGAT_LAUNCH_CHECK();
+  }
+  if (ln_out && !ln_done) {
+    if (NC != 128 || ldo != 128) {
+      cgat_set_error("bilinear_rows: the LayerNorm epilogue needs 128 contiguous columns");
+      return CGAT_ERR_ARG;
+    }
+    return layernorm_tanh_fwd_launch(out, ln_out, nrows, 128, ln_eps, stream);
   }
   return CGAT_OK;
 }

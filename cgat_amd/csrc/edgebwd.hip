@@ -608,62 +608,62 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
 
 // ---------------------------------------------------------------------------------------
 //     Gj[n, :] = sum_{edges leaving n} gZ[t, :]          (edge_gj_kernel: the x_j-side segment sum of the rebuilt rows)
-// One workgroup per GJ_NODES source nodes, one thread per four columns (W2 / 4 threads); per edge a thread fetches its
+// One workgroup per GJ_NODES source nodes, a thread per four columns (256 threads walk the W2 / 4 quads); per edge a thread fetches its
 // mask word, its coefficient and -- message half -- four floats of the destination's gS row (the destinations of a
 // node's edges are its neighbours in the same crystal: those rows stay in L2), instead of 16 bytes of a 6-KB gZ row
 // gathered from HBM.  Edges four at a time so that the dependent chain slot -> destination -> row overlaps.
 // ---------------------------------------------------------------------------------------
 #define GJ_NODES 4
-__global__ __launch_bounds__(512) void edge_gj_kernel(const EdgeRC rc, const int* __restrict__ src_rowptr,
+__global__ __launch_bounds__(256) void edge_gj_kernel(const EdgeRC rc, const int* __restrict__ src_rowptr,
                                                       const int* __restrict__ src_pos, int N, int W2,
                                                       float* __restrict__ Gj, long ldo) {
-  const int q = threadIdx.x;
-  if (4 * q >= W2) return;
-  const int col = 4 * q;
-  const bool isA = col < rc.HHd;
-  const int cc = isA ? col : col - rc.HHd, h = cc / rc.Hd;
-  const int word = col >> 5, bit = col & 31;
-  const float* coef = (isA ? rc.ga : rc.alpha) + h;
   // XCD-aware order: consecutive workgroup ids go to different XCDs (own L2 each), but the gS rows a node gathers are
   // those of its neighbours, i.e. of nearby nodes: give every XCD one contiguous range of nodes, so that a crystal's rows
   // are fetched into one L2 instead of into five to eight (PMC: 3.1 GB of HBM traffic per launch for a 0.26-GB table)
   const int per_xcd = gridDim.x / 8;                       // the grid is a multiple of 8
   const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int n0 = blk * GJ_NODES, n1 = min(N, n0 + GJ_NODES);
-  for (int n = n0; n < n1; ++n) {
-    const int r0 = src_rowptr[n], r1 = src_rowptr[n + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int rb = r0; rb < r1; rb += 4) {
-      long t[4];
-      float k[4];
-      unsigned m[4];
-      float4 v[4];
+  for (int q = threadIdx.x; 4 * q < W2; q += 256) {      // four columns per thread (W2 = 1536: 1.5 rounds)
+    const int col = 4 * q;
+    const bool isA = col < rc.HHd;
+    const int cc = isA ? col : col - rc.HHd, h = cc / rc.Hd;
+    const int word = col >> 5, bit = col & 31;
+    const float* coef = (isA ? rc.ga : rc.alpha) + h;
+    for (int n = n0; n < n1; ++n) {
+      const int r0 = src_rowptr[n], r1 = src_rowptr[n + 1];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int rb = r0; rb < r1; rb += 4) {
+        long t[4];
+        float k[4];
+        unsigned m[4];
+        float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = src_pos[rb + u < r1 ? rb + u : r1 - 1];
+        for (int u = 0; u < 4; ++u) t[u] = src_pos[rb + u < r1 ? rb + u : r1 - 1];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        k[u] = rb + u < r1 ? coef[t[u] * rc.H] : 0.f;
-        m[u] = rc.mask[t[u] * rc.nw + word];
-        // (attention half: the constant wA through the same load -- see edge_gw_kernel)
-        v[u] = *reinterpret_cast<const float4*>(isA ? rc.wA + cc : rc.gS + (long)rc.dst[t[u]] * rc.HHd + cc);
+        for (int u = 0; u < 4; ++u) {
+          k[u] = rb + u < r1 ? coef[t[u] * rc.H] : 0.f;
+          m[u] = rc.mask[t[u] * rc.nw + word];
+          // (attention half: the constant wA through the same load -- see edge_gw_kernel)
+          v[u] = *reinterpret_cast<const float4*>(isA ? rc.wA + cc : rc.gS + (long)rc.dst[t[u]] * rc.HHd + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned mb = m[u] >> bit;
+          acc.x += (k[u] * v[u].x) * rc_d(mb, 0); acc.y += (k[u] * v[u].y) * rc_d(mb, 1);
+          acc.z += (k[u] * v[u].z) * rc_d(mb, 2); acc.w += (k[u] * v[u].w) * rc_d(mb, 3);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned mb = m[u] >> bit;
-        acc.x += (k[u] * v[u].x) * rc_d(mb, 0); acc.y += (k[u] * v[u].y) * rc_d(mb, 1);
-        acc.z += (k[u] * v[u].z) * rc_d(mb, 2); acc.w += (k[u] * v[u].w) * rc_d(mb, 3);
-      }
+      *reinterpret_cast<float4*>(Gj + (long)n * ldo + col) = acc;
     }
-    *reinterpret_cast<float4*>(Gj + (long)n * ldo + col) = acc;
   }
 }
 int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, int N, int W2, float* Gj, long ldo,
                    hipStream_t stream) {
   if (N <= 0) return CGAT_OK;
-  CGAT_CHECK_ARG(W2 % 4 == 0 && W2 / 4 <= 512 && (ldo % 4) == 0 && (((uintptr_t)Gj) & 15) == 0,
-                 "edge_gj: W2 = %d must be a multiple of 4 up to 2048 with a 16-byte aligned output", W2);
+  CGAT_CHECK_ARG(W2 % 4 == 0 && (ldo % 4) == 0 && (((uintptr_t)Gj) & 15) == 0,
+                 "edge_gj: W2 = %d must be a multiple of 4 with a 16-byte aligned output", W2);
   CGAT_PROF("edge_gj", stream);
-  hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(cdiv(N, GJ_NODES), 8) * 8), dim3(cdiv(W2 / 4, 64) * 64), 0, stream, rc, src_rowptr, src_pos,
+  hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(cdiv(N, GJ_NODES), 8) * 8), dim3(256), 0, stream, rc, src_rowptr, src_pos,
                      N, W2, Gj, ldo);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;

@@ -64,7 +64,7 @@ int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);
 int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init,
                          long ldi, float* out, long ldo, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
-                         hipStream_t stream);
+                         hipStream_t stream, float* ln_out = nullptr, float ln_eps = 0.f);   // ln_out: tanh(LayerNorm(out))
 // fused pair (bilinear.hip, bilinear_rows128_dual_kernel): T = bilinear_prepare_T of the [128,128,128] operand
 bool bilinear_dual_fast(int NA, int NB, int NC);
 size_t bilinear_dual_ws_bytes(int nrows);

@@ -89,10 +89,11 @@ struct Ctx {
     return bilinear_wgrad_batch_launch(n, p, W, q, W, r, W, out, rows, W, W, W, scratch, scratch_bytes, s);
   }
   int bilinear(const float* p, long ldp, const float* q, long ldq, const float* T, const float* init, long ldi,
-               float* out, long ldo, int rows, int NA, int NB, int NC) {
+               float* out, long ldo, int rows, int NA, int NB, int NC, float* ln_out = nullptr, float ln_eps = 0.f) {
     need(bilinear_rows_ws_bytes(rows, NA, NB, NC));
     if (dry) return CGAT_OK;
-    return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, scratch, scratch_bytes, s);
+    return bilinear_rows_launch(p, ldp, q, ldq, T, init, ldi, out, ldo, rows, NA, NB, NC, scratch, scratch_bytes, s,
+                                ln_out, ln_eps);
   }
   int dual(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
            const float* init1, long ldi1, float* out1, long ldo1, const float* init2, long ldi2, float* out2, long ldo2,
@@ -1003,9 +1004,12 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
     }
     // trilinear term with T[o,i,k] = head_w[(o*W+i)*W + k] re-laid as Tp[i,k,o]
     RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 1, 2, 0, c.s));
-    CGAT_TRY(c.bilinear(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W));
-    if (l < p->n_hyper - 1) {
-      RUN(layernorm_tanh_fwd_launch(u, sv.vin(l + 1), rows, W, 1e-5f, c.s));
+    // (+ LayerNorm + tanh of every layer but the last, fused into the contraction's slab sum at width 128)
+    const bool ln = l < p->n_hyper - 1;
+    const bool ln_fused = ln && W == 128;
+    CGAT_TRY(c.bilinear(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W, (ln_fused && !c.dry) ? sv.vin(l + 1) : nullptr, 1e-5f));
+    if (ln) {
+      if (!ln_fused) RUN(layernorm_tanh_fwd_launch(u, sv.vin(l + 1), rows, W, 1e-5f, c.s));
       vin = c.dry ? nullptr : sv.vin(l + 1);
     }
   }

@@ -319,7 +319,7 @@ int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const 
 
 /* Storage of the per-edge intermediates of cgat_nodes_attention_*: the pre-activations Z saved by forward, and their
  * gradient gZ inside backward -- which at the benchmark widths is NOT stored at all but rebuilt by its consumers from
- * one sign bit per element and per-node rows (same values, bit for bit).
+ * one sign bit per element and per-node rows (same values to fp32 rounding).
  *   0 = fp32 Z (default);
  *   1 = bf16 Z ("bf16 activations" of BASELINE configs[4]): halves the bytes of the Z-sized passes; attention logits,
  *       softmax statistics, sums and every matrix product stay as they are (fp32 accumulation); tolerance of that mode

@@ -123,6 +123,22 @@ def _compare_with_oracle(mk_prod, mk_orac, inputs, call, tol=TOL):
     return worst
 
 
+@pytest.mark.parametrize("heads", [1, 5])
+def test_nodes_layer_other_head_counts_vs_oracle(heads):
+    """Scalar attention at C = Ce = 128 with 1 and 5 heads (the benchmark has 3): the widths of the per-edge kernels,
+    the sign-bit words and the head-per-wave pass of the segment backward all depend on H."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = P.synthetic_batch(40, 20, 12, seed=5)
+    g = torch.Generator().manual_seed(6)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, heads, concat=True),
+                         lambda: O.GATConvNodes(128, 128, 128, heads, concat=True), inputs, call)
+
+
 @pytest.mark.parametrize("first", [True, False])
 def test_nodes_layer_vs_oracle_random_init(first):
     """Config 1 -> 2 of BASELINE.json at a size the oracle finishes in seconds: 60 crystals
@@ -350,13 +366,14 @@ def test_dynamic_range_inside_one_batch():
         ref_max = ref.abs().amax(dim=(1, 2))
         flip = (flp - ref).abs().amax(dim=(1, 2))
         rel = err / ref_max
-        ok = err <= torch.maximum(TOL * ref_max, FLIP_MULT * flip)
+        ok = err <= TOL * ref_max + FLIP_MULT * flip     # (a sum: a crystal whose error IS one flip sits at err == flip)
         third = G // 3
         lo, hi = rel[:third].median(), rel[-third:].median()
         worst.append(f"  {name}: per-crystal rel err: median {float(rel.median()):.2e}, max {float(rel.max()):.2e} (admitted by "
                      f"its flip sensitivity where above 1e-4); third with the smallest cotangents: median {float(lo):.2e}, "
                      f"third with the largest: {float(hi):.2e}")
-        assert bool(ok.all()), (name, rel, flip / ref_max)
+        bad = (~ok).nonzero().flatten().tolist()
+        assert not bad, (name, [(i, f"err {float(err[i]):.3e} ref {float(ref_max[i]):.3e} flip {float(flip[i]):.3e}") for i in bad])
         # the crystals with the SMALLEST cotangents (1e-3 .. 1e-1 of a batch whose largest is 1e3) are as accurate as
         # the largest ones: the per-tensor fp16 scales do not cost them their relative accuracy
         assert float(lo) <= max(1e-5, 4 * float(hi)), (name, lo, hi)
