@@ -950,6 +950,78 @@ int prepare_T_f16_launch(const float* src, void* dst, int NA, long sa, long sb, 
   return CGAT_OK;
 }
 
+// ---- the same for several [NA,128,128] tensors at once (the predicted layers of a hypernetwork: 4 x (memset + absmax +
+// prepare) = 12 launches of ~8 us each with a dispatch gap between every pair -> 2 launches).  Maxima without atomics:
+// stage 1 writes one partial maximum per workgroup, every workgroup of stage 2 folds the 64 partials of its tensor.
+#define TPREP_PARTS 64
+__global__ void absmax_partial_batch_kernel(TPrepBatch b, long total, float* __restrict__ part) {
+  const float* src = b.src[blockIdx.y];
+  float m = 0.f;
+  const long n4 = total >> 2;                        // total = NA * 16384: a multiple of 4
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = s4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  __shared__ float wm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.y * TPREP_PARTS + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
+__global__ void prepare_T_f16_batch_kernel(TPrepBatch b, int NA, long sa, long sb, long sc, int alternate,
+                                           const float* __restrict__ part) {
+  const float* src = b.src[blockIdx.y];
+  _Float16* d16 = reinterpret_cast<_Float16*>(b.dst[blockIdx.y]);
+  float tm = part[blockIdx.y * TPREP_PARTS + (threadIdx.x & 63)];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+  const long total = (long)NA * 128 * 128;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(b.dst[blockIdx.y])[total] = tm;   // behind the planes
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int a = (int)(i >> 14), bb, c;
+  if (sc == 1) { bb = (int)((i >> 7) & 127); c = (int)(i & 127); }
+  else { c = (int)((i >> 7) & 127); bb = (int)(i & 127); }
+  float v = src[a * sa + bb * sb + c * sc];
+  if (alternate && (a & 1)) v = -v;
+  const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+  const int kh = bb >> 6, s2 = (bb >> 5) & 1, kg = (bb & 31) >> 3, j = bb & 7;
+  const long blk = ((((long)a * 2 + half) * 2 + kh) * 2 + s2) * 2;   // two planes per k-step, each [cb][kg][i][j]
+  const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+  float st, it;
+  pow2_scale(tm, st, it);
+  v *= st;
+  const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+  d16[(blk + 0) * 2048 + in] = h;
+  d16[(blk + 1) * 2048 + in] = l;
+}
+size_t bilinear_prepare_T_batch_ws_floats(int n) { return (size_t)(n > 0 ? n : 1) * TPREP_PARTS; }
+// f16x3 mode, 128-wide interleaved layout only (returns CGAT_ERR_UNSUPPORTED otherwise: prepare one by one);
+// dst[i]: bilinear_T_floats(...) floats each; part: bilinear_prepare_T_batch_ws_floats(n) floats
+int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, int n0, int n1, int n2, int perm0,
+                             int perm1, int perm2, float* part, hipStream_t stream) {
+  int dims[3] = {n0, n1, n2};
+  if (n < 1 || n > TPREP_MAX || bilinear_mode() != 2 || !bilinear_T_interleaved(dims[perm1], dims[perm2]))
+    return CGAT_ERR_UNSUPPORTED;
+  const long st[3] = {(long)n1 * n2, (long)n2, 1};
+  const int NA = dims[perm0];
+  const long total = (long)NA * 128 * 128;
+  TPrepBatch b;
+  b.n = n;
+  for (int i = 0; i < n; ++i) {
+    if ((((uintptr_t)src[i]) & 15) != 0) return CGAT_ERR_UNSUPPORTED;
+    b.src[i] = src[i]; b.dst[i] = dst[i];
+  }
+  hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(TPREP_PARTS, n), dim3(256), 0, stream, b, total, part);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prepare_T_f16_batch_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, stream, b, NA, st[perm0],
+                     st[perm1], st[perm2], 1, (const float*)part);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // out[n, c] = sum_s slab[s][n][c]   (fixed order)
 __global__ void slab_sum_rows_kernel(const float* __restrict__ slab, int splits, long slab_stride, int nrows,
                                      float* __restrict__ out, long ldo) {

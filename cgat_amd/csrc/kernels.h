@@ -59,6 +59,16 @@ bool bilinear_T_interleaved(int NB, int NC);
 int bilinear_mode();               // 0 f32 MFMA, 6 / 3: split-bf16 passes
 void bilinear_set_mode(int m);
 size_t bilinear_T_floats(int NA, int NB, int NC);  // workspace floats of the prepared T
+// several tensors in two launches (f16x3 mode at width 128; CGAT_ERR_UNSUPPORTED otherwise -> prepare one by one)
+#define TPREP_MAX 8
+struct TPrepBatch {
+  int n;
+  const float* src[TPREP_MAX];
+  void* dst[TPREP_MAX];
+};
+size_t bilinear_prepare_T_batch_ws_floats(int n);
+int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, int n0, int n1, int n2, int perm0,
+                             int perm1, int perm2, float* part, hipStream_t stream);
 int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                        hipStream_t stream);
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);

@@ -935,10 +935,23 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
                              float* saved) {
   const int W = p->W;
   const size_t WW = (size_t)W * W;
-  float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
+  // the re-laid T of every predicted layer, prepared up front in two launches where the batched form exists (f16x3)
+  const size_t Tfl = bilinear_T_floats(W, W, W);
+  const bool batch_T = W == 128 && bilinear_mode() == 2 && p->n_hyper <= TPREP_MAX;
+  float* Tp = c.take<float>((batch_T ? (size_t)p->n_hyper : 1) * Tfl);
+  float* Tpart = c.take<float>(bilinear_prepare_T_batch_ws_floats(p->n_hyper));
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
   if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
   c.seal();
+  bool T_ready = false;
+  if (batch_T && !c.dry) {
+    const float* tsrc[TPREP_MAX];
+    float* tdst[TPREP_MAX];
+    for (int l = 0; l < p->n_hyper; ++l) { tsrc[l] = p->layer[l].head_w; tdst[l] = Tp + (size_t)l * Tfl; }
+    const int rc_ = bilinear_prepare_T_batch(p->n_hyper, tsrc, tdst, W, W, W, 1, 2, 0, Tpart, c.s);
+    if (rc_ == CGAT_OK) T_ready = true;
+    else if (rc_ != CGAT_ERR_UNSUPPORTED) return rc_;
+  }
   if (batch_w) {   // every dense-layer weight of the pass, prepared in one launch (forward orientation [out][in])
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], W, 1);
@@ -1003,11 +1016,12 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
       CGAT_TRY(c.gemm(g));
     }
     // trilinear term with T[o,i,k] = head_w[(o*W+i)*W + k] re-laid as Tp[i,k,o]
-    RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 1, 2, 0, c.s));
+    float* Tl = Tp + (T_ready ? (size_t)l * Tfl : 0);
+    if (!T_ready) RUN(bilinear_prepare_T(L.head_w, Tl, W, W, W, 1, 2, 0, c.s));
     // (+ LayerNorm + tanh of every layer but the last, fused into the contraction's slab sum at width 128)
     const bool ln = l < p->n_hyper - 1;
     const bool ln_fused = ln && W == 128;
-    CGAT_TRY(c.bilinear(vin, W, z, W, Tp, u, W, u, W, rows, W, W, W, (ln_fused && !c.dry) ? sv.vin(l + 1) : nullptr, 1e-5f));
+    CGAT_TRY(c.bilinear(vin, W, z, W, Tl, u, W, u, W, rows, W, W, W, (ln_fused && !c.dry) ? sv.vin(l + 1) : nullptr, 1e-5f));
     if (ln) {
       if (!ln_fused) RUN(layernorm_tanh_fwd_launch(u, sv.vin(l + 1), rows, W, 1e-5f, c.s));
       vin = c.dry ? nullptr : sv.vin(l + 1);
@@ -1048,7 +1062,10 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const int W = p->W;
   const size_t WW = (size_t)W * W;
   const size_t rw = (size_t)rows * W;
-  float* Tp = c.take<float>(bilinear_T_floats(W, W, W));
+  const size_t Tfl = bilinear_T_floats(W, W, W);
+  const bool batch_T = W == 128 && bilinear_mode() == 2 && p->n_hyper <= TPREP_MAX && bilinear_dual_fast(W, W, W);
+  float* Tp = c.take<float>((batch_T ? (size_t)p->n_hyper : 1) * Tfl);
+  float* Tpart = c.take<float>(bilinear_prepare_T_batch_ws_floats(p->n_hyper));
   float* g_hin = c.take<float>(rw);
   float* g_u = c.take<float>((size_t)p->n_hyper * rw);   // one per predicted layer: all dT run in ONE launch at the end
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
@@ -1082,6 +1099,15 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       c.wprep_add(p->layer[l].head_w + WW * W, 1, W);
     }
     CGAT_TRY(c.wprep_run());
+  }
+  bool T_ready = false;   // the [a = i][b = o][c = k] operands of all predicted layers in two launches
+  if (batch_T && !c.dry) {
+    const float* tsrc[TPREP_MAX];
+    float* tdst[TPREP_MAX];
+    for (int l = 0; l < p->n_hyper; ++l) { tsrc[l] = p->layer[l].head_w; tdst[l] = Tp + (size_t)l * Tfl; }
+    const int rc_ = bilinear_prepare_T_batch(p->n_hyper, tsrc, tdst, W, W, W, 1, 0, 2, Tpart, c.s);
+    if (rc_ == CGAT_OK) T_ready = true;
+    else if (rc_ != CGAT_ERR_UNSUPPORTED) return rc_;
   }
   HnetSaved sv = hnet_saved(const_cast<float*>(saved), rows, p);
   const float* hin = p->damping ? sv.hin() : h0;
@@ -1134,8 +1160,9 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     }
     if (bilinear_dual_fast(W, W, W)) {
       // both bilinear parts from one contraction: M[n,i,k] = sum_o gu[o] T[o,i,k];  g_z += vin . M,  g_vin += M . z
-      RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 1, 0, 2, c.s));   // operand [a = i][b = o][c = k]
-      CGAT_TRY(c.dual(vin, W, gu, W, z, W, Tp, g_t, W, g_t, W, g_vin, W, g_vin, W, rows));
+      float* Tl = Tp + (T_ready ? (size_t)l * Tfl : 0);
+      if (!T_ready) RUN(bilinear_prepare_T(L.head_w, Tl, W, W, W, 1, 0, 2, c.s));   // operand [a = i][b = o][c = k]
+      CGAT_TRY(c.dual(vin, W, gu, W, z, W, Tl, g_t, W, g_t, W, g_vin, W, g_vin, W, rows));
     } else {
       RUN(bilinear_prepare_T(L.head_w, Tp, W, W, W, 0, 1, 2, c.s));
       CGAT_TRY(c.bilinear(gu, W, vin, W, Tp, g_t, W, g_t, W, rows, W, W, W));
