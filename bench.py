@@ -243,6 +243,74 @@ def bench_optim(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_edge_hyper(args, rank, world, device):
+    """Informational: the edge update WITH its per-edge hypernetwork, GATConvEdges(no_hyper=False)
+    (reference CGAT.py:187-229; not the shipped configuration, which discards this branch): forward + full backward
+    on the 1M-edge batch.  Per edge: the attention / message networks over [x_i; e; x_j], head softmax, and an H_Net
+    update whose contractions run over E rows instead of N."""
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    torch.manual_seed(1)
+    layer = P.GATConvEdges(C_FEA, C_FEA, C_FEA, HEADS, concat=True, no_hyper=False).to(device)
+    params = list(layer.parameters())
+    ei, x, e, x0, cot = make_inputs(args.graphs, rank, device, K_NBR)
+    g = torch.Generator().manual_seed(7 + rank)
+    E = ei.shape[1]
+    e0 = torch.randn(E, C_FEA, generator=g).to(device)     # the edge features the damping mixes in (x_0 of the edge net)
+    cot_e = torch.randn(E, C_FEA, generator=g).to(device)
+    x.requires_grad_(True); e.requires_grad_(True)
+
+    def step():
+        for p in params:
+            p.grad = None
+        x.grad = e.grad = None
+        y = layer(x, ei, e, e0)
+        y.backward(cot_e)
+    for _ in range(args.warmup):
+        step()
+    _fence(world)
+    ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _fence(world)
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        tags = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "mlp_chain", "rows_dw", "linear128", "gemm_f32", "edge_z")
+        shares = {}
+        for t_ in tags:
+            n_t, ms_t = ops.prof_get(t_)
+            if n_t:
+                shares[t_] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3)}
+        fl = 2.0 * E * C_FEA ** 3                           # one contraction launch over E rows
+        n_r, ms_r = ops.prof_get("bilinear_rows")
+        roof = None
+        if n_r:
+            ach = fl / (ms_r / n_r * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS / 3
+            roof = {"bound": "mfma", "kernel": "bilinear_rows128_ring16_kernel", "achieved": round(ach, 2),
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_ms": round(ms_r / n_r, 4), "flops_per_launch": fl}
+        print(json.dumps({
+            "metric": "edges/sec through one GATConvEdges(no_hyper=False) layer (fwd+bwd), 1M-edge batch [informational, SURVEY 8 f2]",
+            "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 storage / " + P.get_bilinear_mode(), "data": "synthetic",
+            "config": {"workload": f"GATConvEdges({C_FEA},{C_FEA},{C_FEA},heads={HEADS},no_hyper=False) fwd+bwd, "
+                                   f"{args.graphs} crystals x {ATOMS} atoms x {K_NBR} nbrs: E={E} rows through the per-edge H_Net",
+                       "parallelism": f"dp{world}"},
+            "roofline": roof, "kernel_ms_per_step": shares}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, device):
     """BASELINE configs[3]: the end-to-end data-parallel training step on a DCGAT-shaped synthetic dataset (ragged
     crystals of 2..40 atoms, 24 stored / 12 used neighbours, y = e_above_hull * n_atoms): device collation of the
@@ -412,7 +480,7 @@ def main():
     ap.add_argument("--edge-storage", choices=["f32", "bf16"], default="f32",
                     help="storage of the per-edge intermediates Z / gZ (bf16 = the 'bf16 activations' of configs[4]; "
                          "tolerance 1e-2 instead of 1e-4: never the default, reported in the line)")
-    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress"], default="layer",
+    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress", "edge_hyper"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -432,6 +500,8 @@ def main():
         return bench_collate(args, rank, world, device)
     if args.workload == "optim":
         return bench_optim(args, rank, world, device)
+    if args.workload == "edge_hyper":
+        return bench_edge_hyper(args, rank, world, device)
     if args.workload == "train":
         return bench_train(args, rank, world, device)
 
@@ -445,7 +515,7 @@ def main():
     K_used = args.nbrs or (64 if stress else K_NBR)
     if stress:
         # BASELINE configs[4]: 50 000 crystals x 20 atoms x 64 neighbours = 64 M edges through one layer, fwd + bwd, in
-        # closed chunks of <= 4 M edges (cgat_amd/chunked.py) so that the per-edge workspace stays bounded
+        # closed chunks of <= 8 M edges (cgat_amd/chunked.py) so that the per-edge workspace stays bounded
         if args.graphs == GRAPHS:
             args.graphs = 50000
         ops.set_validate_indices(False)

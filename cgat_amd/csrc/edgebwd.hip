@@ -307,11 +307,6 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     E1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
     if (NP == 3) E2_ = h1[p2 - HP];                                                                      \
   }
-#define GW_ESTORE(buf_)                                                                                  \
-  {                                                                                                      \
-    Es[buf_][tid] = se0; Es[buf_][p1] = se1;                                                             \
-    if (NP == 3) Es[buf_][p2] = se2;                                                                     \
-  }
   // raw gZ tile pieces: float4 number gt + 256 i of the k-step's contiguous [32][128] tile, i < 4
   float4 r0, r1, r2, r3, s0, s1, s2, s3;
   // RC: (coefficient, mask word) of the four rows in r* / s*, and the destination nodes of the rows one k-step further
@@ -514,7 +509,6 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
 #undef GW_LOADS
 #undef GW_PTRS
 #undef GW_ELOAD
-#undef GW_ESTORE
 #undef GW_G1
 #undef GW_D1
 #undef GW_DLOAD

@@ -21,6 +21,7 @@ python3 $R/bench.py --workload train --steps 5 --warmup 2 > $O/bench_train.json 
 python3 $R/bench.py --workload stack --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass > $O/bench_stack.json 2> $O/bench_stack.err
 python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass --edge-storage bf16 > $O/bench_stress_bf16.json 2> $O/bench_stress_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stack_stats -- python3 $R/bench.py --workload stack --steps 3 --warmup 1 --no-cpu-baseline --no-exclusive-pass > $O/stack_stats.log 2>&1
+python3 $R/bench.py --workload edge_hyper --steps 3 --warmup 1 > $O/bench_edge_hyper.json 2> $O/bench_edge_hyper.err
 # the N > 1 code path on the one GPU this box has (both ranks on cuda:0, gloo instead of RCCL: functional evidence only)
 CGAT_DIST_BACKEND=gloo CGAT_DIST_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-exclusive-pass > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
 CGAT_DIST_BACKEND=gloo CGAT_DIST_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 $R/bench.py --gpus 2 --workload train --steps 3 --warmup 1 > $O/bench_train_2ranks_one_gpu.json 2> $O/bench_train_2ranks_one_gpu.err

@@ -19,7 +19,7 @@ if d.get("roofline"):
     d["roofline"]["mfma_utilisation_from_counters"] = json.load(open("$P/mfma_counters.json"))
 open(b, "w").write(json.dumps(d) + "\n")
 PY
-for w in stress train stack; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
+for w in stress train stack edge_hyper; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
 for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
 [ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/r02_bench_stress_bf16.json
 cp $(ls $D/stress_stats/*/*_kernel_stats.csv | head -1) $P/r02_stress_kernel_stats.csv
