@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   GE_SPLIT(rb0, rb1, rcb_c, rcb_m, qb1, qb2, qb3);
   GE_BSTORE(0);
   ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  GE_BLOAD(1, sb0, sb1, sb2);               // nk >= 4
+  if constexpr (PASSES < 6) GE_BLOAD(1, sb0, sb1, sb2);   // nk >= 4
   GE_ALOAD(1, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m);
   __syncthreads();
 
@@ -161,7 +161,12 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     /* no branches in the body (loads past the end re-fetch the last k-step, splits and stores of such tiles are */ \
     /* harmless): with conditional loads the compiler's wait-count bookkeeping turns conservative at every merge */ \
     const int kl_ = (ks_) + 2 < nk ? (ks_) + 2 : nk - 1;                                                 \
-    GE_BLOAD(kl_, TB0, TB1, TB2);                                                                        \
+    if constexpr (PASSES >= 6) {   /* six-pass form: its three-plane tile one k-step ahead only (12 VGPRs less; */ \
+      const int kb_ = (ks_) + 1 < nk ? (ks_) + 1 : nk - 1;   /* the loads sit in front of the operand loads, so the */ \
+      GE_BLOAD(kb_, UB0, UB1, UB2);                          /* store's wait leaves those in flight) */     \
+    } else {                                                                                             \
+      GE_BLOAD(kl_, TB0, TB1, TB2);                                                                      \
+    }                                                                                                    \
     GE_ALOAD(kl_, SA0, SA1, SB0, SB1, SCA, SCB, SMA, SMB);                                               \
     __builtin_amdgcn_sched_barrier(0);     /* the loads are ISSUED here, not where the scheduler likes them */ \
     /* the raw values in the R set belong to k-step ks + 1: split them while this step's MFMAs run */      \
@@ -610,7 +615,8 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
 #define GJ_NODES 4
 __global__ __launch_bounds__(256) void edge_gj_kernel(const EdgeRC rc, const int* __restrict__ src_rowptr,
                                                       const int* __restrict__ src_pos, int N, int W2,
-                                                      float* __restrict__ Gj, long ldo) {
+                                                      float* __restrict__ Gj, long ldo, float* __restrict__ gjmax) {
+  float gmax = 0.f;
   // XCD-aware order: consecutive workgroup ids go to different XCDs (own L2 each), but the gS rows a node gathers are
   // those of its neighbours, i.e. of nearby nodes: give every XCD one contiguous range of nodes, so that a crystal's rows
   // are fetched into one L2 instead of into five to eight (PMC: 3.1 GB of HBM traffic per launch for a 0.26-GB table)
@@ -648,17 +654,19 @@ __global__ __launch_bounds__(256) void edge_gj_kernel(const EdgeRC rc, const int
         }
       }
       *reinterpret_cast<float4*>(Gj + (long)n * ldo + col) = acc;
+      gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     }
   }
+  if (gjmax) block_absmax_commit(gmax, gjmax);
 }
 int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, int N, int W2, float* Gj, long ldo,
-                   hipStream_t stream) {
+                   hipStream_t stream, float* gjmax) {
   if (N <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(W2 % 4 == 0 && (ldo % 4) == 0 && (((uintptr_t)Gj) & 15) == 0,
                  "edge_gj: W2 = %d must be a multiple of 4 with a 16-byte aligned output", W2);
   CGAT_PROF("edge_gj", stream);
   hipLaunchKernelGGL(edge_gj_kernel, dim3(cdiv(cdiv(N, GJ_NODES), 8) * 8), dim3(256), 0, stream, rc, src_rowptr, src_pos,
-                     N, W2, Gj, ldo);
+                     N, W2, Gj, ldo, gjmax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

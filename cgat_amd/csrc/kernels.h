@@ -193,7 +193,7 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
                    const EdgeRC* rc = nullptr);
 // Gj[n, :] = sum over the edges leaving n of the rebuilt gZ rows (src_rowptr / src_pos: slots grouped by source)
 int edge_gj_launch(const EdgeRC& rc, const int* src_rowptr, const int* src_pos, int N, int W2, float* Gj, long ldo,
-                   hipStream_t stream);
+                   hipStream_t stream, float* gjmax = nullptr);   // gjmax: max |Gj| folded in (zeroed by the caller)
 // dst[(a*d1 + b)*d2 + c] = src[...] under an index permutation of a [n0,n1,n2] tensor
 int permute3_launch(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                     int interleave, hipStream_t stream);

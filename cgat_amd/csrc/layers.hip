@@ -183,13 +183,15 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
                                                            const float* __restrict__ wA_out, int N, int H, int Hd,
                                                            float* __restrict__ tt, float* __restrict__ ga,
                                                            float* __restrict__ Gi, float* __restrict__ partialW,
-                                                           float* __restrict__ gzmax, unsigned* __restrict__ mask) {
+                                                           float* __restrict__ gzmax, unsigned* __restrict__ mask,
+                                                           float* __restrict__ gimax) {
+  // gimax (optional, VEC path): max |Gi| is folded into gimax[0] the same way -- the scale of the node-side products
   // mask (optional, VEC path, W2 % 256 == 0): gZ is NOT written; instead bit (col & 31) of mask[t][col >> 5] records
   // Z[t, col] > 0, from which -- with ga, alpha, gS, wA -- the consumers rebuild the row (struct EdgeRC, kernels.h)
   // gzmax (optional, VEC path): max |gZ| is folded into gzmax[0] (zeroed before) -- the per-tensor scale the fp16
   // forms of the two kernels that consume gZ need (edgebwd.hip); a maximum does not depend on the order it is taken in
   extern __shared__ float pw[];  // [HHd] per-column partial sums of g_a * leaky(zA)
-  float gm = 0.f;
+  float gm = 0.f, gim_max = 0.f;
   const int HHd = H * Hd, W2 = 2 * HHd;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < HHd; c += 256) pw[c] = 0.f;
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
           }
         }
         *reinterpret_cast<float4*>(Gi + (long)n * W2 + wcol) = gim;
+        gim_max = fmaxf(fmaxf(gim_max, fmaxf(fabsf(gim.x), fabsf(gim.y))), fmaxf(fabsf(gim.z), fabsf(gim.w)));
       }
     }
   } else
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
           }
         }
         *reinterpret_cast<float4*>(Gi + (long)n * W2 + col) = gi;
+        gim_max = fmaxf(fmaxf(gim_max, fmaxf(fabsf(gi.x), fabsf(gi.y))), fmaxf(fabsf(gi.z), fabsf(gi.w)));
         if (isA) {
           pw[cc] += ps.x; pw[cc + 1] += ps.y; pw[cc + 2] += ps.z; pw[cc + 3] += ps.w;
         }
@@ -400,6 +404,10 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   __syncthreads();
   for (int c = tid; c < HHd; c += 256) partialW[(long)blockIdx.x * HHd + c] = pw[c];
   if (VEC && gzmax) block_absmax_commit(gm, gzmax);
+  if (VEC && gimax) {
+    __syncthreads();                               // (the commit's staging words are shared by the two calls)
+    block_absmax_commit(gim_max, gimax);
+  }
 }
 
 struct AttnDims {
@@ -553,8 +561,11 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // segment sums of gZ: by destination (x_i side) unless the caller already has them, by source (x_j side)
   if (!have_Gi)
     RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
+  // node-side scales {max |Gi|, max |Gj|, max |x|} at scales[2..4] (rebuilt path in the f16x3 mode, see the caller)
+  const float* ns = (rc && scales && d.C == 128 && (((uintptr_t)x) & 15) == 0) ? scales + 2 : nullptr;
   if (rc) {
-    RUN(edge_gj_launch(*rc, plan->src_rowptr, plan->src_pos, d.N, d.W2, Gj, d.W2, c.s));
+    RUN(edge_gj_launch(*rc, plan->src_rowptr, plan->src_pos, d.N, d.W2, Gj, d.W2, c.s,
+                       ns ? const_cast<float*>(ns) + 1 : nullptr));
   } else {
     RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
                         c.s, xb));
@@ -564,10 +575,12 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
   if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
       ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
-    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, nullptr, c.s));
-    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, nullptr, c.s));
-    RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s));
-    RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s));
+    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, nullptr, c.s, ns));
+    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, nullptr, c.s,
+                       ns ? ns + 1 : nullptr));
+    RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s, ns, ns ? ns + 2 : nullptr));
+    RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s,
+                       ns ? ns + 1 : nullptr, ns ? ns + 2 : nullptr));
   } else {
     GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
     g.b_kmajor = 1;
@@ -711,7 +724,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     const bool vec = (d.Hd % 4 == 0) && ((((uintptr_t)sv.Z) | ((uintptr_t)gZ) | ((uintptr_t)gS) | ((uintptr_t)Gi) |
                                           ((uintptr_t)p->A_out_w)) & 15) == 0;
     have_scales = vec && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0;
-    if (have_scales) CGAT_HIP(hipMemsetAsync(scales, 0, 2 * sizeof(float), c.s));
+    if (have_scales) CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
     // the forward stored Z as bf16 under exactly this predicate (same tensors, same alignment)
     zb = attn_bf16(d) && edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
          edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
@@ -720,17 +733,19 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
                      "nodes_attention_backward: saved, edge_attr and MH_A.fc_out.weight must be 16-byte aligned at these widths");
     unsigned* mask = rc_shape ? reinterpret_cast<unsigned*>(gZ) : nullptr;
     float* gzmax = have_scales ? scales : (float*)nullptr;
+    // [2] max |Gi|, [3] max |Gj|, [4] max |x|: with them the node-side products run in the fp16 form too (rebuilt path)
+    float* gimax = (have_scales && rc_shape) ? scales + 2 : (float*)nullptr;
     if (zb) {
       CGAT_CHECK_ARG(rc_shape && have_scales, "nodes_attention_backward: the bf16 edge storage needs the vector form");
       hipLaunchKernelGGL((edge_seg_bwd_kernel<true, true>), dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask, gimax);
     } else if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
-                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask);
+                         plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask, gimax);
     else
       hipLaunchKernelGGL(edge_seg_bwd_kernel<false>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
                          plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, (float*)nullptr,
-                         (unsigned*)nullptr);
+                         (unsigned*)nullptr, (float*)nullptr);
     CGAT_LAUNCH_CHECK();
   }
   EdgeRC rc = {};
@@ -739,6 +754,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     rc.dst = plan->dst_sorted; rc.H = d.H; rc.Hd = d.Hd; rc.HHd = d.HHd; rc.nw = d.W2 / 32;
   }
   if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
+  if (have_scales && rc_shape && d.C == 128 && (((uintptr_t)x) & 15) == 0) RUN(absmax_rows128_launch(x, d.C, d.N, scales + 4, c.s));
   CGAT_TRY(c.colsum(ga, d.H, d.E, d.H, gr->A_out_b, 1.f));
   CGAT_TRY(c.colsum(partial, d.HHd, d.N > 0 ? chunks : 0, d.HHd, gr->A_out_w, 1.f));
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, rc_shape ? nullptr : gZ, gz_ld, gzb, Gi, Gj, true,
