@@ -459,6 +459,8 @@ __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict
         const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
         const float4 va = make_float4(pa[0] + ia.x, pa[1] + ia.y, pa[2] + ia.z, pa[3] + ia.w);
         const float4 vb = make_float4(pb[0] + ib.x, pb[1] + ib.y, pb[2] + ib.z, pb[3] + ib.w);
+        // (non-temporal stores of Z were tried at the end of round 2: 2.77 -> 3.27 ms -- the 64-byte pieces of a row that
+        // four consecutive store instructions write are merged into full lines by L2 only when they allocate there)
         // no `row < E` guard: the ring's vmcnt allowances count exactly eight stores per epilogue, and a wave whose
         // second row block lies past the end would skip four of them (lanes past the end hold the clamped row E - 1
         // and rewrite it with identical values)
