@@ -466,8 +466,8 @@ def layer_step_bytes(N, E):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)      # 20 x 25 ms: the clocks settle within the first steps
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--graphs", type=int, default=GRAPHS, help="crystals per rank (default: the 1M-edge batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exclusive-pass", action="store_true",
