@@ -526,7 +526,20 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   RUN(seg_wsum_launch(zb ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(sv.Z) + d.HHd) : sv.Z + d.HHd, d.W2,
                       nullptr, sv.alpha, d.H, d.Hd, plan->dst_rowptr, d.N, d.HHd, CGAT_ACT_LEAKY, sv.S, d.HHd, c.s, 0,
                       zb ? 1 : 0));
+  // aggr = (1/H) [ sum_h S[:,h,:] fc_out_M[h]^T + ssum b ].  At the benchmark widths the H products run as
+  // H * Hd / 128 accumulating launches of the dense-layer kernel (K = 128 each; the generic f32 GEMM tile took 0.1 ms
+  // per head) and 1/H is applied by the bias product that closes the sum.
+  const bool out_fast = bilinear_mode() != 0 && d.C == 128 && d.Hd % 128 == 0;
   for (int h = 0; h < d.H; ++h) {
+    if (out_fast) {
+      for (int j = 0; j < d.Hd / 128; ++j) {
+        GemmParams g = gemm_params(d.N, d.C, 128, sv.S + (size_t)h * d.Hd + 128 * j, d.HHd,
+                                   p->M_out_w + (size_t)h * d.C * d.Hd + 128 * j, d.Hd, aggr, d.C);
+        g.beta = (h > 0 || j > 0) ? 1.f : 0.f;
+        CGAT_TRY(c.gemm(g));
+      }
+      continue;
+    }
     GemmParams g = gemm_params(d.N, d.C, d.Hd, sv.S + (size_t)h * d.Hd, d.HHd, p->M_out_w + (size_t)h * d.C * d.Hd,
                                d.Hd, aggr, d.C);
     g.alpha = 1.f / d.H;
@@ -537,7 +550,7 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
     GemmParams g = gemm_params(d.N, d.C, d.H, sv.ssum, d.H, p->M_out_b, d.C, aggr, d.C);
     g.b_kmajor = 1;
     g.alpha = 1.f / d.H;
-    g.beta = 1.f;
+    g.beta = out_fast ? 1.f / d.H : 1.f;
     CGAT_TRY(c.gemm(g));
   }
   return check_ws(c, "nodes_attention_forward");
