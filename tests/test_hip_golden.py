@@ -206,6 +206,28 @@ def test_ragged_graphs_fast_widths_vs_oracle():
                          lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
 
 
+def test_irregular_degrees_fast_widths_vs_oracle():
+    """An arbitrary directed graph at the benchmark widths: atoms without incoming edges, atoms without outgoing edges,
+    a hub with 300 incoming edges, E = 3001 (no tile size divides it).  The backward's rebuilt-gZ kernels walk
+    destination segments (edge_seg_bwd, edge_ge), fixed-size slot tiles (edge_gw) and source segments (edge_gj): empty
+    segments, a segment longer than a workgroup's tile and clamped tails all occur here."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    rs = np.random.RandomState(77)
+    N, E = 500, 3001
+    src = rs.randint(0, 400, size=E)                      # atoms 400..499 never send
+    dst = rs.randint(100, 500, size=E)                    # atoms 0..99 never receive
+    dst[:300] = 123                                       # a hub
+    order = np.argsort(src, kind="stable")                # (source-major, like the reference's batches)
+    ei = torch.from_numpy(np.stack([src[order], dst[order]])).long()
+    g = torch.Generator().manual_seed(78)
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": ei,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True),
+                         lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
+
+
 def _ragged_k24(n_crystals, seed):
     rs = np.random.RandomState(seed)
     sizes = rs.randint(2, 41, size=n_crystals).tolist()
