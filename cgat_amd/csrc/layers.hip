@@ -1294,9 +1294,10 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     }
   }
   if (dwb.n > 0 && !c.dry) {
-    // HBM-bound, 0.7 ms for 24 products at 83 340 rows.  On the side stream it goes BEHIND the dT launch: that launch must
-    // be resident before the caller's next kernel floods the chip with small workgroups (its 132-KB workgroups are not
-    // placed while those keep arriving -- measured: 9.5 ms instead of 6.2 when it started 0.7 ms later)
+    // HBM-bound, 0.7 ms for 24 products at 83 340 rows; by default on the main stream, right here.  On the side stream
+    // (CGAT_SIDE_DW=1) it goes BEHIND the dT launch: that launch must be resident before the caller's next kernel floods
+    // the chip with small workgroups (its 132-KB workgroups are not placed while those keep arriving -- measured: 9.5 ms
+    // instead of 6.2 when it started 0.7 ms later), and there it ends up beside the matrix-bound edge_ge (1.3 -> 2.5 ms)
     if (side && side->dw_side) {
       CGAT_TRY(side_wait());
       CGAT_TRY(rows_dw128_batch_launch(dwb, (char*)side->ws + SL.dw, SL.wgrad - SL.dw, side->s));
@@ -1362,8 +1363,8 @@ extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_param
   }
   static int dw_side = -1;
   if (dw_side < 0) {
-    const char* e = getenv("CGAT_SIDE_DW");
-    dw_side = (e && e[0] == '0') ? 0 : 1;
+    const char* e = getenv("CGAT_SIDE_DW");   // default: main stream (behind the dT launch on the side stream the batch
+    dw_side = (e && e[0] == '1') ? 1 : 0;     // collided with the matrix-bound edge_ge: 24.14 vs 23.95 ms per step)
   }
   HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_wgs, dw_side};
   return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);

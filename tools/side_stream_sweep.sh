@@ -12,10 +12,10 @@ print("$n", round(d["ms_per_step"],3), {t:k[t]["ms_per_step"] for t in ("bilinea
 PY
 }
 run default X=1
-run dw_main CGAT_SIDE_DW=0
+run dw_side CGAT_SIDE_DW=1
 run wgs256 CGAT_SIDE_WGRAD_WGS=256
 run wgs192 CGAT_SIDE_WGRAD_WGS=192
 run wgs160 CGAT_SIDE_WGRAD_WGS=160
-run wgs256_dwmain CGAT_SIDE_WGRAD_WGS=256 CGAT_SIDE_DW=0
+run wgs256_dwside CGAT_SIDE_WGRAD_WGS=256 CGAT_SIDE_DW=1
 run serial CGAT_OVERLAP_WGRAD=0
 run default2 X=1
