@@ -113,6 +113,11 @@ class GATConvEdges(nn.Module):
         if self.no_hyper:
             return self.Pooling_NN(edge_attr)
         plan = get_plan(edge_index, x.shape[0])
+        if x.is_cuda and type(self.MH_A) is MultiHeadNetwork and type(self.MH_M) is MultiHeadNetwork:
+            aggr_out = self._message_fast(x, edge_attr, plan)
+            if self.first:
+                return self.Pooling_NN(edge_attr, aggr_out)
+            return self.Pooling_NN(x_0, edge_attr, aggr_out)
         splan0, splan1 = _endpoint_plans(plan, edge_index)
         x_i = gather_rows(x, edge_index[0], splan0)           # note: opposite naming to GATConvNodes (209-210)
         x_j = gather_rows(x, edge_index[1], splan1)
@@ -124,6 +129,31 @@ class GATConvEdges(nn.Module):
         if self.first:
             return self.Pooling_NN(edge_attr, aggr_out)
         return self.Pooling_NN(x_0, edge_attr, aggr_out)
+
+
+def _gatconvedges_message_fast(self, x, edge_attr, plan):
+    """The attention / message networks of the edge update without the concatenated [E, 2C+Ce] rows: first layers of
+    both networks as ONE operand-split op in destination-sorted slot order (EdgeHiddenFn, the op of the vector-attention
+    node layer), the 2H second layers as one autograd node, the head softmax and mean on [E, H, .] tensors, and one
+    permutation back to the caller's edge order at the end."""
+    a, m = self.MH_A, self.MH_M
+    H, Hd, Co = self.heads, a.hidden_layer_dim, self.out_channels
+    D, C, Ce = a.input_dim, self.in_channels, self.nbr_channels
+    w = torch.cat([a.fc_in.weight.reshape(H * Hd, D), m.fc_in.weight.reshape(H * Hd, D)], dim=0)
+    # the edge update names the endpoints the other way round (CGAT.py:209-210: x_i = x[edge_index[0]]); the op
+    # multiplies its first column block with x[edge_index[1]] and its last with x[edge_index[0]]: swap the blocks
+    w = torch.cat([w[:, C + Ce:], w[:, C:C + Ce], w[:, :C]], dim=1)
+    b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
+    hid = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                                # [E, 2*H*Hd], sorted slots
+    sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd,
+                                 (a.output_dim, Co))
+    alpha = sa.exp()
+    alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction (CGAT.py:219-221)
+    aggr = (sm * alpha).mean(dim=1)                       # [E, Co] in sorted slot order
+    return torch.empty_like(aggr).index_copy(0, plan.dst_perm.long(), aggr)
+
+
+GATConvEdges._message_fast = _gatconvedges_message_fast
 
 
 class _RowPlan:

@@ -456,13 +456,20 @@ class LinearFn(torch.autograd.Function):
         return g_x, (None if g_w is None else g_w.reshape(ctx.wshape)), g_b, None
 
 
+def _cos(Co, n):
+    """Output width per network: one int for all, or one per network (scalar attention: 1 for MH_A, C for MH_M)."""
+    return tuple(Co) if isinstance(Co, (tuple, list)) else (Co,) * n
+
+
 def _heads_forward(hid, nets, H, Hd, Co):
     """nets: list of (weight [H*Co, Hd], bias [H*Co] or None); network i reads columns [i*H*Hd, (i+1)*H*Hd) of hid."""
     E, W2 = hid.shape
-    outs = [torch.empty(E, H * Co, dtype=torch.float32, device=hid.device) for _ in nets]
-    ws = workspace(lib.cgat_linear_forward_workspace_bytes(E, Hd, Co), hid.device)
+    cos = _cos(Co, len(nets))
+    outs = [torch.empty(E, H * co, dtype=torch.float32, device=hid.device) for co in cos]
+    ws = workspace(max(lib.cgat_linear_forward_workspace_bytes(E, Hd, co) for co in cos), hid.device)
     with torch.cuda.device(hid.device):
         for net, (w, b) in enumerate(nets):
+            Co = cos[net]
             for h in range(H):
                 xs = hid[:, (net * H + h) * Hd:(net * H + h + 1) * Hd]
                 check(lib.cgat_linear_forward(_ptr(xs), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
@@ -475,13 +482,15 @@ def _heads_forward(hid, nets, H, Hd, Co):
 def _heads_backward(hid, weights, has_b, grads, H, Hd, Co, need_hid):
     E, W2 = hid.shape
     dev = hid.device
-    gs = [_f32c(g.reshape(E, H * Co)) for g in grads]
+    cos = _cos(Co, len(weights))
+    gs = [_f32c(g.reshape(E, H * co)) for g, co in zip(grads, cos)]
     g_hid = torch.empty_like(hid) if need_hid else None
-    g_w = [torch.empty(H * Co, Hd, dtype=torch.float32, device=dev) for _ in weights]
-    g_b = [torch.empty(H * Co, dtype=torch.float32, device=dev) if hb else None for hb in has_b]
-    ws = workspace(lib.cgat_linear_backward_workspace_bytes(E, Hd, Co), dev)
+    g_w = [torch.empty(H * co, Hd, dtype=torch.float32, device=dev) for co in cos]
+    g_b = [torch.empty(H * co, dtype=torch.float32, device=dev) if hb else None for hb, co in zip(has_b, cos)]
+    ws = workspace(max(lib.cgat_linear_backward_workspace_bytes(E, Hd, co) for co in cos), dev)
     with torch.cuda.device(dev):
         for net, w in enumerate(weights):
+            Co = cos[net]
             for h in range(H):
                 col = (net * H + h) * Hd
                 check(lib.cgat_linear_backward(_ptr(hid[:, col:col + Hd]), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd, None, Co,
@@ -506,14 +515,15 @@ class HeadsLinearFn(torch.autograd.Function):
         _require_gpu(hid, wa, wm)
         hid = _f32c(hid)
         E = hid.shape[0]
-        ws_ = [_f32c(w.detach().reshape(H * Co, Hd)) for w in (wa, wm)]
+        cos = _cos(Co, 2)                   # (Co may be a pair: scalar attention's MH_A emits one logit per head)
+        ws_ = [_f32c(w.detach().reshape(H * co, Hd)) for w, co in zip((wa, wm), cos)]
         bs_ = [None if b is None else _f32c(b.detach()) for b in (ba, bm)]
-        outs = _heads_forward(hid, list(zip(ws_, bs_)), H, Hd, Co)
-        ctx.dims = (H, Hd, Co)
+        outs = _heads_forward(hid, list(zip(ws_, bs_)), H, Hd, cos)
+        ctx.dims = (H, Hd, cos)
         ctx.shapes = (wa.shape, wm.shape)
         ctx.has_b = (ba is not None, bm is not None)
         ctx.save_for_backward(hid, ws_[0], ws_[1])
-        return outs[0].reshape(E, H, Co), outs[1].reshape(E, H, Co)
+        return outs[0].reshape(E, H, cos[0]), outs[1].reshape(E, H, cos[1])
 
     @staticmethod
     def backward(ctx, g_a, g_m):
