@@ -31,6 +31,11 @@ C_FEA, HEADS, K_NBR, ATOMS = 128, 3, 12, 20
 GRAPHS = 4167                       # -> E = 1 000 080
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense f32-input matrix peak (= vector peak)
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak
+# CGAT_DIST_FORCE=1: the gradient all-reduce path (GradientAverager over a ONE-RANK RCCL communicator) also at N = 1, e.g.
+#   CGAT_DIST_FORCE=1 python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 bench.py --gpus 1
+# -- the step then contains what every rank of an N > 1 run does besides its own layer step (bucket views, hooks,
+# asynchronous all-reduces, used-bitmap reduction); reported as "allreduce" in the line.
+FORCE_ALLREDUCE = os.environ.get("CGAT_DIST_FORCE") == "1"
 
 
 def make_inputs(graphs, seed, device, K=K_NBR):
@@ -73,27 +78,27 @@ def cpu_baseline():
     """The oracle (op-for-op restatement of the reference's CPU path: cat -> head repeat -> grouped
     Conv1d -> LeakyReLU -> conv -> segment softmax -> scatter-add -> Linear(C -> C*C+C) hypernet ->
     bmm -> LayerNorm -> tanh) timed on this box's host cores as BASELINE.md §3 specifies: BASELINE config 1 run
-    whole (1000 crystals, E = 240 000, one layer forward, no_grad) and the metric's fwd+bwd at two sizes of the same
-    synthetic workload (E = 24 000 and 60 000; the 1M-edge batch needs ~240 GB of host memory for the reference's
-    materialised hypernetwork weights) with the linearity of the per-edge cost checked between them.  `value` is the
-    fwd+bwd rate at the larger size."""
+    whole (1000 crystals, E = 240 000, one layer forward, no_grad) and the metric's fwd+bwd at E = 60 000 and
+    E = 240 000 of the same synthetic workload (the 1M-edge batch needs ~240 GB of host memory for the reference's
+    materialised hypernetwork weights; 240 000 edges need ~15 GB), 3 repetitions each, median, with the linearity of the
+    per-edge cost checked between the two sizes.  `value` is the fwd+bwd rate at the larger size."""
     from oracle import cgat_oracle as O
     torch.manual_seed(1)
     layer = O.GATConvNodes(C_FEA, C_FEA, C_FEA, HEADS, concat=True)
-    t24, e24 = _cpu_layer_time(layer, 100, True, reps=2, warm=1)
-    t60, e60 = _cpu_layer_time(layer, 250, True, reps=2, warm=0)
+    t60, e60 = _cpu_layer_time(layer, 250, True, reps=3, warm=1)
+    t240, e240 = _cpu_layer_time(layer, 1000, True, reps=3, warm=0)
     tf, ef = _cpu_layer_time(layer, 1000, False, reps=1, warm=0)
-    r24, r60 = e24 / t24, e60 / t60
-    return {"value": r60, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+    r60, r240 = e60 / t60, e240 / t240
+    return {"value": r240, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
             "config1_fwd": {"edges": ef, "seconds": round(tf, 3), "edges_per_s": round(ef / tf, 1),
                             "what": "BASELINE configs[0]: 1000 crystals, one layer forward, no_grad, run whole"},
-            "fwdbwd_24k": {"edges": e24, "seconds": round(t24, 3), "edges_per_s": round(r24, 1)},
             "fwdbwd_60k": {"edges": e60, "seconds": round(t60, 3), "edges_per_s": round(r60, 1)},
-            "linearity": {"per_edge_cost_ratio_60k_over_24k": round((t60 / e60) / (t24 / e24), 3),
+            "fwdbwd_240k": {"edges": e240, "seconds": round(t240, 3), "edges_per_s": round(r240, 1)},
+            "linearity": {"per_edge_cost_ratio_240k_over_60k": round((t240 / e240) / (t60 / e60), 3),
                           "what": "1.0 = the per-edge cost does not depend on the batch size, i.e. the rate measured "
-                                  "at 60 000 edges extrapolates to the 1M-edge batch"},
-            "sample": f"oracle layer fwd+bwd on {e24} and {e60} edges (median of 2), forward on {ef} edges (1 pass), "
-                      "fp32, all host threads; run BEFORE the GPU leg"}
+                                  "at 240 000 edges extrapolates to the 1M-edge batch"},
+            "sample": f"oracle layer fwd+bwd on {e60} edges (median of 3 after 1 warm-up) and on {e240} edges (median of "
+                      f"3), forward on {ef} edges (1 pass), fp32, all host threads; run BEFORE the GPU leg"}
 
 
 def cpu_baseline_collate(data, emb, n_graphs, reps=5):
@@ -329,7 +334,7 @@ def bench_train(args, rank, world, device):
     ds = P.PackedDataset.from_dict(data, emb, max_neighbor_number=K_NBR, device=device)
     torch.manual_seed(1)                                   # identical replicas
     net = P.CGAtNet(200, C_FEA, 4, msg_heads=HEADS, neighbor_number=K_NBR, update_edges=True).to(device)
-    tr = DataParallelTrainer(net, ds, lr=1e-4, weight_decay=1e-6, rank=rank, world=world)
+    tr = DataParallelTrainer(net, ds, lr=1e-4, weight_decay=1e-6, rank=rank, world=world, force_averager=FORCE_ALLREDUCE)
     ops.set_validate_indices(False)                        # the collation kernel is the only producer of the indices
     rs = np.random.RandomState(rank)
     batches = [rs.permutation(n_data)[:per_rank] for _ in range(args.warmup + args.steps)]
@@ -363,10 +368,24 @@ def bench_train(args, rank, world, device):
                           "edges_per_step_all_ranks": edges / args.steps,
                           "parallelism": f"dp{world} (graphs sharded, bucketed gradient all-reduce overlapped with backward)"},
                "roofline": None}
+        if tr.averager is not None:
+            out["allreduce"] = _allreduce_report(tr.averager, args.warmup + args.steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _allreduce_report(avg, n_steps):
+    import torch.distributed as dist
+    st = avg.stats
+    return {"backend": dist.get_backend(), "world": avg.world, "buckets": len(avg.buckets), "hot_buckets": avg.n_hot,
+            "launched_from_hooks_per_step": round(st["launched_in_backward"] / n_steps, 2),
+            "launched_in_finish_per_step": round(st["launched_in_finish"] / n_steps, 2),
+            "cold_buckets_skipped_per_step": round(st["cold_skipped"] / n_steps, 2),
+            "MB_reduced_per_step": round(st["bytes_reduced"] / n_steps / 1e6, 1),
+            "what": "cgat_amd.dist.GradientAverager: gradients live in the buckets, hot buckets are all-reduced from the "
+                    "autograd hooks while backward is running, parameters unused on every rank are cold (not reduced)"}
 
 
 def _fence(world):
@@ -397,7 +416,7 @@ def make_layer_workload(graphs, rank, world, device, K=K_NBR):
     params = list(layer.parameters())
     ei, x, e, x0, cot = make_inputs(graphs, rank, device, K)  # each rank: its own crystals
     x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
-    averager = GradientAverager(params) if world > 1 else None
+    averager = GradientAverager(params, force=FORCE_ALLREDUCE) if (world > 1 or FORCE_ALLREDUCE) else None
 
     def step():
         if averager is not None:
@@ -410,6 +429,7 @@ def make_layer_workload(graphs, rank, world, device, K=K_NBR):
         y.backward(cot)
         if averager is not None:
             averager.finish()
+    step.averager = averager
     return step, x.shape[0], ei.shape[1]
 
 
@@ -423,7 +443,7 @@ def make_stack_workload(graphs, rank, world, device):
     b, roost = P.synthetic_batch(graphs, ATOMS, K_NBR, seed=rank)
     b = b.to(device)
     roost = tuple(t.to(device) for t in roost)
-    averager = GradientAverager(params) if world > 1 else None
+    averager = GradientAverager(params, force=FORCE_ALLREDUCE) if (world > 1 or FORCE_ALLREDUCE) else None
 
     def step():
         if averager is not None:
@@ -525,10 +545,26 @@ def main():
     else:
         step, N, E = make_stack_workload(args.graphs, rank, world, device)
     layer_like = args.workload in ("layer", "stress")
+    step_averager = getattr(step, "averager", None)
 
     for _ in range(args.warmup):
         step()
     _fence(world)
+    # The CSR plan of the batch is built once per edge_index and cached (every layer of a stack, forward and backward,
+    # shares it), so the timed steps below do not contain it; what one build costs -- kernels plus the two host
+    # synchronisations of the index validation -- is reported beside ms_per_step.
+    plan_build_ms = None
+    if layer_like and not stress:
+        ei_probe = make_inputs(args.graphs, rank, device, K_used)[0]
+        reps = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ops.EdgePlan(ei_probe, N)
+            torch.cuda.synchronize()
+            reps.append(1e3 * (time.perf_counter() - t0))
+        plan_build_ms = round(sorted(reps[1:])[1], 3)
+        del ei_probe
     ops.prof_reset()
     ops.prof_enable(True)                                  # HIP events around the kernel launches, on their stream
     t0 = time.perf_counter()
@@ -537,6 +573,7 @@ def main():
     _fence(world)
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
+    ar_report = _allreduce_report(step_averager, args.warmup + args.steps) if step_averager is not None else None
     ALL_TAGS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
                 "edge_gw", "edge_gj", "rows_ge", "rows_gw", "linear128", "mlp_chain", "rows_dw", "gemm_f32")
     prof = {t: ops.prof_get(t) for t in ALL_TAGS}          # (launches, total ms) inside the timed region
@@ -608,8 +645,13 @@ def main():
                     f"accumulate (measured fp32-equivalent accuracy): executed MFMA flop = {passes} x algorithmic, so the "
                     f"roof for ALGORITHMIC flop is the dense bf16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / {passes}; the "
                     f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
+        # NOT measured in this run: HBM bytes per launch and matrix-core busy cycles come from separate rocprofv3 --pmc
+        # passes of this same command, collected by the builder and committed under profiles/; the line says so
         traffic_file = os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json")
         traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        traffic_src = ("profiles/pmc_contraction_kernels.json @ " + str(traffic.get("collected_at_commit", "unknown commit")) +
+                       " (builder-collected rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, replayed here; "
+                       "not measured in this run)") if traffic else None
         per_kernel, roof = {}, None
         for tag, kname in kernels.items():
             n_t, ms_t = prof[tag]
@@ -623,6 +665,7 @@ def main():
                                # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
                                # per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
                                "traffic": traffic.get(kname, {}).get("hbm_bytes_per_launch"),
+                               "traffic_source": traffic_src,
                                "launches_per_step": n_t / args.steps, "avg_launch_ms": round(avg_ms, 4),
                                "ms_per_step": round(ms_t / args.steps, 3), "flops_per_launch": fl}
         for tag in per_kernel:
@@ -646,7 +689,10 @@ def main():
                                                  for t, v in per_kernel.items() if t != dom}
             counters_file = os.path.join(ROOT, "profiles", "mfma_counters.json")
             if os.path.exists(counters_file):              # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x clock x time)
-                roof["mfma_utilisation_from_counters"] = json.load(open(counters_file))
+                cnt = json.load(open(counters_file))
+                cnt["source"] = ("profiles/mfma_counters.json @ " + str(cnt.get("collected_at_commit", "unknown commit")) +
+                                 " (builder-collected rocprofv3 --pmc pass, replayed here; not measured in this run)")
+                roof["mfma_utilisation_from_counters"] = cnt
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
         W2b = 2 * HEADS * 256 * (2 if args.edge_storage == "bf16" else 4)
@@ -724,7 +770,8 @@ def main():
         out = {
             "metric": metric,
             "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms, "plan_build_ms": plan_build_ms,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype + ("; Z / gZ of the edge phase stored as bf16 (tolerance 1e-2)"
                                                    if args.edge_storage == "bf16" else ""),
             "data": "synthetic", "bilinear_mode": mode, "edge_storage": args.edge_storage,
@@ -761,8 +808,10 @@ def main():
                                                    "on the same 1M-edge batch, default arithmetic mode (3 steps after 1 warm-up)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if ar_report is not None:
+            out["allreduce"] = ar_report
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -105,6 +105,7 @@ PROTOTYPES = {
                                                C.c_size_t, vp]),
     "cgat_nodes_attention_backward": (C.c_int, [C.POINTER(Plan), C.POINTER(AttnParams), vp, vp, vp, vp, vp, vp,
                                                 C.POINTER(AttnGrads), vp, C.c_size_t, vp]),
+    "cgat_debug_nodes_attention_signs": (C.c_int, [C.POINTER(Plan), C.POINTER(AttnParams), vp, vp, vp]),
     "cgat_hnet_saved_floats": (C.c_size_t, [C.c_int32, C.POINTER(HnetParams)]),
     "cgat_hnet_forward_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(HnetParams)]),
     "cgat_hnet_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(HnetParams)]),

@@ -916,6 +916,32 @@ extern "C" int cgat_nodes_attention_forward(const cgat_plan* plan, const cgat_at
     return attn_forward_impl(c, plan, p, x, edge_attr, aggr, saved);
   }
 }
+// ---- debug: the sign pattern of the saved pre-activations in original edge order (include/cgat_hip.h) ----
+__global__ void attn_signs_kernel(const float* __restrict__ Z, const int* __restrict__ perm, long E, int W2,
+                                  uint8_t* __restrict__ mask) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * W2) return;
+  const long t = i / W2;
+  const int c = (int)(i - t * W2);
+  mask[(long)perm[t] * W2 + c] = Z[i] > 0.f ? 1 : 0;
+}
+extern "C" int cgat_debug_nodes_attention_signs(const cgat_plan* plan, const cgat_attn_params* p, const float* saved,
+                                                uint8_t* mask, void* stream) {
+  CGAT_TRY(attn_check(plan, p));
+  CGAT_CHECK_ARG(saved && mask, "debug_nodes_attention_signs: null pointer");
+  const AttnDims d = attn_dims(plan, p);
+  if (attn_bf16(d)) {
+    cgat_set_error("debug_nodes_attention_signs: fp32 edge storage only");
+    return CGAT_ERR_UNSUPPORTED;
+  }
+  const long n = (long)d.E * d.W2;
+  if (n == 0) return CGAT_OK;
+  hipLaunchKernelGGL(attn_signs_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, saved,
+                     plan->dst_perm, (long)d.E, d.W2, mask);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 extern "C" int cgat_nodes_attention_backward(const cgat_plan* plan, const cgat_attn_params* p, const float* x,
                                              const float* edge_attr, const float* saved, const float* g_aggr,
                                              float* g_x, float* g_edge_attr, const cgat_attn_grads* g, void* ws,

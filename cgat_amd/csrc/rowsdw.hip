@@ -269,8 +269,15 @@ static int dw_batch_splits(int n_items, int rows) {
   if (sp > most) sp = most;
   return sp < 1 ? 1 : sp;
 }
+// Slab space for a batch of AT MOST n_items items: a caller that reserves for its full item list and then batches fewer
+// (an operand off the 16-byte grid takes the per-layer launch instead) gets more splits per item -- n * (256 / n) is not
+// monotonic in n (24 items: 240 units, 23 items: 253) -- so the reservation covers every count up to n_items.
 size_t rows_dw128_batch_ws_bytes(int n_items, int rows) {
-  return ws_round((size_t)n_items * dw_batch_splits(n_items, rows) * (16384 + 128), 4);
+  if (n_items < 1) n_items = 1;
+  const long most = cdiv(rows > 0 ? rows : 1, 64);
+  long units = n_items > 256 ? n_items : 256;
+  if (units > (long)n_items * most) units = (long)n_items * most;
+  return ws_round((size_t)units * (16384 + 128), 4);
 }
 bool rows_dw128_batch_fast(const DwBatchDesc& d) {
   if (d.n < 1 || d.n > DW_BATCH_MAX || d.rows < 1) return false;
@@ -284,13 +291,17 @@ int rows_dw128_batch_launch(DwBatchDesc d, void* ws, size_t ws_bytes, hipStream_
     cgat_set_error("rows_dw128_batch: not the fast shape (n = %d, rows = %d)", d.n, d.rows);
     return CGAT_ERR_UNSUPPORTED;
   }
-  const size_t need = rows_dw128_batch_ws_bytes(d.n, d.rows);
+  const size_t need = ws_round((size_t)d.n * dw_batch_splits(d.n, d.rows) * (16384 + 128), 4);   // what THIS batch uses
   if (!ws || ws_bytes < need) {
     cgat_set_error("rows_dw128_batch: workspace too small (%zu < %zu)", ws_bytes, need);
     return CGAT_ERR_WORKSPACE;
   }
   d.splits = dw_batch_splits(d.n, d.rows);
   d.rows_per_unit = cdiv(cdiv(d.rows, d.splits), 16) * 16;   // whole 16-row double batches
+  // rounding the unit up to 16 rows can leave trailing units that start past the last row (rows = 650, n = 24: unit 9
+  // would start at row 720); the kernel's clamped prologue loads would then read past the operands.  Only units that
+  // own a row are launched (never more than the bound above, so the workspace check stands).
+  d.splits = cdiv(d.rows, d.rows_per_unit);
   const size_t lds = (16384 + 128) * sizeof(float);
   {
     CGAT_PROF("rows_dw", stream);

@@ -287,7 +287,7 @@ int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, c
 //   * Roost's WeightedAttention (roost_message.py:305-317: aF = 1, fw = C, mult = weights ** pow, eps = 1e-13).
 // Forward keeps per (segment, logit column) the maximum and 1 / (sum + eps) instead of alpha[rows, aF]; backward
 // recomputes alpha from them:  g_m = alpha * g_out,  g_a[r, c] = sum_{f in c} alpha * g_out * (m - out),
-// g_mult[r] = g_a[r, 0] / mult[r]  (aF == 1).  One workgroup per segment, four consecutive features per thread, rows
+// g_mult[r] = e inv sum_f g_out (m - out) (aF == 1; also where mult[r] == 0).  One workgroup per segment, four consecutive features per thread, rows
 // in CSR order (row r of the segment is ridx[r] of the operands when ridx is given, so callers whose rows are not
 // grouped pass the plan's permutation instead of gathering), U of them in flight; no atomics, fixed summation order.
 // ---------------------------------------------------------------------------------------
@@ -403,9 +403,17 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
       } else {
         float p = live ? (t.x + t.y) + (t.z + t.w) : 0.f;
         for (int o = grp >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        // d out / d mult[r] = e inv sum_f g_out (m - out): from the UN-multiplied softmax term, so that a zero weight
+        // (whose row contributes nothing to out) still gets its -- in general non-zero -- gradient
+        float q = 0.f;
+        if (g_mult) {                                    // kernel argument: uniform branch
+          const float e0 = expf(av.x - mx.x) * inv.x;
+          q = live ? e0 * ((go.x * (mv.x - o4.x) + go.y * (mv.y - o4.y)) + (go.z * (mv.z - o4.z) + go.w * (mv.w - o4.w))) : 0.f;
+          for (int o = grp >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        }
         if (live && (threadIdx.x & (grp - 1)) == 0) {
           g_a[r * aF + ac] = p;
-          if (g_mult) g_mult[r] = w != 0.f ? p / w : 0.f;
+          if (g_mult) g_mult[r] = q;
         }
       }
     }

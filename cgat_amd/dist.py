@@ -25,8 +25,10 @@ def init_from_env(backend=None):
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("CGAT_DIST_FORCE") == "1"                  # a one-rank communicator (RCCL on a 1-GPU box)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world)
     return rank, world, device
 
@@ -50,54 +52,94 @@ class GradientAverager:
     * Buckets are filled in reverse registration order (~ the order backward produces them) and
       launched strictly in bucket order -- bucket i waits for bucket i-1 -- so every rank issues
       the same sequence of collectives whatever order its autograd engine ran in.
+    * Parameters that received no gradient on ANY rank in the last step (the reference's
+      never-trained Edge.MH_A / Edge.MH_M, SURVEY §5: 2.7-5.5 MB in every 64-MB bucket of the
+      shipped network) are COLD: they do not gate a bucket.  The globally all-reduced used-bitmap
+      of a step -- identical on every rank -- decides the layout of the next one: hot parameters
+      fill the leading buckets, which launch from the hooks while backward is still running;
+      cold ones sit in trailing buckets that are reduced in `finish()` only if the bitmap shows
+      that some rank used one of them after all (it is hot again from the next step on), and
+      cost nothing otherwise.  The first step has no history: every parameter is hot and the
+      buckets holding never-used ones launch in `finish()`.
     * Gradient accumulation: inside `with averager.no_sync():` backward only accumulates; the
       backward outside it reduces the sum of all micro-batches (as DDP.no_sync).
-    * Parameters that received no gradient on ANY rank since the last `finish()` (the reference's
-      never-trained Edge.MH_A / Edge.MH_M) end with `p.grad = None`, so optimisers
-      skip them on every rank alike; one that was used on some rank gets the mean on all of them
-      (zeros contributed where it was unused) -- DDP's find_unused_parameters, with the same
-      used-bitmap all-reduce."""
+    * A parameter without gradient on ANY rank since the last `finish()` ends with
+      `p.grad = None`, so optimisers skip it on every rank alike; one that was used on some rank
+      gets the mean on all of them (zeros contributed where it was unused) -- DDP's
+      find_unused_parameters, with the same used-bitmap all-reduce.
+    * `force=True` keeps all of this alive at world size 1 (a one-rank communicator): the mean is
+      then the identity, and the hooks, the asynchronous collectives and their interplay with the
+      layer's side stream can be exercised over RCCL on a single GPU (tests/test_rccl_one_rank.py).
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+    `stats` after each `finish()`: buckets launched from the hooks (i.e. overlapped with backward)
+    and in finish(), cold buckets reduced / skipped, bytes reduced."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = []
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):
+        self.active = (self.world > 1 or bool(force)) and dist.is_initialized()
+        self.bucket_bytes = int(bucket_bytes)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._cold = frozenset()
+        self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "cold_reduced": 0, "cold_skipped": 0,
+                      "bytes_reduced": 0, "rebuilds": 0}
+        self._layout(preserve=False)
+        self._sync = True
+        self._handles = []
+        self._reset()
+        if self.active:
+            for p in self.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- bucket layout --------------------------------------------------------------------
+    def _pack(self, idxs):
+        """Consecutive parameters of one dtype/device into buckets of <= bucket_bytes."""
+        buckets, cur, cur_bytes = [], [], 0
+        for i in idxs:
+            p = self.params[i]
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self.buckets.append(cur)
+            if cur and (cur_bytes + nb > self.bucket_bytes or p.dtype != self.params[cur[0]].dtype or
+                        p.device != self.params[cur[0]].device):
+                buckets.append(cur)
                 cur, cur_bytes = [], 0
-            cur.append(p)
+            cur.append(i)
             cur_bytes += nb
         if cur:
-            self.buckets.append(cur)
-        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device)
-                     for b in self.buckets]
-        self._view, self._bucket_of, self._index = {}, {}, {}
+            buckets.append(cur)
+        return buckets
+
+    def _layout(self, preserve):
+        """(Re)build the buckets: hot parameters in reverse registration order first, then the cold ones.  With
+        `preserve` the gradients held by the old views move to the new ones."""
+        order = list(range(len(self.params) - 1, -1, -1))
+        hot = self._pack([i for i in order if i not in self._cold])
+        cold = self._pack([i for i in order if i in self._cold])
+        idx_buckets = hot + cold
+        self.n_hot = len(hot)
+        old_view = getattr(self, "_view", None)
+        self.buckets = [[self.params[i] for i in b] for b in idx_buckets]
+        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device) for b in self.buckets]
+        self._view, self._bucket_of = {}, {}
         for bi, b in enumerate(self.buckets):
             off = 0
             for p in b:
                 self._view[id(p)] = self.flat[bi][off:off + p.numel()].view_as(p)
                 self._bucket_of[id(p)] = bi
                 off += p.numel()
-        for i, p in enumerate(self.params):
-            self._index[id(p)] = i
-        self._sync = True
-        self._handles = []
-        self._reset()
-        self._stale = [True] * len(self.params)        # the view holds last step's mean, not this step's sum
-        if self.world > 1:
+        if preserve and old_view is not None:
             for p in self.params:
-                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                if p.grad is not None and p.grad.data_ptr() == old_view[id(p)].data_ptr():
+                    self._view[id(p)].copy_(p.grad)
+                    p.grad = self._view[id(p)]
 
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
         self._works = [None] * len(self.buckets)
         self._next = 0                                 # buckets [0, _next) have been launched
         self._used = [0] * len(self.params)
-        self._stale = [True] * len(self.params)
+        self._stale = [True] * len(self.params)        # the view holds last step's mean, not this step's sum
+        self._in_finish = False
 
     # -- public ---------------------------------------------------------------------------
     def zero_grad(self):
@@ -120,22 +162,38 @@ class GradientAverager:
 
     def finish(self):
         """Call after the (last) backward().  Leaves the mean gradients in p.grad."""
-        if self.world == 1:
+        if not self.active:
             return
+        self._in_finish = True
         for i, p in enumerate(self.params):            # never reached by autograd in this step
             if not self._used[i]:
                 self._adopt(i, p, arrived=False)
-        while self._next < len(self.buckets):          # buckets some parameter of which never got a gradient
+        while self._next < self.n_hot:                 # hot buckets some parameter of which never got a gradient
             self._launch(self._next)
         dev = self.flat[0].device if self.flat else torch.device("cpu")
         used = torch.tensor(self._used, dtype=torch.int32, device=dev)
         dist.all_reduce(used, op=dist.ReduceOp.SUM, group=self.group)
         used = used.tolist()
+        # cold buckets: reduced only if the (global, hence rank-independent) bitmap shows one of their parameters in use
+        for bi in range(self.n_hot, len(self.buckets)):
+            if any(used[self._index[id(p)]] for p in self.buckets[bi]):
+                self._launch(bi)
+                self.stats["cold_reduced"] += 1
+            else:
+                self.stats["cold_skipped"] += 1
+        inv = 1.0 / self.world
         for bi in range(len(self.buckets)):
-            self._works[bi].wait()
-            self.flat[bi].mul_(1.0 / self.world)
+            if self._works[bi] is not None:
+                self._works[bi].wait()
+                if inv != 1.0:
+                    self.flat[bi].mul_(inv)
         for i, p in enumerate(self.params):
             p.grad = self._view[id(p)] if used[i] else None
+        cold = frozenset(i for i in range(len(self.params)) if not used[i])
+        if cold != self._cold:                         # same decision on every rank: the bitmap is global
+            self._cold = cold
+            self._layout(preserve=True)
+            self.stats["rebuilds"] += 1
         self._reset()
 
     def close(self):
@@ -166,7 +224,10 @@ class GradientAverager:
 
     def _launch(self, bi):
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._next = bi + 1
+        if bi < self.n_hot:
+            self._next = bi + 1
+        self.stats["launched_in_finish" if self._in_finish else "launched_in_backward"] += 1
+        self.stats["bytes_reduced"] += self.flat[bi].numel() * self.flat[bi].element_size()
 
     def _on_grad(self, p):
         i = self._index[id(p)]
@@ -176,6 +237,6 @@ class GradientAverager:
             return
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
-        # strictly in bucket order: the same sequence of collectives on every rank
-        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+        # strictly in bucket order: the same sequence of collectives on every rank (cold buckets wait for finish())
+        while self._next < self.n_hot and self._pending[self._next] <= 0:
             self._launch(self._next)

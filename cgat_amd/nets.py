@@ -14,7 +14,7 @@ import itertools
 import torch
 import torch.nn as nn
 
-from . import _lib, chunked
+from . import _lib, chunked, debug
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
 from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
@@ -145,6 +145,8 @@ def _gatconvedges_message_fast(self, x, edge_attr, plan):
     w = torch.cat([w[:, C + Ce:], w[:, C:C + Ce], w[:, :C]], dim=1)
     b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
     hid = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                                # [E, 2*H*Hd], sorted slots
+    if debug.recording():
+        debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
     sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd,
                                  (a.output_dim, Co))
     alpha = sa.exp()
@@ -213,6 +215,8 @@ class GATConvNodes(nn.Module):
         b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
         hid = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                             # [E, 2*H*Hd], sorted slots
         E = hid.shape[0]
+        if debug.recording():
+            debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
 
         # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
         sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co)

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, debug
 from ._lib import lib, check
 
 
@@ -106,6 +106,11 @@ def get_plan(edge_index, num_nodes):
     """Small LRU keyed by the edge_index storage: every layer of a stack (and its backward)
     reuses the same plan."""
     key = (edge_index.data_ptr(), tuple(edge_index.shape), int(num_nodes), edge_index._version, edge_index.device.index)
+    # a long-lived edge_index object carries its plan itself (the closed chunks of chunked.py: 8+ chunk tensors per 64 M
+    # edges would evict each other from the 8-entry LRU and rebuild -- and re-validate, two host syncs -- their plan in
+    # every forward, recomputation and backward)
+    if hasattr(edge_index, "_cgat_plan"):                 # marked by its owner (chunked.closed_chunks): built on first use
+        return attach_plan(edge_index, num_nodes)
     plan = _plan_cache.get(key)
     if plan is None:
         if len(_plan_cache) >= 8:
@@ -114,6 +119,15 @@ def get_plan(edge_index, num_nodes):
         plan._keepalive = edge_index
         _plan_cache[key] = plan
     return plan
+
+
+def attach_plan(edge_index, num_nodes):
+    """Build (and validate) the plan of `edge_index` once and keep it on the tensor object itself."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), int(num_nodes), edge_index._version, edge_index.device.index)
+    own = getattr(edge_index, "_cgat_plan", None)
+    if own is None or own[0] != key:
+        edge_index._cgat_plan = (key, EdgePlan(edge_index, num_nodes))
+    return edge_index._cgat_plan[1]
 
 
 class SegmentPlan:
@@ -175,6 +189,8 @@ class NodesAttentionFn(torch.autograd.Function):
                   "cgat_nodes_attention_forward")
         ctx.plan, ctx.H, ctx.storage = plan, H, lib.cgat_get_edge_storage()
         ctx.save_for_backward(x, edge_attr, saved, *weights)
+        if debug.recording():
+            debug.note_attention(A_in_w, M_in_w, plan, p, saved, 2 * H * Hd)
         return aggr
 
     @staticmethod
@@ -367,6 +383,8 @@ class NodeLayerFn(torch.autograd.Function):
         ctx.plan, ctx.H, ctx.n_fc, ctx.n_hyper, ctx.has_d = plan, H, n_fc, n_hyper, d is not None
         ctx.storage = lib.cgat_get_edge_storage()
         ctx.save_for_backward(x, edge_attr, h0, aggr, saved_a, saved_h, *([d] if d is not None else []), *attn_w, *flat)
+        if debug.recording():
+            debug.note_attention(params[0], params[4], plan, pa, saved_a, 2 * H * Hd)
         return y
 
     @staticmethod
@@ -435,6 +453,8 @@ class LinearFn(torch.autograd.Function):
                                           _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
         ctx.act, ctx.has_b, ctx.wshape = act, b is not None, w.shape
         ctx.save_for_backward(x, w2, y)
+        if act in (_lib.ACT_LEAKY, _lib.ACT_RELU) and debug.recording():
+            debug.note(w, y > 0)
         return y
 
     @staticmethod
@@ -704,7 +724,10 @@ class ChainMLPFn(torch.autograd.Function):
     def forward(ctx, x, resid, act, *wb):
         n = len(wb) // 2
         ws_, bs_ = [_f32c(w.detach()) for w in wb[:n]], [_f32c(b.detach()) for b in wb[n:]]
-        ctx.same = resid is x                            # x + f(x): the backward chain then adds g_out in its last layer
+        # x + f(x): the backward chain then adds g_out in its last layer.  Callers pass two separate reshape() results
+        # of one tensor (SimpleNetwork.forward), so identity is decided on storage, shape and strides
+        ctx.same = resid is not None and (resid is x or (resid.data_ptr() == x.data_ptr() and resid.shape == x.shape and
+                                                         resid.stride() == x.stride() and resid.dtype == x.dtype))
         x = _f32c(x)
         r = None if resid is None else (x if ctx.same else _f32c(resid))
         rows, dev = x.shape[0], x.device
@@ -713,6 +736,9 @@ class ChainMLPFn(torch.autograd.Function):
         layers = [dict(W=ws_[i], bias=bs_[i], act=act, out=hid[i]) for i in range(n - 1)]
         layers.append(dict(W=ws_[-1], bias=bs_[-1], act=_lib.ACT_NONE, resid=r, out=out))
         _run_chain(_chain_desc(rows, x, layers), dev)
+        if act in (_lib.ACT_LEAKY, _lib.ACT_RELU) and debug.recording():
+            for i in range(n - 1):
+                debug.note(wb[i], hid[i] > 0)
         ctx.act, ctx.n, ctx.has_r = act, n, resid is not None
         ctx.save_for_backward(x, *hid, *ws_)
         return out

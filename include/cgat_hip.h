@@ -161,6 +161,15 @@ int cgat_nodes_attention_backward(const cgat_plan* plan, const cgat_attn_params*
                                   float* g_x /* [N,C] */, float* g_edge_attr /* [E,Ce] */, const cgat_attn_grads* g,
                                   void* ws, size_t ws_bytes, void* stream);
 
+/* Debug / parity instrumentation (tests only, not on the hot path): the LeakyReLU derivative pattern the backward of
+ * cgat_nodes_attention_forward will use -- mask[e, c] = (Z[slot(e), c] > 0) for the pre-activations of MH_A (columns
+ * [0, H*Hd)) and MH_M ([H*Hd, 2*H*Hd)) of CGAT/CGAT.py:96,105-108, in ORIGINAL edge order.  LeakyReLU's derivative
+ * jumps at 0 (CGAT.py:95, slope 0.01), so two correct fp32 evaluations can disagree on elements with |z| ~ 1e-7 max|z|
+ * and then differ in every upstream gradient by a finite amount; the parity tests force the oracle's derivative
+ * pattern to THIS one and compare at the flat tolerance.  fp32 edge storage only. */
+int cgat_debug_nodes_attention_signs(const cgat_plan* plan, const cgat_attn_params* p, const float* saved,
+                                     uint8_t* mask /* out [E, 2*H*Hd] */, void* stream);
+
 /* ---- first layer of the message networks alone (vector-attention variants) ---------------
  * hidden[t, :] = LeakyReLU(w_in [x_i ; edge_attr ; x_j] + b_in), t = destination-sorted edge slot (plan.dst_perm),
  * for the stacked first-layer weights w_in [W2, 2C+Ce] of any number of heads / networks: MultiHeadNetwork's

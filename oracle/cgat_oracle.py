@@ -71,12 +71,71 @@ class flip_probe:
         _FLIP_TAU = self.prev
 
 
-def leaky(z):
+# `forced_masks(model, masks)`: the derivative pattern of every LeakyReLU / ReLU is taken from `masks` instead of the
+# sign of the oracle's own pre-activation -- {name of the layer's weight in the state_dict: [bool [rows, units] per
+# call]}, as recorded from the implementation under test (cgat_amd.debug.record_masks).  An element whose recorded
+# side differs from the oracle's own is one of the |z| ~ 1e-7 max|z| cases above: the value moves by <= 0.99 |z|, the
+# derivative becomes the one the other implementation used, and the two gradients are comparable at the flat
+# tolerance.  `stats` counts the elements on which the two sides disagreed.
+_FORCED = None
+
+
+class forced_masks:
+    def __init__(self, model, masks):
+        self.names = {id(p): n for n, p in model.named_parameters()}
+        self.masks = {k: list(v) for k, v in masks.items()}
+        self.stats = {"layers": 0, "elements": 0, "disagree": 0, "max_rel_z": 0.0}
+
+    def __enter__(self):
+        global _FORCED
+        self.prev, _FORCED = _FORCED, self
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED
+        _FORCED = self.prev
+
+    def take(self, weight, z):
+        name = self.names.get(id(weight))
+        if name is None or not self.masks.get(name):
+            return None
+        lst = self.masks[name]
+        if lst[0].numel() != z.numel() and sum(t.numel() for t in lst) == z.numel():
+            m = torch.cat(lst, dim=0)                  # recorded in consecutive row chunks (cgat_amd/chunked.py)
+            del lst[:]
+        else:
+            m = lst.pop(0)
+        m = m.reshape(z.shape)
+        own = z.detach() > 0
+        dis = own != m
+        self.stats["layers"] += 1
+        self.stats["elements"] += m.numel()
+        nd = int(dis.sum())
+        if nd:
+            self.stats["disagree"] += nd
+            self.stats["max_rel_z"] = max(self.stats["max_rel_z"],
+                                          float(z.detach().abs()[dis].max() / z.detach().abs().max()))
+        return m
+
+
+def leaky(z, weight=None):
+    if _FORCED is not None and weight is not None:
+        m = _FORCED.take(weight, z)
+        if m is not None:
+            return torch.where(m, z, 0.01 * z)
     out = F.leaky_relu(z, 0.01)
     if _FLIP_TAU is None:
         return out
     near = z.detach().abs() < _FLIP_TAU * z.detach().abs().max()
     return torch.where(near, torch.where(z > 0, 0.01 * z, z), out)
+
+
+def relu(z, weight=None):
+    if _FORCED is not None and weight is not None:
+        m = _FORCED.take(weight, z)
+        if m is not None:
+            return torch.where(m, z, torch.zeros_like(z))
+    return torch.relu(z)
 
 
 # ----------------------------------------------------------------------------------------
@@ -94,7 +153,7 @@ class SimpleNetwork(nn.Module):
 
     def forward(self, fea):
         for fc in self.fcs:
-            fea = leaky(fc(fea))
+            fea = leaky(fc(fea), fc.weight)
         return self.fc_out(fea)
 
 
@@ -127,7 +186,7 @@ class ResidualNetwork(nn.Module):
 
     def forward(self, fea, *, last_layer=True):
         for k, (fc, res) in enumerate(zip(self.fcs, self.res_fcs)):
-            h = torch.relu(fc(fea))
+            h = relu(fc(fea), fc.weight)
             if self.if_rezero:
                 h = self.rezeros[k](h)
             fea = h + res(fea)
@@ -282,7 +341,7 @@ class MultiHeadNetwork(nn.Module):
 
     def forward(self, fea):
         fea = fea.reshape(-1, self.input_dim, 1).repeat(1, self.nb_heads, 1)      # 105/107
-        fea = leaky(self.fc_in(fea))
+        fea = leaky(self.fc_in(fea), self.fc_in.weight)
         return self.fc_out(fea).view(-1, self.nb_heads, self.output_dim)          # 109
 
 

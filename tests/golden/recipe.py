@@ -349,7 +349,7 @@ def grad_probe(g):
 PROBE_ABOVE = 4096
 
 
-def run_case(case, dtype=torch.float32, device="cpu", want_grads=True):
+def run_case(case, dtype=torch.float32, device="cpu", want_grads=True, ctx=None):
     """Build the module, fill its parameters by recipe, run forward and the backward of
     sum(out * cotangent).  Returns (out, {name: grad or None}) with names `gin.<input>` and
     `gp.<param>`; the module's parameter names must equal the reference's."""
@@ -359,7 +359,11 @@ def run_case(case, dtype=torch.float32, device="cpu", want_grads=True):
     leaves = {k: v for k, v in inputs.items() if torch.is_tensor(v) and v.is_floating_point()}
     for v in leaves.values():
         v.requires_grad_(True)
-    y = case.call(mod, inputs)
+    if ctx is None:
+        y = case.call(mod, inputs)
+    else:
+        with ctx(mod):                 # tests: record / force the activation derivative patterns around the forward
+            y = case.call(mod, inputs)
     if not want_grads:
         return y, {}, mod
     params = dict(mod.named_parameters())

@@ -34,7 +34,11 @@ def maxnorm_rel(a, b):
     return float(np.abs(a - b).max() / den)
 
 
-NOISE_MULT = 16.0
+# Tensors the reference itself cannot resolve to `tol` in fp32 are admitted up to NOISE_MULT times the reference's own
+# fp32-vs-fp64 deviation nf.  The difference of two independent fp32 evaluations is ~sqrt(2) x one evaluation's error in
+# max-norm, and nf is ONE sample of that error, so small multiples are the expected range; 4 (16 until round 3) leaves
+# room for that and nothing else.
+NOISE_MULT = 4.0
 
 
 def check_case(fname, cname, case, *, device="cpu", tol=1e-4, grad_tol=None, report=None):

@@ -120,6 +120,89 @@ def test_two_rank_replicas_identical_after_optimizer_steps():
     assert unused_untouched
 
 
+def _net_worker(rank, world, port, out):
+    """The shipped network structure (update_edges=True, no_hyper=True: Edge.MH_A / Edge.MH_M never receive a gradient,
+    reference CGAT.py:224-225) over two ranks: after the first step those parameters are cold and must not gate a
+    bucket, so buckets launch from the hooks, i.e. while backward is still running."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cgat_amd.dist import GradientAverager, init_from_env, shard_range
+    from cgat_amd.graph import synthetic_batch
+    from oracle import cgat_oracle as O
+    torch.set_num_threads(2)
+    init_from_env("gloo")
+    kw = dict(msg_heads=2, neighbor_number=4, update_edges=True)
+    torch.manual_seed(1)
+    net = O.CGAtNet(200, 16, 2, **kw)
+    late = torch.nn.Parameter(torch.ones(5))              # unused in steps 0-1 (goes cold), used on rank 1 in step 2
+    params = list(net.parameters()) + [late]
+    avg = GradientAverager(params, bucket_bytes=64 << 10)
+    G = 4
+    shards = [synthetic_batch(2, 5, 4, seed=10 + r) for r in range(world)]      # each rank: its own two crystals
+    b, roost = shards[rank]
+    log = []
+    for it in range(5):
+        avg.zero_grad()
+        loss = net(b, roost)[:, 0].sum() * world / G
+        if it == 2 and rank == 1:
+            loss = loss + late.sum() * 4.0
+        before = dict(avg.stats)
+        loss.backward()
+        in_bwd = avg.stats["launched_in_backward"] - before["launched_in_backward"]
+        n_hot, n_buckets = avg.n_hot, len(avg.buckets)
+        avg.finish()
+        log.append(dict(in_backward=in_bwd, in_finish=avg.stats["launched_in_finish"] - before["launched_in_finish"],
+                        cold_reduced=avg.stats["cold_reduced"] - before["cold_reduced"],
+                        cold_skipped=avg.stats["cold_skipped"] - before["cold_skipped"], n_hot=n_hot,
+                        n_buckets=n_buckets, late=None if late.grad is None else float(late.grad[0])))
+    if rank == 0:
+        torch.manual_seed(1)
+        ref = O.CGAtNet(200, 16, 2, **kw)
+        tot = 0.0
+        for bb, rr in shards:
+            tot = tot + ref(bb, rr)[:, 0].sum() / G
+        tot.backward()
+        scale = max(q.grad.abs().max().item() for q in ref.parameters() if q.grad is not None)
+        worst, none_mismatch = 0.0, 0
+        for (name, p), q in zip(net.named_parameters(), ref.parameters()):
+            if (p.grad is None) != (q.grad is None):
+                none_mismatch += 1
+            elif q.grad is not None:
+                worst = max(worst, (p.grad - q.grad).abs().max().item() / max(q.grad.abs().max().item(), 1e-3 * scale))
+        n_unused = sum(1 for q in ref.parameters() if q.grad is None)
+        out.put((worst, none_mismatch, n_unused, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_parameters_do_not_gate_the_buckets():
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_net_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    worst, none_mismatch, n_unused, log = out.get()
+    assert worst <= 2e-5 and none_mismatch == 0, (worst, none_mismatch)
+    assert n_unused >= 16                                  # Edge.MH_A / Edge.MH_M of both layers + the last Edge.Pooling_NN
+    # step 0 has no history: the never-used parameters sit in every bucket and nothing can launch before finish()
+    assert log[0]["in_backward"] == 0 and log[0]["in_finish"] == log[0]["n_buckets"] >= 2
+    # from step 1 on they are cold: every hot bucket launches from the hooks, the cold ones are skipped altogether
+    for it in (1, 4):
+        assert log[it]["in_backward"] == log[it]["n_hot"] >= 2 and log[it]["in_finish"] == 0, log[it]
+        assert log[it]["cold_skipped"] >= 1 and log[it]["cold_reduced"] == 0
+    # step 2: a cold parameter gets a gradient on ONE rank -> its cold bucket is reduced in finish(), mean on both ranks
+    assert log[2]["cold_reduced"] >= 1 and log[2]["late"] == 2.0, log[2]
+    assert log[1]["late"] is None and log[3]["late"] is None
+    # step 3: that parameter is hot (used somewhere in step 2) but unused again: it holds its bucket back until finish()
+    # for this one step and is cold again from step 4 on
+    assert log[3]["in_finish"] >= 1 and log[3]["n_hot"] >= log[1]["n_hot"]
+
+
 def test_shard_range_partitions():
     from cgat_amd.dist import shard_range
     for n in (0, 1, 7, 4167):

@@ -40,7 +40,13 @@ alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           #
        "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 4 + C ** 3 * 4,  # pT, qT, r planes + out
        # the batched f16x3 launch covers the four predicted layers: 4 x (pT, qT, two fp16 planes of r, out)
        "bilinear_wgrad128_f16p_kernel": 4 * (2 * N * C * 4 + N * C * 4 + C ** 3 * 4)}
-out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py "
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = "unknown"
+out = {"collected_at_commit": commit + " (HEAD when the counters were summarised; the build profiled is that tree)",
+       "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py "
                   "--steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
        "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE halves wide coalesced reads)"}
 for k, n, f_kb, w_kb, b in rows:

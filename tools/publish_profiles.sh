@@ -1,27 +1,28 @@
 #!/bin/bash
 # Authoring side: turn one gpurun_out/<dir> written by tools/collect_profiles.sh into the files under profiles/ that
-# DESIGN.md §6 and bench.py cite.   bash tools/publish_profiles.sh gpurun_out/r2final
+# DESIGN.md §6 and bench.py cite.   bash tools/publish_profiles.sh gpurun_out/r3final r03
 set -e
 D=${1:?gpurun_out/<dir>}
+T=${2:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/profiles
-cp $D/bench.json $P/r02_final_bench.json
-cp $(ls $D/stats/*/*_kernel_stats.csv | head -1) $P/r02_final_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do cp $(ls $D/pmc_$c/*/*_counter_collection.csv | head -1) $P/r02_final_pmc_${c}_counter_collection.csv; done
-python3 $R/tools/pmc_summary.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE r02
-COUNTER_JSON=$P/mfma_counters.json python3 $R/tools/counter_summary.py $D/pmc_mfma > $P/r02_final_counters_mfma.txt
+cp $D/bench.json $P/${T}_final_bench.json
+cp $(ls $D/stats/*/*_kernel_stats.csv | head -1) $P/${T}_final_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do cp $(ls $D/pmc_$c/*/*_counter_collection.csv | head -1) $P/${T}_final_pmc_${c}_counter_collection.csv; done
+python3 $R/tools/pmc_summary.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE $T
+COUNTER_JSON=$P/mfma_counters.json python3 $R/tools/counter_summary.py $D/pmc_mfma > $P/${T}_final_counters_mfma.txt
 # the bench line read profiles/mfma_counters.json as it was on the box (the previous collection); attach this one's
 python3 - <<PY
 import json
-b = "$P/r02_final_bench.json"
+b = "$P/${T}_final_bench.json"
 d = json.loads(open(b).read().strip().splitlines()[-1])
 if d.get("roofline"):
     d["roofline"]["mfma_utilisation_from_counters"] = json.load(open("$P/mfma_counters.json"))
 open(b, "w").write(json.dumps(d) + "\n")
 PY
-for w in stress train stack edge_hyper; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
-for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/r02_bench_$w.json; done
-[ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/r02_bench_stress_bf16.json
-cp $(ls $D/stress_stats/*/*_kernel_stats.csv | head -1) $P/r02_stress_kernel_stats.csv
-[ -d $D/stack_stats ] && cp $(ls $D/stack_stats/*/*_kernel_stats.csv | head -1) $P/r02_stack_kernel_stats.csv
-ls -la $P | grep r02_ | wc -l
+for w in stress train stack edge_hyper; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/${T}_bench_$w.json; done
+for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/${T}_bench_$w.json; done
+[ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/${T}_bench_stress_bf16.json
+cp $(ls $D/stress_stats/*/*_kernel_stats.csv | head -1) $P/${T}_stress_kernel_stats.csv
+[ -d $D/stack_stats ] && cp $(ls $D/stack_stats/*/*_kernel_stats.csv | head -1) $P/${T}_stack_kernel_stats.csv
+ls -la $P | grep ${T}_ | wc -l
