@@ -342,12 +342,16 @@ def bench_train(args, rank, world, device):
     for i in range(args.warmup):
         tr.step(batches[i])
     _fence(world)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         _, e = tr.step(batches[args.warmup + i])
+        marks[i + 1].record()
         edges += e
     _fence(world)
     elapsed = time.perf_counter() - t0
+    step_ms = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
     tot = torch.tensor([elapsed, float(edges)], device=device, dtype=torch.float64)
     if world > 1:
         mx = tot.clone()
@@ -359,7 +363,8 @@ def bench_train(args, rank, world, device):
         out = {"metric": "batch-edges/sec through the end-to-end data-parallel training step (collate -> CGAtNet fwd+bwd -> "
                          "gradient all-reduce -> AdamW), DCGAT-shaped synthetic dataset [BASELINE configs[3]]",
                "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+               "ms_per_step": 1e3 * elapsed / args.steps, "step_ms_gpu_events": step_ms,
+               "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
                "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
                "config": {"workload": f"train step: {per_rank} ragged crystals (2..40 atoms, 24 stored / {K_NBR} used nbrs) per "
@@ -416,7 +421,7 @@ def make_layer_workload(graphs, rank, world, device, K=K_NBR):
     params = list(layer.parameters())
     ei, x, e, x0, cot = make_inputs(graphs, rank, device, K)  # each rank: its own crystals
     x.requires_grad_(True); e.requires_grad_(True); x0.requires_grad_(True)
-    averager = GradientAverager(params, force=FORCE_ALLREDUCE) if (world > 1 or FORCE_ALLREDUCE) else None
+    averager = GradientAverager(params, force=FORCE_ALLREDUCE, static_graph=True) if (world > 1 or FORCE_ALLREDUCE) else None
 
     def step():
         if averager is not None:
@@ -443,7 +448,7 @@ def make_stack_workload(graphs, rank, world, device):
     b, roost = P.synthetic_batch(graphs, ATOMS, K_NBR, seed=rank)
     b = b.to(device)
     roost = tuple(t.to(device) for t in roost)
-    averager = GradientAverager(params, force=FORCE_ALLREDUCE) if (world > 1 or FORCE_ALLREDUCE) else None
+    averager = GradientAverager(params, force=FORCE_ALLREDUCE, static_graph=True) if (world > 1 or FORCE_ALLREDUCE) else None
 
     def step():
         if averager is not None:

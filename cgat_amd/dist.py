@@ -67,6 +67,11 @@ class GradientAverager:
       `p.grad = None`, so optimisers skip it on every rank alike; one that was used on some rank
       gets the mean on all of them (zeros contributed where it was unused) -- DDP's
       find_unused_parameters, with the same used-bitmap all-reduce.
+    * `static_graph=True` (as DDP's): once two consecutive steps have produced the same global bitmap the cold set is
+      FROZEN -- `finish()` then issues no bitmap all-reduce and, above all, no host synchronisation (reading the bitmap
+      drains the launch queue: +2.3 ms on the 24.4 ms layer step, measured over a one-rank RCCL communicator); the
+      all-reduces are only stream-ordered.  A cold parameter that receives a gradient after that raises, a hot one
+      that does not contributes zeros and keeps its (zero-mean) gradient instead of None.
     * `force=True` keeps all of this alive at world size 1 (a one-rank communicator): the mean is
       then the identity, and the hooks, the asynchronous collectives and their interplay with the
       layer's side stream can be exercised over RCCL on a single GPU (tests/test_rccl_one_rank.py).
@@ -74,12 +79,13 @@ class GradientAverager:
     `stats` after each `finish()`: buckets launched from the hooks (i.e. overlapped with backward)
     and in finish(), cold buckets reduced / skipped, bytes reduced."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, force=False):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, force=False, static_graph=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = (self.world > 1 or bool(force)) and dist.is_initialized()
         self.bucket_bytes = int(bucket_bytes)
+        self.static_graph, self._frozen = bool(static_graph), False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._cold = frozenset()
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "cold_reduced": 0, "cold_skipped": 0,
@@ -170,6 +176,8 @@ class GradientAverager:
                 self._adopt(i, p, arrived=False)
         while self._next < self.n_hot:                 # hot buckets some parameter of which never got a gradient
             self._launch(self._next)
+        if self._frozen:
+            return self._finish_frozen()
         dev = self.flat[0].device if self.flat else torch.device("cpu")
         used = torch.tensor(self._used, dtype=torch.int32, device=dev)
         dist.all_reduce(used, op=dist.ReduceOp.SUM, group=self.group)
@@ -194,6 +202,25 @@ class GradientAverager:
             self._cold = cold
             self._layout(preserve=True)
             self.stats["rebuilds"] += 1
+        elif self.static_graph:
+            self._frozen = True                        # two steps with the same global bitmap: no more bitmap / host sync
+        self._reset()
+
+    def _finish_frozen(self):
+        """static_graph after the cold set froze: stream-ordered waits only, no collective on the bitmap, no host sync."""
+        for i in self._cold:
+            if self._used[i]:
+                raise RuntimeError("GradientAverager(static_graph=True): a parameter that was unused on every rank when "
+                                   "the graph froze received a gradient; construct the averager with static_graph=False")
+        inv = 1.0 / self.world
+        for bi in range(self.n_hot):
+            self._works[bi].wait()
+            if inv != 1.0:
+                self.flat[bi].mul_(inv)
+        for bi in range(self.n_hot, len(self.buckets)):
+            self.stats["cold_skipped"] += 1
+        for i, p in enumerate(self.params):
+            p.grad = None if i in self._cold else self._view[id(p)]
         self._reset()
 
     def close(self):

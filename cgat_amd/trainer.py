@@ -30,13 +30,15 @@ class Normalizer:
 
 class DataParallelTrainer:
     def __init__(self, model, dataset, lr=1e-3, weight_decay=1e-2, loss="L1", normalizer=None, accumulate_grad_batches=1,
-                 rank=0, world=1, bucket_bytes=64 << 20, force_averager=False):
+                 rank=0, world=1, bucket_bytes=64 << 20, force_averager=False, static_graph=True):
         self.model, self.dataset = model, dataset
         self.rank, self.world = rank, world
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.optimizer = FusedAdamW(self.params, lr=lr, weight_decay=weight_decay)
+        # static_graph: the set of never-used parameters is fixed by the architecture (Edge.MH_A / Edge.MH_M under
+        # no_hyper=True), so the averager may freeze it after two steps and stop synchronising with the host
         # force_averager: the bucketed all-reduce also at world size 1 (a one-rank RCCL communicator; dist.GradientAverager)
-        self.averager = (GradientAverager(self.params, bucket_bytes=bucket_bytes, force=force_averager)
+        self.averager = (GradientAverager(self.params, bucket_bytes=bucket_bytes, force=force_averager, static_graph=static_graph)
                          if (world > 1 or force_averager) else None)
         self.criterion = RobustL1 if loss == "L1" else RobustL2
         self.normalizer = normalizer or Normalizer()

@@ -203,6 +203,67 @@ def test_unused_parameters_do_not_gate_the_buckets():
     assert log[3]["in_finish"] >= 1 and log[3]["n_hot"] >= log[1]["n_hot"]
 
 
+def _static_worker(rank, world, port, out):
+    """static_graph=True: after two steps with the same global bitmap the cold set freezes -- no bitmap all-reduce, no
+    host synchronisation in finish() -- the mean stays right, and a cold parameter that gets a gradient raises."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cgat_amd.dist import GradientAverager, init_from_env
+    torch.set_num_threads(2)
+    init_from_env("gloo")
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(6, 4)
+    dead = torch.nn.Parameter(torch.ones(3))
+    params = list(lin.parameters()) + [dead]
+    avg = GradientAverager(params, bucket_bytes=64, static_graph=True)
+    x = torch.arange(12, dtype=torch.float32).reshape(2, 6) * (rank + 1)
+    frozen, calls = [], []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.dtype)
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    for it in range(4):
+        avg.zero_grad()
+        n0 = sum(1 for d in calls if d == torch.int32)
+        lin(x).sum().backward()
+        avg.finish()
+        frozen.append((avg._frozen, sum(1 for d in calls if d == torch.int32) - n0))
+    want_w = (torch.arange(12, dtype=torch.float32).reshape(2, 6).sum(0) * 1.5).expand(4, 6)   # mean of ranks 1x and 2x
+    ok = bool(torch.allclose(lin.weight.grad, want_w)) and dead.grad is None
+    raised = False
+    avg.zero_grad()
+    try:
+        (lin(x).sum() + dead.sum()).backward()
+        avg.finish()
+    except RuntimeError as ex:
+        raised = "static_graph" in str(ex)
+    if rank == 0:
+        out.put((frozen, ok, raised))
+    dist.all_reduce = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_static_graph_freezes_the_cold_set():
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_static_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    frozen, ok, raised = out.get()
+    # step 0 learns the bitmap, step 1 confirms it (both reduce the int32 bitmap), from step 2 on: frozen, no bitmap
+    assert [f for f, _ in frozen] == [False, True, True, True], frozen
+    assert [n for _, n in frozen] == [1, 1, 0, 0], frozen
+    assert ok and raised
+
+
 def test_shard_range_partitions():
     from cgat_amd.dist import shard_range
     for n in (0, 1, 7, 4167):
