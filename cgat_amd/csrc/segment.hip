@@ -24,6 +24,45 @@ __device__ __forceinline__ float act_f(float v, int act) {
   }
 }
 
+// Segments longer than SEG_LONG rows (a hub atom: 20 000 incoming edges in the test) leave the thread-per-output /
+// workgroup-per-segment kernels below and are handled by the *_long kernels: all threads of a workgroup stride over
+// the rows of ONE segment and combine through wavefront (DPP / shuffle) and LDS reductions in a fixed order, so the
+// results stay bitwise reproducible.  Which segments are long is found on the device (every workgroup of a long
+// kernel scans the row pointers of its share of segments and collects the long ones in LDS): no host round trip, no
+// workspace, nothing to capture around.
+#define SEG_LONG 256
+
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum / max over the 256 threads of a workgroup, result in every thread; `red` = 4 floats of LDS
+__device__ __forceinline__ float block256_sum(float v, float* red) {
+  v = wave_sum64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block256_max(float v, float* red) {
+  v = wave_max64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// the long segments among segments [256 b, 256 b + 256): ids into list[] (LDS), count returned; order irrelevant (each
+// is processed independently)
+__device__ __forceinline__ int collect_long256(const int* __restrict__ rowptr, int S, int* list, int* count) {
+  if (threadIdx.x == 0) *count = 0;
+  __syncthreads();
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < S && rowptr[s + 1] - rowptr[s] > SEG_LONG) list[atomicAdd(count, 1)] = s;
+  __syncthreads();
+  return *count;
+}
+
 // one thread per (segment, feature)
 __global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mult,
                                        const int* __restrict__ rowptr, int S, int F, float eps,
@@ -32,6 +71,7 @@ __global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float*
   if (i >= (long)S * F) return;
   int s = (int)(i / F), f = (int)(i % F);
   int r0 = rowptr[s], r1 = rowptr[s + 1];
+  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_fwd_long_kernel
   float mx = -INFINITY;
   for (int r = r0; r < r1; ++r) mx = fmaxf(mx, a[(long)r * F + f]);
   float z = 0.f;
@@ -52,6 +92,43 @@ __global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float*
   if (ssum) ssum[i] = tot;
 }
 
+__global__ __launch_bounds__(256) void seg_softmax_fwd_long_kernel(const float* __restrict__ a, const float* __restrict__ mult,
+                                                                   const int* __restrict__ rowptr, int S, int F, float eps,
+                                                                   float* __restrict__ alpha, float* __restrict__ ssum) {
+  __shared__ int list[256];
+  __shared__ int count;
+  __shared__ float red[4];
+  const int n = collect_long256(rowptr, S, list, &count);
+  for (int k = 0; k < n; ++k) {
+    const int s = list[k], r0 = rowptr[s], r1 = rowptr[s + 1];
+    for (int f = 0; f < F; ++f) {
+      float mx = -INFINITY;
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) mx = fmaxf(mx, a[(long)r * F + f]);
+      mx = block256_max(mx, red);
+      float z = 0.f;
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        float e = expf(a[(long)r * F + f] - mx);
+        if (mult) e *= mult[r];
+        z += e;
+      }
+      z = block256_sum(z, red);
+      const float inv = 1.f / (z + eps);
+      float tot = 0.f;
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        float e = expf(a[(long)r * F + f] - mx);
+        if (mult) e *= mult[r];
+        const float al = e * inv;
+        alpha[(long)r * F + f] = al;
+        tot += al;
+      }
+      if (ssum) {                                  // (uniform: kernel argument)
+        tot = block256_sum(tot, red);
+        if (threadIdx.x == 0) ssum[(long)s * F + f] = tot;
+      }
+    }
+  }
+}
+
 // ga = alpha * (g - sum_seg alpha*g),  g = galpha + gssum[seg];   gmult = ga / mult  (F == 1 only)
 __global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
                                        const float* __restrict__ gssum, const float* __restrict__ mult,
@@ -61,6 +138,7 @@ __global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const fl
   if (i >= (long)S * F) return;
   int s = (int)(i / F), f = (int)(i % F);
   int r0 = rowptr[s], r1 = rowptr[s + 1];
+  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_bwd_long_kernel
   float gs = gssum ? gssum[i] : 0.f;
   float dot = 0.f;
   for (int r = r0; r < r1; ++r) dot += alpha[(long)r * F + f] * (galpha[(long)r * F + f] + gs);
@@ -72,11 +150,39 @@ __global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const fl
   }
 }
 
+__global__ __launch_bounds__(256) void seg_softmax_bwd_long_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
+                                                                   const float* __restrict__ gssum, const float* __restrict__ mult,
+                                                                   const int* __restrict__ rowptr, int S, int F,
+                                                                   float* __restrict__ ga, float* __restrict__ gmult) {
+  __shared__ int list[256];
+  __shared__ int count;
+  __shared__ float red[4];
+  const int n = collect_long256(rowptr, S, list, &count);
+  for (int k = 0; k < n; ++k) {
+    const int s = list[k], r0 = rowptr[s], r1 = rowptr[s + 1];
+    for (int f = 0; f < F; ++f) {
+      const float gs = gssum ? gssum[(long)s * F + f] : 0.f;
+      float dot = 0.f;
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) dot += alpha[(long)r * F + f] * (galpha[(long)r * F + f] + gs);
+      dot = block256_sum(dot, red);
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float al = alpha[(long)r * F + f];
+        const float g = al * (galpha[(long)r * F + f] + gs - dot);
+        ga[(long)r * F + f] = g;
+        if (gmult) gmult[r] = (mult[r] != 0.f) ? g / mult[r] : 0.f;
+      }
+    }
+  }
+}
+
 int seg_softmax_fwd_launch(const float* a, const float* mult, const int* rowptr, int S, int F, float eps, float* alpha,
                            float* ssum, hipStream_t s) {
   long n = (long)S * F;
   if (n <= 0) return CGAT_OK;
   hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
+                     ssum);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_softmax_fwd_long_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
                      ssum);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
@@ -89,6 +195,9 @@ int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float*
   CGAT_CHECK_ARG(!gmult || F == 1, "seg_softmax_bwd: gradient of the multiplier needs F == 1");
   hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult, rowptr, S,
                      F, ga, gmult);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_softmax_bwd_long_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult, rowptr,
+                     S, F, ga, gmult);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -122,6 +231,7 @@ __global__ __launch_bounds__(256) void seg_wsum_vec_kernel(const float* __restri
                                                            float* __restrict__ out, long ldo, long xblock) {
   const int s = blockIdx.x;
   const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  if (r1 - r0 > SEG_LONG) return;                 // seg_wsum_long_kernel
   for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
     const int wf = w ? f / fw : 0;
     const float* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
@@ -162,6 +272,7 @@ __global__ __launch_bounds__(256) void seg_wsum_vec_bf16_kernel(const __bf16* __
                                                                 int act, float* __restrict__ out, long ldo, long xblock) {
   const int s = blockIdx.x;
   const int r0 = rowptr[s], r1 = rowptr[s + 1];
+  if (r1 - r0 > SEG_LONG) return;                 // seg_wsum_long_kernel
   for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
     const int wf = w ? f / fw : 0;
     const __bf16* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
@@ -191,6 +302,75 @@ __global__ __launch_bounds__(256) void seg_wsum_vec_bf16_kernel(const __bf16* __
   }
 }
 
+// Long segments of the vector forms: 1024 threads = G row groups x (up to 256) column quads; group g sums rows
+// r0 + g, r0 + g + G, ... (four in flight), the groups are added through LDS in group order.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) { return load4_bf16(p); }
+template <typename T>
+__global__ __launch_bounds__(1024) void seg_wsum_long_kernel(const T* __restrict__ x, long ldx, const int* __restrict__ ridx,
+                                                             const float* __restrict__ w, int wF, int fw,
+                                                             const int* __restrict__ rowptr, int S, int F, int act,
+                                                             float* __restrict__ out, long ldo, long xblock) {
+  __shared__ int list[1024];
+  __shared__ int count;
+  __shared__ float4 part[1024];
+  if (threadIdx.x == 0) count = 0;
+  __syncthreads();
+  {
+    const int s = blockIdx.x * 1024 + threadIdx.x;
+    if (s < S && rowptr[s + 1] - rowptr[s] > SEG_LONG) list[atomicAdd(&count, 1)] = s;
+  }
+  __syncthreads();
+  const int n = count;
+  const int quads = F / 4;
+  const int tpr = quads < 256 ? quads : 256;      // threads per row (column quads handled at a time)
+  const int G = 1024 / tpr;                        // row groups
+  const int g = threadIdx.x / tpr, q = threadIdx.x - g * tpr;
+  for (int k = 0; k < n; ++k) {
+    const int s = list[k], r0 = rowptr[s], r1 = rowptr[s + 1];
+    for (int q0 = 0; q0 < quads; q0 += tpr) {      // (uniform trip count)
+      const int f = 4 * (q0 + q);
+      const bool live = g < G && q0 + q < quads;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        const int wf = w ? f / fw : 0;
+        const T* xb = xblock ? x + (long)(f >> 7) * xblock + (f & 127) : x + f;
+        const long pitch = xblock ? 128 : ldx;
+        for (int r = r0 + g; r < r1; r += 4 * G) {
+          float4 v[4];
+          float wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * G < r1 ? r + u * G : r1 - 1;
+            const long row = ridx ? (long)ridx[rr] : (long)rr;
+            v[u] = ld4(xb + row * pitch);
+            wv[u] = w ? w[(long)rr * wF + wf] : 1.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (r + u * G < r1) {
+              acc.x += act_f(v[u].x, act) * wv[u];
+              acc.y += act_f(v[u].y, act) * wv[u];
+              acc.z += act_f(v[u].z, act) * wv[u];
+              acc.w += act_f(v[u].w, act) * wv[u];
+            }
+        }
+      }
+      __syncthreads();
+      part[threadIdx.x] = acc;
+      __syncthreads();
+      if (g == 0 && q0 + q < quads) {
+        float4 t = part[q];
+        for (int gg = 1; gg < G; ++gg) {
+          const float4 o = part[gg * tpr + q];
+          t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        *reinterpret_cast<float4*>(out + (long)s * ldo + f) = t;
+      }
+    }
+  }
+}
+
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
                     int F, int act, float* out, long ldo, hipStream_t s, long xblock, int x_bf16) {
   if (S <= 0 || F <= 0) return CGAT_OK;
@@ -207,6 +387,9 @@ int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, i
       hipLaunchKernelGGL(seg_wsum_vec_bf16_kernel<12>, dim3(S), dim3(threads), 0, s, xb, ldx, ridx, w, wF, fw, rowptr, F, act,
                          out, ldo, xblock);
     CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_wsum_long_kernel<__bf16>, dim3(cdiv(S, 1024)), dim3(1024), 0, s, xb, ldx, ridx, w, wF, fw, rowptr,
+                       S, F, act, out, ldo, xblock);
+    CGAT_LAUNCH_CHECK();
     return CGAT_OK;
   }
   const bool vec = (F % 4) == 0 && (!w || (fw % 4) == 0) && (ldx % 4) == 0 && (ldo % 4) == 0 && (xblock % 4) == 0 &&
@@ -220,6 +403,9 @@ int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, i
     else
       hipLaunchKernelGGL(seg_wsum_vec_kernel<12>, dim3(S), dim3(threads), 0, s, x, ldx, ridx, w, wF, fw, rowptr, F, act, out,
                          ldo, xblock);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_wsum_long_kernel<float>, dim3(cdiv(S, 1024)), dim3(1024), 0, s, x, ldx, ridx, w, wF, fw, rowptr, S,
+                       F, act, out, ldo, xblock);
     CGAT_LAUNCH_CHECK();
     return CGAT_OK;
   }

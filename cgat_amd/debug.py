@@ -26,6 +26,7 @@ class record_masks:
     def __init__(self, model):
         self.names = {p.data_ptr(): n for n, p in model.named_parameters()}
         self.masks = {}
+        self.dropout = []      # keep-masks of the attention dropout (scaled by 1 / (1 - p)), original edge order, in call order
 
     def __enter__(self):
         global _active
@@ -48,6 +49,11 @@ def note(weight, mask):
     name = _active.names.get(weight.data_ptr())
     if name is not None:
         _active.masks.setdefault(name, []).append(mask.detach().to("cpu", torch.bool))
+
+
+def note_dropout(keep):
+    if _active is not None:
+        _active.dropout.append(keep.detach().to("cpu"))
 
 
 def note_attention(a_in_w, m_in_w, plan, attn_params, saved, W2):

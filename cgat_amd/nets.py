@@ -74,6 +74,15 @@ class MHAttention(nn.Module):
         return attention_pool(alpha, m, plan, index, eps=1e-16)                    # softmax over the crystal, x m, summed
 
 
+def _dropout_keep(like, p):
+    """Keep-mask of F.dropout(alpha, p, training=True) (reference CGAT.py:221, 325) as an explicit tensor: Bernoulli(1 - p)
+    scaled by 1 / (1 - p), drawn from torch's Philox generator of the device (seeded by torch.manual_seed, as the
+    reference's own mask is)."""
+    if p >= 1.0:
+        return torch.zeros_like(like)
+    return torch.empty_like(like).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+
+
 def _edge_hidden(in_channels, nbr_channels):
     return int((2 * in_channels + nbr_channels) / 1.5)
 
@@ -108,13 +117,12 @@ class GATConvEdges(nn.Module):
         self.no_hyper = no_hyper
 
     def forward(self, x, edge_index, edge_attr, x_0, size=None):
-        if self.dropout:
-            raise NotImplementedError("attention dropout is always 0 in the reference stack")
         if self.no_hyper:
-            return self.Pooling_NN(edge_attr)
+            return self.Pooling_NN(edge_attr)     # (the discarded attention's dropout mask is discarded with it)
+        drop = self.dropout if (self.dropout and self.training) else 0.0
         plan = get_plan(edge_index, x.shape[0])
         if x.is_cuda and type(self.MH_A) is MultiHeadNetwork and type(self.MH_M) is MultiHeadNetwork:
-            aggr_out = self._message_fast(x, edge_attr, plan)
+            aggr_out = self._message_fast(x, edge_attr, plan, drop)
             if self.first:
                 return self.Pooling_NN(edge_attr, aggr_out)
             return self.Pooling_NN(x_0, edge_attr, aggr_out)
@@ -125,13 +133,17 @@ class GATConvEdges(nn.Module):
         alpha = self.MH_A(m).exp()
         m = self.MH_M(m)
         alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction
+        if drop:
+            keep = _dropout_keep(alpha, drop)                 # CGAT.py:221
+            debug.note_dropout(keep)
+            alpha = alpha * keep
         aggr_out = (m * alpha).mean(dim=1)
         if self.first:
             return self.Pooling_NN(edge_attr, aggr_out)
         return self.Pooling_NN(x_0, edge_attr, aggr_out)
 
 
-def _gatconvedges_message_fast(self, x, edge_attr, plan):
+def _gatconvedges_message_fast(self, x, edge_attr, plan, drop=0.0):
     """The attention / message networks of the edge update without the concatenated [E, 2C+Ce] rows: first layers of
     both networks as ONE operand-split op in destination-sorted slot order (EdgeHiddenFn, the op of the vector-attention
     node layer), the 2H second layers as one autograd node, the head softmax and mean on [E, H, .] tensors, and one
@@ -151,6 +163,11 @@ def _gatconvedges_message_fast(self, x, edge_attr, plan):
                                  (a.output_dim, Co))
     alpha = sa.exp()
     alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction (CGAT.py:219-221)
+    if drop:
+        keep = _dropout_keep(alpha, drop)                 # CGAT.py:221; rows are destination-sorted slots here
+        if debug.recording():
+            debug.note_dropout(torch.empty_like(keep).index_copy(0, plan.dst_perm.long(), keep))
+        alpha = alpha * keep
     aggr = (sm * alpha).mean(dim=1)                       # [E, Co] in sorted slot order
     return torch.empty_like(aggr).index_copy(0, plan.dst_perm.long(), aggr)
 
@@ -239,6 +256,10 @@ class GATConvNodes(nn.Module):
         perm = plan.dst_perm.long()
         al = SegmentSoftmaxFn.apply(alpha.reshape(E, -1).index_select(0, perm), None, plan.dst_rowptr, 1e-16)
         alpha = torch.empty_like(al).index_copy(0, perm, al).reshape(alpha.shape)
+        if self.dropout and self.training:
+            keep = _dropout_keep(alpha, self.dropout)         # CGAT.py:325: sample attention coefficients stochastically
+            debug.note_dropout(keep)
+            alpha = alpha * keep
         return m * alpha
 
     # -- whole layer as one autograd node (scalar attention + H_Net update): lets the backward overlap the
@@ -271,17 +292,18 @@ class GATConvNodes(nn.Module):
 
     def _propagate_one(self, edge_index, x, edge_attr, x_0):
         plan = get_plan(edge_index, x.shape[0])
-        if (ops_overlap_enabled() and not self.vector_attention and not self.final and not self.dropout and
+        drop = bool(self.dropout and self.training)       # F.dropout(..., training=self.training): identity in eval mode
+        if (ops_overlap_enabled() and not self.vector_attention and not self.final and not drop and
                 type(self).message is GATConvNodes.message and type(self).update is GATConvNodes.update and
                 type(self.Pooling_NN) in (H_Net, H_Net_0)):
             return self._layer_fused(x, edge_attr, x_0, plan)
-        if not self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
+        if not self.vector_attention and type(self).message is GATConvNodes.message and not drop:
             aggr = self._aggregate_fused(x, edge_attr, plan)
-        elif self.vector_attention and type(self).message is GATConvNodes.message and not self.dropout:
+        elif self.vector_attention and type(self).message is GATConvNodes.message and not drop:
             aggr = self._aggregate_vector(x, edge_attr, plan, edge_index)
         else:
-            if self.dropout:
-                raise NotImplementedError("attention dropout is always 0 in the reference stack")
+            # the MessagePassing-style route: subclasses overriding message(), and training-mode attention dropout
+            # (the mask multiplies the normalised coefficients, so the fused softmax x message kernels do not apply)
             splan0, splan1 = _endpoint_plans(plan, edge_index)
             x_j = gather_rows(x, edge_index[0], splan0)
             x_i = gather_rows(x, edge_index[1], splan1)
@@ -302,9 +324,37 @@ class GATConvNodes(nn.Module):
             return self.Pooling_NN(x_0, x, aggr_out)
         return aggr_out
 
+    def _propagate_pair(self, edge_index, x_src, x_dst, edge_attr):
+        """x = (x_source, x_target) (CGAT.py:308-312): PyG gathers x_j from the first entry with edge_index[0], x_i from
+        the second with edge_index[1] and aggregates over the second's rows."""
+        n_src, n_dst = x_src.shape[0], x_dst.shape[0]
+        plan = get_plan(edge_index, max(n_src, n_dst))
+        if not hasattr(plan, "_pair_plans"):
+            plan._pair_plans = {}
+        key = (n_src, n_dst)
+        if key not in plan._pair_plans:
+            if edge_index.shape[1] and int(edge_index[1].max()) >= n_dst:
+                raise IndexError(f"cgat_amd: edge_index[1] reaches beyond the {n_dst} target rows")
+            plan._pair_plans[key] = (SegmentPlan(edge_index[0], n_src), _RowPlan(plan.dst_rowptr, plan.dst_perm, n_dst))
+        splan0, splan1 = plan._pair_plans[key]
+        x_j = gather_rows(x_src, edge_index[0], splan0)
+        x_i = gather_rows(x_dst, edge_index[1], splan1)
+        msg = self.message(x_i, x_j, edge_attr, edge_index[1], plan=plan)                 # [E,H,C]
+        E = msg.shape[0]
+        perm = plan.dst_perm.long()
+        agg = SegmentSumFn.apply(msg.reshape(E, -1).index_select(0, perm), plan.dst_rowptr,
+                                 edge_index[1].index_select(0, perm))
+        return agg.reshape(plan.N, self.heads, self.out_channels).mean(dim=1)[:n_dst]
+
     def forward(self, x, edge_index, edge_attr, x_0, size=None):
         if not torch.is_tensor(x):
-            raise NotImplementedError("bipartite (tuple) node features are not used by CGAtNet")
+            x_src, x_dst = x[0], x[1]
+            if x_src is None or x_dst is None or not self.final:
+                # the reference's update() hands `x` to the hypernetwork (CGAT.py:328-335), which needs a tensor, and its
+                # message() concatenates both entries: a pair works there with final=True and two tensors only
+                raise TypeError("GATConvNodes: x = (x_source, x_target) needs two tensors and final=True "
+                                "(the hypernetwork update takes a single node tensor, as in the reference)")
+            return self._propagate_pair(edge_index, x_src, x_dst, edge_attr)
         return self.propagate(edge_index, x=x, edge_attr=edge_attr, x_0=x_0)
 
     def __repr__(self):
@@ -356,7 +406,7 @@ class CGAtNet(nn.Module):
         for graph_func in self.graphs:
             node_update = graph_func['Node'](elem_fea, edge_index, edge_attr, elem_fea_0)
             edge = graph_func['Edge']
-            if edge.no_hyper and type(edge).forward is GATConvEdges.forward and not edge.dropout:
+            if edge.no_hyper and type(edge).forward is GATConvEdges.forward:
                 # shipped form: Edge(...) = Pooling_NN(edge_attr) (its attention is dead code, CGAT.py:224-225); the
                 # residual add of CGAT.py:582 rides in the same launch
                 edge_attr = edge.Pooling_NN(edge_attr, residual=edge_attr)

@@ -130,6 +130,33 @@ def leaky(z, weight=None):
     return torch.where(near, torch.where(z > 0, 0.01 * z, z), out)
 
 
+# Attention dropout (CGAT.py:221, 325: F.dropout(alpha, p=self.dropout, training=self.training)).  The reference draws its
+# mask from torch's global RNG stream of the device it runs on; no two devices share that stream, so parity is checked
+# with the SAME mask on both sides: `dropout_masks([...])` makes the next dropout calls use the given keep-masks
+# (already scaled by 1 / (1 - p), as recorded from the implementation under test) instead of drawing their own.
+_DROPOUT = None
+
+
+class dropout_masks:
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _DROPOUT
+        self.prev, _DROPOUT = _DROPOUT, self
+        return self
+
+    def __exit__(self, *exc):
+        global _DROPOUT
+        _DROPOUT = self.prev
+
+
+def attention_dropout(alpha, p, training):
+    if _DROPOUT is not None and p and training and _DROPOUT.masks:
+        return alpha * _DROPOUT.masks.pop(0).to(alpha.dtype).reshape(alpha.shape)
+    return F.dropout(alpha, p=p, training=training)
+
+
 def relu(z, weight=None):
     if _FORCED is not None and weight is not None:
         m = _FORCED.take(weight, z)
@@ -379,6 +406,7 @@ class GATConvEdges(nn.Module):
         super().__init__()
         self.in_channels, self.out_channels, self.nbr_channels = in_channels, out_channels, nbr_channels
         self.heads, self.vector_attention, self.first, self.no_hyper = heads, vector_attention, first, no_hyper
+        self.dropout = dropout
         self.MH_A, self.MH_M = _edge_nets(in_channels, out_channels, nbr_channels, heads, vector_attention)
         if no_hyper:
             self.Pooling_NN = SimpleNetwork(out_channels, out_channels, [out_channels])
@@ -391,6 +419,7 @@ class GATConvEdges(nn.Module):
         alpha = self.MH_A(m).exp()                                                # 212, 214
         m = self.MH_M(m)
         alpha = alpha / alpha.sum(dim=1, keepdim=True)                            # 216-219 (over heads)
+        alpha = attention_dropout(alpha, self.dropout, self.training)             # 221
         aggr = (m * alpha).mean(dim=1)                                            # 222-223
         if self.no_hyper:
             return self.Pooling_NN(edge_attr)                                     # 224-225
@@ -408,6 +437,7 @@ class GATConvNodes(nn.Module):
         super().__init__()
         self.in_channels, self.out_channels, self.nbr_channels = in_channels, out_channels, nbr_channels
         self.heads, self.final, self.first = heads, final, first
+        self.dropout = dropout
         self.MH_A, self.MH_M = _edge_nets(in_channels, out_channels, nbr_channels, heads, vector_attention)
         if not final:
             cls = H_Net_0 if first else H_Net
@@ -416,12 +446,17 @@ class GATConvNodes(nn.Module):
     def message(self, x_i, x_j, edge_attr, edge_index_i, n):
         m = torch.cat([x_i, edge_attr, x_j], dim=-1)                              # 320
         alpha = seg_softmax(self.MH_A(m), edge_index_i, n)                        # 321, 323
+        alpha = attention_dropout(alpha, self.dropout, self.training)             # 325
         return self.MH_M(m) * alpha                                               # 322, 326
 
     def forward(self, x, edge_index, edge_attr, x_0, size=None):
-        n = x.shape[0]
+        # 308-312: a pair (x_source, x_target) for bipartite propagation; PyG gathers x_j from the first entry with
+        # edge_index[0], x_i from the second with edge_index[1] and aggregates over the second's rows.  update()
+        # (328-335) hands `x` to the hypernetwork, which only works for a tensor: a pair is usable with final=True
+        xs, xt = (x, x) if torch.is_tensor(x) else (x[0], x[1])
+        n = xt.shape[0]
         j, i = edge_index[0], edge_index[1]
-        msg = self.message(x[i], x[j], edge_attr, i, n)
+        msg = self.message(xt[i], xs[j], edge_attr, i, n)
         aggr = seg_sum(msg, i, n).mean(dim=1)                                     # aggregate + 329
         if self.final:
             return aggr

@@ -1,0 +1,164 @@
+"""The corners of the layer API the stack driver never visits but the boundary promises: training-mode
+attention dropout (reference CGAT.py:221, 325) and the (x_source, x_target) pair of MessagePassing (CGAT.py:308-312).
+Parity against the oracle with the SAME keep-masks: the reference draws them from the RNG stream of the device it runs
+on, which no other device reproduces, so the masks the HIP run drew are replayed on the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import maxnorm_rel
+from test_hip_golden import _compare_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer_inputs(G=24, seed=3, C=128):
+    import cgat_amd as P
+    b, _ = P.synthetic_batch(G, 20, 12, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    return {"x": torch.randn(N, C, generator=g), "edge_index": b.edge_index, "edge_attr": torch.randn(E, C, generator=g),
+            "x_0": torch.randn(N, C, generator=g)}
+
+
+CALL = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+
+
+@pytest.mark.parametrize("vector", [False, True])
+def test_nodes_attention_dropout_training_vs_oracle(vector):
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    torch.manual_seed(11)
+    kw = dict(concat=True, dropout=0.3, vector_attention=vector)
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, **kw), lambda: O.GATConvNodes(128, 128, 128, 3, **kw),
+                         _layer_inputs(), CALL)
+
+
+@pytest.mark.parametrize("first", [True, False])
+def test_edges_attention_dropout_training_vs_oracle(first):
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    torch.manual_seed(12)
+    kw = dict(concat=True, dropout=0.25, no_hyper=False, first=first)
+    ins = _layer_inputs(G=6, C=64)
+    ins["x_0"] = torch.randn(ins["edge_attr"].shape, generator=torch.Generator().manual_seed(5))   # the edge net's x_0
+    _compare_with_oracle(lambda: P.GATConvEdges(64, 64, 64, 3, **kw), lambda: O.GATConvEdges(64, 64, 64, 3, **kw), ins, CALL)
+
+
+def test_dropout_mask_statistics_and_eval_mode():
+    """The drawn keep-mask is Bernoulli(1 - p) / (1 - p); in eval mode (F.dropout(training=False)) the layer with
+    dropout is bit-identical to the layer without, on the fused path; p = 1 zeroes the aggregated message."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    ins = {k: v.to(dev) for k, v in _layer_inputs(G=200).items()}
+    torch.manual_seed(1)
+    drop = P.GATConvNodes(128, 128, 128, 3, concat=True, dropout=0.4).to(dev)
+    torch.manual_seed(1)
+    plain = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    rec = P.debug.record_masks(drop)
+    with rec, torch.no_grad():
+        y_train = CALL(drop, ins)
+    keep = rec.dropout[0]
+    vals = set(np.unique(keep.numpy()).tolist())
+    assert vals <= {0.0, float(np.float32(1.0 / 0.6))} and len(vals) == 2
+    frac = float((keep != 0).float().mean())
+    n = keep.numel()
+    assert abs(frac - 0.6) <= 5 * np.sqrt(0.24 / n), (frac, n)
+    with torch.no_grad():
+        y_plain = CALL(plain, ins)
+        drop.eval()
+        y_eval = CALL(drop, ins)
+    assert torch.equal(y_eval, y_plain)
+    assert not torch.equal(y_train, y_plain)
+    torch.manual_seed(1)
+    all_ = P.GATConvNodes(128, 128, 128, 3, concat=True, dropout=1.0, final=True).to(dev)
+    with torch.no_grad():
+        assert float(CALL(all_, ins).abs().max()) == 0.0
+
+
+def test_pair_of_node_tensors_vs_oracle():
+    """x = (x_source, x_target), final=True: a bipartite graph with 37 sources and 23 targets (targets without incoming
+    edges included), edges in arbitrary order."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    rs = np.random.RandomState(5)
+    n_src, n_dst, E = 37, 23, 300
+    ei = torch.from_numpy(np.stack([rs.randint(0, n_src, E), rs.randint(0, n_dst - 3, E)])).long()
+    g = torch.Generator().manual_seed(6)
+    ins = {"xs": torch.randn(n_src, 128, generator=g), "xt": torch.randn(n_dst, 128, generator=g), "edge_index": ei,
+           "edge_attr": torch.randn(E, 128, generator=g)}
+    call = lambda m, i: m((i["xs"], i["xt"]), i["edge_index"], i["edge_attr"], None)
+    kw = dict(concat=True, final=True)
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, **kw), lambda: O.GATConvNodes(128, 128, 128, 3, **kw), ins, call)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to("cuda:0")          # final=False: as in the reference, no pair
+    with pytest.raises(TypeError):
+        layer((ins["xs"].to("cuda:0"), ins["xt"].to("cuda:0")), ei.to("cuda:0"), ins["edge_attr"].to("cuda:0"), None)
+    with pytest.raises(IndexError):
+        bad = ei.clone(); bad[1, 0] = n_dst                                      # beyond the target rows
+        P.GATConvNodes(128, 128, 128, 3, **kw).to("cuda:0")((ins["xs"].to("cuda:0"), ins["xt"].to("cuda:0")), bad.to("cuda:0"),
+                                                            ins["edge_attr"].to("cuda:0"), None)
+
+
+def _hub_graph(n_atoms, K, hub_in, seed):
+    """Every atom sends K edges to random atoms; the first `hub_in` atoms send their first edge to atom 0 (the hub)."""
+    rs = np.random.RandomState(seed)
+    src = np.repeat(np.arange(n_atoms), K)
+    dst = rs.randint(0, n_atoms, size=n_atoms * K)
+    if hub_in:
+        dst[np.arange(hub_in) * K] = 0
+    return torch.from_numpy(np.stack([src, dst])).long()
+
+
+def test_hub_segment_vs_oracle():
+    """A destination with 3000 incoming edges (SEG_LONG = 256 rows: the long-segment kernels of csrc/segment.hip take its
+    softmax and its weighted message sum) among ordinary atoms, scalar and vector attention, against the oracle."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    ei = _hub_graph(3000, 4, 3000, seed=31)
+    g = torch.Generator().manual_seed(32)
+    N, E = 3000, ei.shape[1]
+    ins = {"x": torch.randn(N, 128, generator=g), "edge_index": ei, "edge_attr": torch.randn(E, 128, generator=g),
+           "x_0": torch.randn(N, 128, generator=g)}
+    for vector in (False, True):
+        kw = dict(concat=True, vector_attention=vector)
+        _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, **kw), lambda: O.GATConvNodes(128, 128, 128, 3, **kw),
+                             ins, CALL)
+
+
+def test_hub_segment_timing():
+    """One atom with 20 000 incoming edges in a 240 000-edge batch: the layer step (fwd+bwd) must cost about what the
+    same batch without a hub costs.  (Before round 3 the softmax of a segment was ONE thread walking its rows three
+    times and the weighted sum one 192-thread workgroup: the hub alone added tens of milliseconds.)"""
+    import json
+    import os
+    import cgat_amd as P
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    g = torch.Generator().manual_seed(33)
+    N, K = 20000, 12
+    x, x0, cot = (torch.randn(N, 128, generator=g).to(dev) for _ in range(3))
+    e = torch.randn(N * K, 128, generator=g).to(dev)
+    x.requires_grad_(True); e.requires_grad_(True)
+    times = {}
+    for name, hub_in in (("regular", 0), ("hub20000", 20000)):
+        ei = _hub_graph(N, K, hub_in, seed=34).to(dev)
+        assert hub_in == 0 or int((ei[1] == 0).sum()) >= 20000
+        reps = []
+        for r in range(4):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            y = layer(x, ei, e, x0)
+            y.backward(cot)
+            t1.record()
+            torch.cuda.synchronize()
+            reps.append(t0.elapsed_time(t1))
+            for p in layer.parameters():
+                p.grad = None
+            x.grad = e.grad = None
+        times[name] = sorted(reps[1:])[1]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r03_hub_timing.json"), "w") as f:
+            json.dump({"what": "GATConvNodes fwd+bwd, N = 20000, E = 240000, ms (median of 3 after 1 warm-up)", **times}, f)
+    assert times["hub20000"] <= 1.5 * times["regular"] + 1.0, times

@@ -103,16 +103,19 @@ def _compare_with_oracle(mk_prod, mk_orac, inputs, call, tol=TOL, label=None):
         g = torch.autograd.grad((y * c).sum(), leaves + list(params.values()), allow_unused=True)
         return [f"in{i}" for i in range(len(leaves))] + list(params), g
 
-    with P.debug.record_masks(pm) as masks:
+    rec = P.debug.record_masks(pm)
+    with rec as masks:
         yp = call(pm, pin)
     cot = torch.randn(yp.shape, generator=torch.Generator().manual_seed(9))
     _, gp = grads(pm, pin, yp, cot.to("cuda:0"))
-    with _O.forced_masks(om, masks) as f32:
+    # (training-mode attention dropout, CGAT.py:221 / 325: the keep-masks the HIP run drew are replayed on the oracle)
+    with _O.forced_masks(om, masks) as f32, _O.dropout_masks(rec.dropout) as d32:
         yo = call(om, oin)
         names, go = grads(om, oin, yo, cot)
-    with _O.forced_masks(om64, masks):
+    with _O.forced_masks(om64, masks), _O.dropout_masks(rec.dropout):
         yo64 = call(om64, oin64)
         _, go64 = grads(om64, oin64, yo64, cot.double())
+    assert not d32.masks, "dropout masks the oracle never consumed"
     assert f32.stats["layers"] > 0 or not masks, "no activation layer of the oracle took a recorded mask"
     assert all(not v for v in f32.masks.values()), "recorded masks the oracle never consumed: " + \
         ", ".join(k for k, v in f32.masks.items() if v)
