@@ -316,6 +316,98 @@ def bench_edge_hyper(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_lightning(args, rank, world, device):
+    """The network the reference harness builds with its argparse defaults (lightning_module.py:427-593 -> 165-176):
+    CGAtNet(200, 128, n_graph=5, msg_heads=5, neighbor_number=24, vector_attention=True, global_vector_attention=True,
+    mean_pooling=False, rezero=True, n_graph_roost=3), forward + backward of the L1 loss on a ~1M-edge batch
+    (2083 crystals x 20 atoms x 24 neighbours = 999 840 edges).  The roofline object is for the kernel tag with the most
+    GPU time in the timed region."""
+    import torch.distributed as dist
+    import cgat_amd as P
+    from cgat_amd import ops
+    H, K, L = 5, 24, 5
+    graphs = args.graphs if args.graphs != GRAPHS else 2083
+    torch.manual_seed(1)
+    net = P.CGAtNet(200, C_FEA, L, msg_heads=H, neighbor_number=K, update_edges=True, vector_attention=True,
+                    global_vector_attention=True, mean_pooling=False, rezero=True, n_graph_roost=3).to(device)
+    params = list(net.parameters())
+    b, roost = P.synthetic_batch(graphs, ATOMS, K, seed=rank)
+    b = b.to(device)
+    roost = tuple(t.to(device) for t in roost)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = net(b, roost)
+        (out[:, 0] - b.y).abs().mean().backward()
+    for _ in range(args.warmup):
+        step()
+    _fence(world)
+    ops.prof_reset(); ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _fence(world)
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        Hd, W2 = 256, 2 * H * 256
+        tags = ("edge_z", "linear128", "seg_attnpool_fwd", "seg_attnpool_bwd", "bilinear_rows", "bilinear_dual",
+                "bilinear_wgrad", "edge_ge", "edge_gw", "rows_ge", "rows_gw", "edge_gj", "mlp_chain", "rows_dw", "gemm_f32")
+        shares = {}
+        for t_ in tags:
+            n_t, ms_t = ops.prof_get(t_)
+            if n_t:
+                shares[t_] = {"launches_per_step": n_t / args.steps, "ms_per_step": round(ms_t / args.steps, 3),
+                              "avg_launch_ms": round(ms_t / n_t, 4)}
+        # algorithmic work per launch of the tags that can dominate (per Node layer; C = 128, H = 5, Hd = 256):
+        #   edge_z (first layers of both networks, operand split): writes hidden [E, W2] fp32, reads e and gathers Pj
+        #   linear128 (per-head second layers, 128-wide blocks): 2 * rows * 128 * 128 flop per launch
+        #   seg_attnpool_*: reads logits + messages [E, 2 * H * C] (+ the gradient pair in backward)
+        alg = {"edge_z": ("hbm", E * (W2 * 4.0 + W2 * 4.0 + C_FEA * 4.0) + N * W2 * 4.0),
+               "seg_attnpool_fwd": ("hbm", E * 2.0 * H * C_FEA * 4 + N * H * C_FEA * 4.0),
+               "seg_attnpool_bwd": ("hbm", E * 4.0 * H * C_FEA * 4 + 2.0 * N * H * C_FEA * 4),
+               "linear128": ("mfma", 2.0 * E * 128 * 128)}
+        roof = None
+        if shares:
+            dom = max(shares, key=lambda k: shares[k]["ms_per_step"])
+            roof = {"kernel_tag": dom, **shares[dom]}
+            if dom in alg:
+                kind, amount = alg[dom]
+                avg_s = shares[dom]["avg_launch_ms"] * 1e-3
+                if kind == "hbm":
+                    roof.update({"bound": "hbm", "achieved": round(amount / avg_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(amount / avg_s / 8e12, 4), "traffic": None,
+                                 "algorithmic_bytes_per_launch": int(amount)})
+                else:
+                    peak = MFMA_BF16_PEAK_TFLOPS / 3
+                    roof.update({"bound": "mfma", "achieved": round(amount / avg_s / 1e12, 2), "peak": round(peak, 1),
+                                 "unit": "TFLOP/s", "frac": round(amount / avg_s / 1e12 / peak, 4), "traffic": None,
+                                 "flops_per_launch": amount,
+                                 "note": "per-launch figure at E rows; launches over N rows (trunks) share the tag"})
+        n_par = sum(p.numel() for p in params)
+        print(json.dumps({
+            "metric": "batch-edges/sec through the reference harness' DEFAULT network (5 layers, 5 heads, 24 neighbours, vector "
+                      "attention, concat pooling, rezero), fwd+bwd, ~1M-edge batch [informational, SURVEY 8 f2]",
+            "value": world * E * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 storage / " + P.get_bilinear_mode(), "data": "synthetic",
+            "config": {"workload": f"CGAtNet(200,128,5,msg_heads=5,neighbor_number=24,vector_attention=True,"
+                                   f"global_vector_attention=True,mean_pooling=False,rezero=True) fwd+bwd of the L1 loss, "
+                                   f"{graphs} crystals x {ATOMS} atoms x {K} nbrs: N={N}, E={E}, {n_par} parameters",
+                       "edge_layer_passes_per_s": round(L * E * args.steps / elapsed, 1), "parallelism": f"dp{world}"},
+            "roofline": roof, "kernel_ms_per_step": shares,
+            "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, device):
     """BASELINE configs[3]: the end-to-end data-parallel training step on a DCGAT-shaped synthetic dataset (ragged
     crystals of 2..40 atoms, 24 stored / 12 used neighbours, y = e_above_hull * n_atoms): device collation of the
@@ -352,6 +444,10 @@ def bench_train(args, rank, world, device):
     _fence(world)
     elapsed = time.perf_counter() - t0
     step_ms = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
+    n0 = ops.prof_launches()
+    tr.step(batches[0])
+    train_launches = ops.prof_launches() - n0
+    train_syncs = _count_host_syncs(lambda: tr.step(batches[0]))
     tot = torch.tensor([elapsed, float(edges)], device=device, dtype=torch.float64)
     if world > 1:
         mx = tot.clone()
@@ -364,6 +460,7 @@ def bench_train(args, rank, world, device):
                          "gradient all-reduce -> AdamW), DCGAT-shaped synthetic dataset [BASELINE configs[3]]",
                "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * elapsed / args.steps, "step_ms_gpu_events": step_ms,
+               "launch_bound": {"library_kernel_launches_per_step": train_launches, "host_syncs_per_step": train_syncs},
                "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
                "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
@@ -391,6 +488,53 @@ def _allreduce_report(avg, n_steps):
             "MB_reduced_per_step": round(st["bytes_reduced"] / n_steps / 1e6, 1),
             "what": "cgat_amd.dist.GradientAverager: gradients live in the buckets, hot buckets are all-reduced from the "
                     "autograd hooks while backward is running, parameters unused on every rank are cold (not reduced)"}
+
+
+def _count_host_syncs(step):
+    """Host synchronisations of ONE step, counted by torch's sync-debug mode (every .item() / .tolist() / blocking copy
+    of a device tensor warns); the library's own calls never synchronise (include/cgat_hip.h)."""
+    import warnings
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    return sum(1 for x in w if "synchroniz" in str(x.message).lower())
+
+
+def _launch_report(step, steps, world, try_graph):
+    """Launch-bound regime (the reference's shipped --batch-size 64, lightning_module.py:468-473): library kernel launches
+    and host synchronisations per step, and the same step captured into ONE hipGraph (cgat_amd.GraphedStep) and
+    replayed."""
+    import cgat_amd as P
+    from cgat_amd import ops
+    n0 = ops.prof_launches()
+    step()
+    launches = ops.prof_launches() - n0
+    rep = {"library_kernel_launches_per_step": launches, "host_syncs_per_step": _count_host_syncs(step),
+           "what": "launches = kernels issued by libcgat_hip in one step (torch's own elementwise / copy kernels not "
+                   "counted; profiles/ has the rocprofv3 totals); host syncs by torch.cuda.set_sync_debug_mode"}
+    if try_graph:
+        try:
+            gs = P.GraphedStep(step, warmup=2)
+            for _ in range(3):
+                gs.replay()
+            _fence(world)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gs.replay()
+            _fence(world)
+            rep["hipgraph"] = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / steps, 4),
+                               "library_kernel_launches_in_graph": gs.kernel_launches,
+                               "what": "the same step (forward + backward) captured once into a hipGraph and replayed: one "
+                                       "host-side launch per step; bit-identical results (tests/test_capture.py)"}
+        except Exception as ex:                      # never let the informational leg take the bench line down
+            rep["hipgraph"] = {"error": repr(ex)[:300]}
+    return rep
 
 
 def _fence(world):
@@ -501,11 +645,14 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the untimed-for-`value` legs after the timed region (other arithmetic modes, full stack)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="--workload train: per-rank or total batch fixed")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="layer / stack workloads: also capture the step into one hipGraph and time its replay (reported "
+                         "as launch_bound.hipgraph; `value` stays the eager step); on by default below 512 crystals")
     ap.add_argument("--nbrs", type=int, default=None, help="neighbours per atom (default 12; --workload stress: 64)")
     ap.add_argument("--edge-storage", choices=["f32", "bf16"], default="f32",
                     help="storage of the per-edge intermediates Z / gZ (bf16 = the 'bf16 activations' of configs[4]; "
                          "tolerance 1e-2 instead of 1e-4: never the default, reported in the line)")
-    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress", "edge_hyper"], default="layer",
+    ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress", "edge_hyper", "lightning"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
     args = ap.parse_args()
@@ -529,6 +676,8 @@ def main():
         return bench_edge_hyper(args, rank, world, device)
     if args.workload == "train":
         return bench_train(args, rank, world, device)
+    if args.workload == "lightning":
+        return bench_lightning(args, rank, world, device)
 
     # CPU leg FIRST (rank 0, N = 1 only): the GPU leg that follows is then one contiguous block of device work
     cpu = None
@@ -579,6 +728,9 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
     ar_report = _allreduce_report(step_averager, args.warmup + args.steps) if step_averager is not None else None
+    launch_rep = None
+    if not stress and (args.hipgraph or args.graphs < 512):
+        launch_rep = _launch_report(step, args.steps, world, try_graph=step_averager is None)
     ALL_TAGS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad", "edge_z", "edge_proj", "edge_seg_bwd", "edge_ge",
                 "edge_gw", "edge_gj", "rows_ge", "rows_gw", "linear128", "mlp_chain", "rows_dw", "gemm_f32")
     prof = {t: ops.prof_get(t) for t in ALL_TAGS}          # (launches, total ms) inside the timed region
@@ -815,6 +967,8 @@ def main():
             out["cpu_baseline"] = cpu
         if ar_report is not None:
             out["allreduce"] = ar_report
+        if launch_rep is not None:
+            out["launch_bound"] = launch_rep
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -16,9 +16,11 @@ from .optim import FusedAdamW, FusedLamb, RobustL1, RobustL2, cyclical_lr
 from .ops import get_bilinear_mode, set_bilinear_mode, set_validate_indices, set_edge_storage, get_edge_storage
 from .trainer import DataParallelTrainer, Normalizer
 from .chunked import set_max_edges_per_pass
+from .capture import GraphedStep
+from . import debug
 
 __all__ = ["CGAtNet", "GATConvNodes", "GATConvEdges", "MultiHeadNetwork", "MHAttention", "H_Net", "H_Net_0",
            "HyperFC", "SimpleNetwork", "ResidualNetwork", "Rezero", "Roost", "MessageLayer", "WeightedAttention",
            "GraphBatch", "synthetic_batch", "PackedDataset", "FusedAdamW", "FusedLamb", "RobustL1", "RobustL2", "cyclical_lr", "set_bilinear_mode", "get_bilinear_mode",
            "set_validate_indices", "DataParallelTrainer", "Normalizer", "set_max_edges_per_pass",
-           "set_edge_storage", "get_edge_storage"]
+           "set_edge_storage", "get_edge_storage", "GraphedStep", "debug"]

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "cgat_prof_enable": (None, [C.c_int]),
     "cgat_prof_reset": (None, []),
     "cgat_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "cgat_prof_launches": (C.c_uint64, []),
     "cgat_plan_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cgat_plan_build": (C.c_int, [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "cgat_csr_workspace_bytes": (C.c_size_t, [C.c_int32]),

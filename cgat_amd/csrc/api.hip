@@ -47,6 +47,8 @@ ProfScope::~ProfScope() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].end, stream);
 }
+unsigned long long g_cgat_launches = 0;
+extern "C" uint64_t cgat_prof_launches(void) { return __atomic_load_n(&g_cgat_launches, __ATOMIC_RELAXED); }
 extern "C" void cgat_prof_enable(int on) { g_prof_on = on != 0; }
 extern "C" void cgat_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

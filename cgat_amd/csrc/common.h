@@ -44,8 +44,11 @@ struct ProfScope {
 };
 #define CGAT_PROF(tag, stream) ProfScope _prof_scope_##__LINE__(tag, stream)
 
+// every kernel launch of the library passes through CGAT_LAUNCH_CHECK: a process-wide launch counter (cgat_prof_launches)
+extern unsigned long long g_cgat_launches;
 #define CGAT_LAUNCH_CHECK()                                                  \
   do {                                                                       \
+    __atomic_fetch_add(&g_cgat_launches, 1ull, __ATOMIC_RELAXED);            \
     hipError_t _e = hipGetLastError();                                       \
     if (_e != hipSuccess) {                                                  \
       cgat_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \

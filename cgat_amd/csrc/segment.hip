@@ -626,6 +626,7 @@ int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const flo
   if (S <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out), "segment_attention_pool: unsupported shape (F=%d, aF=%d)", F, aF);
   const int fw = F / aF;
+  CGAT_PROF("seg_attnpool_fwd", s);
   if (fw == 1)
     hipLaunchKernelGGL(seg_attnpool_fwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, mult, m, ldm,
                        rowptr, ridx, F, eps, out, mx, inv);
@@ -643,6 +644,7 @@ int seg_attnpool_bwd_launch(const float* a, int aF, const float* mult, const flo
                  "segment_attention_pool backward: unsupported shape (F=%d, aF=%d)", F, aF);
   CGAT_CHECK_ARG(!g_mult || aF == 1, "segment_attention_pool backward: gradient of the multiplier needs one logit column");
   const int fw = F / aF;
+  CGAT_PROF("seg_attnpool_bwd", s);
   if (fw == 1)
     hipLaunchKernelGGL(seg_attnpool_bwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, 1, mult, m, ldm,
                        rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult);

@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib, chunked, debug
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, linear, small_embedding,
+from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, get_segment_plan, linear, small_embedding,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -67,7 +67,7 @@ class MHAttention(nn.Module):
 
     def forward(self, fea, cry_fea, index, size=None):
         size = int(index[-1]) + 1 if size is None else size
-        plan = SegmentPlan(index, size)
+        plan = get_segment_plan(index, size)
         m = self.MH_M(fea)                                                         # [N,H,C]
         pair = torch.cat([fea, gather_rows(cry_fea, index, plan)], dim=1)          # == stack+transpose+reshape, 55-58
         alpha = self.MH_A(pair)                                                    # [N,H,1|C]

@@ -149,6 +149,24 @@ class SegmentPlan:
         self.perm64 = self.perm.long()
 
 
+_seg_plan_cache = {}
+
+
+def get_segment_plan(index, num_segments):
+    """SegmentPlan through a small LRU keyed by the index storage (as get_plan): the Roost branch and the crystal
+    pooling of one batch build four plans per forward; a batch that is evaluated again (validation epochs, the
+    hipGraph-captured step) builds -- and validates, one host synchronisation each -- none."""
+    key = (index.data_ptr(), tuple(index.shape), int(num_segments), index._version, index.device.index)
+    plan = _seg_plan_cache.get(key)
+    if plan is None:
+        if len(_seg_plan_cache) >= 16:
+            _seg_plan_cache.pop(next(iter(_seg_plan_cache)))
+        plan = SegmentPlan(index, num_segments)
+        plan._keepalive = index
+        _seg_plan_cache[key] = plan
+    return plan
+
+
 # ----------------------------------------------------------------------------------------
 # GATConvNodes message + softmax + aggregate
 # ----------------------------------------------------------------------------------------
@@ -936,6 +954,11 @@ def prof_enable(on=True):
 
 def prof_reset():
     lib.cgat_prof_reset()
+
+
+def prof_launches():
+    """Kernel launches the library has issued so far in this process (all streams)."""
+    return int(lib.cgat_prof_launches())
 
 
 def prof_get(tag):

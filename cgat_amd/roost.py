@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .mlp import SimpleNetwork
-from .ops import SegmentPlan, attention_pool, gather_rows
+from .ops import SegmentPlan, attention_pool, gather_rows, get_segment_plan
 
 
 class WeightedAttention(nn.Module):
@@ -20,7 +20,7 @@ class WeightedAttention(nn.Module):
     def forward(self, fea, index, weights, plan=None, dim_size=None):
         if plan is None:
             n = int(index.max()) + 1 if dim_size is None else dim_size   # reference: scatter's implicit size
-            plan = SegmentPlan(index, n)
+            plan = get_segment_plan(index, n)
         gate = self.gate_nn(fea)                                                       # [M,1]
         fea = self.message_nn(fea)
         # (weights ** pow) * exp(gate - segmax) / (segsum + 1e-13), times the message, summed per segment (305-317)
@@ -45,7 +45,7 @@ class MessageLayer(nn.Module):
     def forward(self, elem_weights, elem_in_fea, self_fea_idx, nbr_fea_idx, plans=None):
         n = elem_in_fea.shape[0]
         if plans is None:
-            plans = (SegmentPlan(self_fea_idx, n), SegmentPlan(nbr_fea_idx, n))
+            plans = (get_segment_plan(self_fea_idx, n), get_segment_plan(nbr_fea_idx, n))
         self_plan, nbr_plan = plans
         elem_nbr_weights = elem_weights.index_select(0, nbr_fea_idx)
         elem_nbr_fea = gather_rows(elem_in_fea, nbr_fea_idx, nbr_plan)
@@ -80,11 +80,11 @@ class Roost(nn.Module):
         elem_fea = linear(orig_elem_fea, self.embedding.weight, self.embedding.bias)
         elem_fea = torch.cat([elem_fea, elem_weights], dim=1)                  # C-1 learned + the weight itself
         n = elem_fea.shape[0]
-        plans = (SegmentPlan(self_fea_idx, n), SegmentPlan(nbr_fea_idx, n))   # shared by all message layers
+        plans = (get_segment_plan(self_fea_idx, n), get_segment_plan(nbr_fea_idx, n))   # shared by all message layers
         for graph_func in self.graphs:
             elem_fea = graph_func(elem_weights, elem_fea, self_fea_idx, nbr_fea_idx, plans=plans)
         G = int(crystal_elem_idx.max()) + 1 if num_crystals is None else num_crystals
-        cplan = SegmentPlan(crystal_elem_idx, G)
+        cplan = get_segment_plan(crystal_elem_idx, G)
         head_fea = [att(fea=elem_fea, index=crystal_elem_idx, weights=elem_weights, plan=cplan)
                     for att in self.cry_pool]
         return torch.mean(torch.stack(head_fea), dim=0)

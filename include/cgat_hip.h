@@ -31,6 +31,8 @@ void cgat_prof_reset(void);
 /* sums all recorded launches of kernels tagged `tag` ("bilinear_rows", "bilinear_wgrad",
  * "gemm_f32", ...); synchronises the recorded events. */
 int cgat_prof_get(const char* tag, int* count, float* total_ms);
+/* kernel launches issued by the library since the process started (every launch is counted, on any stream) */
+uint64_t cgat_prof_launches(void);
 
 /* ---- CSR plan: PyG propagate's implicit segment structure, built once per batch --------
  * replaces the index handling of torch_geometric MessagePassing.propagate / utils.softmax /
