@@ -49,6 +49,18 @@ def workspace(nbytes, device):
     return buf
 
 
+def _scratch(numel, dtype, device):
+    """A saved-for-backward / side buffer whose size the library dictates (only its pointer is used): the element count is
+    rounded up to 1/16 of its octave.  Ragged batches change E by a few per cent from step to step; with exact sizes
+    every new maximum made torch's caching allocator hipMalloc a fresh multi-GB block per layer (two 840-ms steps among
+    121-ms ones in the training bench), with rounded sizes the cached blocks fit."""
+    n = int(numel)
+    if n > (1 << 20):
+        step = 1 << (n.bit_length() - 5)
+        n = (n + step - 1) // step * step
+    return torch.empty(n, dtype=dtype, device=device)
+
+
 _validate_indices = os.environ.get("CGAT_VALIDATE_INDICES", "1") != "0"
 
 
@@ -198,7 +210,7 @@ class NodesAttentionFn(torch.autograd.Function):
             raise ValueError(f"plan is for N={N}, E={E}; got x {tuple(x.shape)}, edge_attr {tuple(edge_attr.shape)}")
         p, Hd = _attn_params(x, edge_attr, H, weights)
         dev = x.device
-        saved = torch.empty(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), dtype=torch.float32, device=dev)
+        saved = _scratch(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), torch.float32, dev)
         aggr = torch.empty(N, x.shape[1], dtype=torch.float32, device=dev)
         ws = workspace(lib.cgat_nodes_attention_forward_workspace_bytes(C.byref(plan.c), C.byref(p)), dev)
         with torch.cuda.device(dev):
@@ -334,7 +346,7 @@ class HNetFn(torch.autograd.Function):
                 raise ValueError(f"hypernetwork head weight must be [{W * W + W}, {W}] (all widths equal), got {tuple(hw.shape)}")
         p = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
         dev = v.device
-        saved = torch.empty(lib.cgat_hnet_saved_floats(rows, C.byref(p)), dtype=torch.float32, device=dev)
+        saved = _scratch(lib.cgat_hnet_saved_floats(rows, C.byref(p)), torch.float32, dev)
         y = torch.empty_like(v)
         ws = workspace(lib.cgat_hnet_forward_workspace_bytes(rows, C.byref(p)), dev)
         with torch.cuda.device(dev):
@@ -387,8 +399,8 @@ class NodeLayerFn(torch.autograd.Function):
         pa, Hd = _attn_params(x, edge_attr, H, attn_w)
         W = x.shape[1]
         ph = _hnet_struct(_lib.HnetParams, W, n_fc, n_hyper, flat, d)
-        saved_a = torch.empty(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), dtype=torch.float32, device=dev)
-        saved_h = torch.empty(lib.cgat_hnet_saved_floats(N, C.byref(ph)), dtype=torch.float32, device=dev)
+        saved_a = _scratch(lib.cgat_nodes_attention_saved_floats(N, E, H, Hd), torch.float32, dev)
+        saved_h = _scratch(lib.cgat_hnet_saved_floats(N, C.byref(ph)), torch.float32, dev)
         aggr, y = torch.empty(N, W, dtype=torch.float32, device=dev), torch.empty(N, W, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = workspace(lib.cgat_nodes_attention_forward_workspace_bytes(C.byref(plan.c), C.byref(pa)), dev)
@@ -429,7 +441,7 @@ class NodeLayerFn(torch.autograd.Function):
             # side_ws (the side stream's inputs and scratch) is its own allocation: the attention backward reuses the
             # cached main workspace while the side stream is still running
             ws_h = workspace(lib.cgat_hnet_backward_workspace_bytes(N, C.byref(ph)), dev)
-            side_ws = torch.empty(lib.cgat_hnet_backward_side_workspace_bytes(N, C.byref(ph)), dtype=torch.uint8, device=dev)
+            side_ws = _scratch(lib.cgat_hnet_backward_side_workspace_bytes(N, C.byref(ph)), torch.uint8, dev)
             check(lib.cgat_hnet_backward_overlapped(N, C.byref(ph), _ptr(h0), _ptr(aggr), _ptr(saved_h), _ptr(g_y),
                                                     _ptr(g_h0), _ptr(g_aggr), C.byref(gh), _ptr(ws_h), ws_h.numel(),
                                                     main.cuda_stream, _ptr(side_ws), side_ws.numel(), s2.cuda_stream),
