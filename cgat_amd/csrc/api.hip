@@ -135,6 +135,9 @@ extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int
   if (b > a) a = b;
   if (c > a) a = c;
   if (K == 128 && N == 128 && rows_dw128_ws_bytes(M, 1) > a) a = rows_dw128_ws_bytes(M, 1);
+  if (K % 128 == 0 && N % 128 == 0 && (K / 128) * (N / 128) <= DW_BATCH_MAX &&
+      rows_dw128_batch_ws_bytes((K / 128) * (N / 128), M) > a)
+    a = rows_dw128_batch_ws_bytes((K / 128) * (N / 128), M);
   return a + 256;
 }
 
@@ -172,6 +175,23 @@ extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w,
       rows_dw128_fast(gp, ldgp, x, ldx, nullptr, 0)) {
     // g_W = gpre^T @ x and g_b = column sums of gpre in one pass over both operands (rowsdw.hip)
     return rows_dw128_launch(gp, ldgp, x, ldx, g_w, ldgw, nullptr, 0, nullptr, 0, g_b, M, ws, ws_bytes, s);
+  }
+  // widths that are multiples of 128 on both sides (the per-head second layers of vector attention: 256 -> 128 at E
+  // rows, 47 ms of split-K generic GEMMs per step of the Lightning-default network): the (N / 128) x (K / 128) blocks
+  // of g_W as ONE batched launch of the rows kernel, bias gradient from the first block column
+  {
+    const int nb = N / 128, kb = K / 128;
+    DwBatchDesc b;
+    memset(&b, 0, sizeof(b));
+    b.rows = M; b.ldg = ldgp; b.ldx = ldx; b.ldo = ldgw;
+    if (g_w && M > 0 && N % 128 == 0 && K % 128 == 0 && nb * kb <= DW_BATCH_MAX && nb * kb > 1 && bilinear_mode() != 0) {
+      for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < kb; ++j)
+          b.it[b.n++] = {gp + 128 * i, x + 128 * j, g_w + (size_t)128 * i * ldgw + 128 * j,
+                         (g_b && j == 0) ? g_b + 128 * i : nullptr};
+      if (rows_dw128_batch_fast(b) && ws && ws_bytes >= rows_dw128_batch_ws_bytes(b.n, M))
+        return rows_dw128_batch_launch(b, ws, ws_bytes, s);
+    }
   }
   if (g_w) {  // g_W = gpre^T @ x
     GemmParams g = gemm_params(N, K, M, gp, ldgp, x, ldx, g_w, ldgw);

@@ -1095,6 +1095,14 @@ static bool rows_fast(const float* q, long ldq, int NB, int NC) {
 // how many ways to split the `a` range so that tiles*split fills 256 CUs without a ragged last wave
 static int rows_asplit(int nrows, int rows_wg) {
   const int tiles = cdiv(nrows, rows_wg);
+  // Few rows (the reference's shipped batch of 64 crystals is 1 280 atoms = 10 tiles): every workgroup streams its share
+  // of T through its LDS ring whatever the row count, so the launch takes as long as ONE workgroup needs for 128 / sp
+  // slices of T -- with sp <= 4 that left 216 of the 256 CUs idle and ~60-100 us per contraction.  Up to 32 ways then
+  // (>= 4 values of `a` per workgroup); the slab sum over sp x [nrows, 128] floats is negligible at these sizes.
+  if (tiles * 4 <= 128) {
+    int sp = 256 / tiles;
+    return sp > 32 ? 32 : (sp < 4 ? 4 : sp);
+  }
   int best = 1;
   double best_eff = 0.0;
   for (int sp = 1; sp <= 4; ++sp) {

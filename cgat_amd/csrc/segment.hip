@@ -179,6 +179,7 @@ int seg_softmax_fwd_launch(const float* a, const float* mult, const int* rowptr,
                            float* ssum, hipStream_t s) {
   long n = (long)S * F;
   if (n <= 0) return CGAT_OK;
+  CGAT_PROF("seg_softmax", s);
   hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
                      ssum);
   CGAT_LAUNCH_CHECK();
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(1024) void seg_wsum_long_kernel(const T* __restrict
 int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, int wF, int fw, const int* rowptr, int S,
                     int F, int act, float* out, long ldo, hipStream_t s, long xblock, int x_bf16) {
   if (S <= 0 || F <= 0) return CGAT_OK;
+  CGAT_PROF("seg_wsum", s);
   if (x_bf16) {
     CGAT_CHECK_ARG((F % 4) == 0 && (!w || (fw % 4) == 0) && (ldx % 4) == 0 && (ldo % 4) == 0 && (xblock % 4) == 0 &&
                    (((uintptr_t)x) & 7) == 0 && (((uintptr_t)out) & 15) == 0, "seg_wsum: bf16 input needs the vector shape");

@@ -41,6 +41,11 @@ _ws = {}
 def workspace(nbytes, device):
     """Grow-only per-device scratch buffer.  All launches are ordered on the current stream, so
     one buffer serves every call (no allocation in the steady state)."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture (cgat_amd.GraphedStep) the buffer must belong to THAT graph's memory pool: a cached
+        # one would come from an earlier capture on the same capture stream, whose pool dies with its graph.  The pool
+        # reuses the block as soon as the tensor is dropped, exactly as the caching allocator does in eager mode.
+        return torch.empty(int(nbytes) + 4096, dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
