@@ -1297,11 +1297,18 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   bool side_waits = false;   // the side stream has been made to wait for everything issued above
   auto side_wait = [&]() -> int {
     if (side_waits) return CGAT_OK;
-    hipEvent_t ev;
-    CGAT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    CGAT_HIP(hipEventRecord(ev, c.s));
-    CGAT_HIP(hipStreamWaitEvent(side->s, ev, 0));
-    CGAT_HIP(hipEventDestroy(ev));
+    // Events come from a small ring created once and never destroyed: under a hipGraph capture (cgat_amd.GraphedStep) the
+    // captured dependency keeps referring to the event object, and destroying it right after the wait -- legal in eager
+    // mode -- crashed hipStreamEndCapture on the second capture of a process.
+    static hipEvent_t ring[64];
+    static unsigned next = 0, made = 0;
+    const unsigned slot = next++ % 64;
+    if (slot >= made) {
+      CGAT_HIP(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming));
+      made = slot + 1;
+    }
+    CGAT_HIP(hipEventRecord(ring[slot], c.s));
+    CGAT_HIP(hipStreamWaitEvent(side->s, ring[slot], 0));
     side_waits = true;
     return CGAT_OK;
   };

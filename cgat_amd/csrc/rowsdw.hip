@@ -17,6 +17,8 @@
 // (the lane's float4 of X gives the B operands of four interleaved column blocks), so a lane's four accumulators at
 // register t are four consecutive floats of out[4 m + w][4 n ..]: one 16-byte store.  The two row halves are added
 // through LDS, one slab per workgroup, then a deterministic reduction over the slabs.
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "mfma_bf16.h"
@@ -151,6 +153,140 @@ __global__ __launch_bounds__(512, 1) void rows_dw128_batch_kernel(DwBatchDesc d,
   rows_dw128_body<1>(G, d.ldg, X, d.ldx, X, d.ldx, slab + (long)blockIdx.x * (16384 + 128), nbeg,
                      min(d.rows, nbeg + d.rows_per_unit), red);
 }
+// ---- the same products on the bf16 matrix cores (split arithmetic modes) -------------------------------------------
+// The f32-input form above is bound by the f32 MFMA rate (64 FLOP/clk/SIMD): 0.73 ms for the 24 products of a
+// hypernetwork backward whose operands are 2 GB (0.33 ms of HBM time), and 0.95 ms per 256 -> 128 second layer of the
+// vector-attention networks at E = 1M rows (47 ms of the Lightning-default step).  Here every fp32 value is split
+// exactly into three bf16 pieces (24 bits, no scales needed: bf16 has fp32's exponent range) and a product is the six
+// cross terms of weight >= 2^-24 as v_mfma_f32_16x16x32_bf16 passes with fp32 accumulation -- the arithmetic of the
+// "bf16x6" contraction kernels (mfma_bf16.h) -- at 1/16 of the f32-MFMA cycles per flop x 6 passes.
+//
+// The reduction runs over the ROW index, so both operands need the row on the MFMA k axis while memory has it on the
+// slow axis: a K-step is 32 rows; thread (operand, m = column, half) loads its column's 16 rows of the step with
+// 4-byte loads (a wave-instruction = 256 contiguous bytes of one row), splits them and writes 8 consecutive k of one
+// column as one ds_write_b128 into the image [plane][m][k] (pitch 80 B: conflict-free 16-byte writes and reads); a
+// fragment is then one ds_read_b128.  Two images (double buffer), one barrier per K-step, loads two K-steps ahead.
+// Accumulator bias of the bf16 MFMA: odd K-steps are accumulated NEGATED into a second accumulator set
+// and subtracted at the end, so the sign-independent rounding bias cancels.
+#define DWS_PITCH 80                                   // bytes per column of an image: 32 bf16 + 16 B of padding
+#define DWS_IMG (128 * DWS_PITCH)                      // one plane of one operand
+__global__ __launch_bounds__(512, 1) void rows_dw128_split_batch_kernel(DwBatchDesc d, float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [buf 2][operand 2][plane 3][128][DWS_PITCH]
+  const int item = blockIdx.x / d.splits, sp = blockIdx.x - item * d.splits;
+  const float* G = d.it[item].G;
+  const float* X = d.it[item].X;
+  const int nbeg = sp * d.rows_per_unit, nend = min(d.rows, nbeg + d.rows_per_unit);
+  float* o = slab + (long)blockIdx.x * (16384 + 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // loader role
+  const int opnd = tid >> 8, m = tid & 127, half = (tid >> 7) & 1;
+  const float* src = opnd ? X : G;
+  const long ld = opnd ? d.ldx : d.ldg;
+  unsigned char* wr_base = lds + (size_t)opnd * 3 * DWS_IMG + (size_t)m * DWS_PITCH + half * 32;
+  // consumer role: wave (wo, wi) owns output rows 32 wo .. +31 (two 16-blocks) x columns 64 wi .. +63 (four 16-blocks)
+  const int wo = wave & 3, wi = wave >> 2;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const unsigned char* rdA = lds + (size_t)(32 * wo + n16) * DWS_PITCH + kg * 16;
+  const unsigned char* rdB = lds + (size_t)3 * DWS_IMG + (size_t)(64 * wi + n16) * DWS_PITCH + kg * 16;
+
+  f32x4 accp[8], accn[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { accp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float cs = 0.f;                                      // G loaders: column sum over this thread's rows
+  const int nsteps = (nend - nbeg + 31) / 32;
+
+  float va[16], vb[16];
+#define DWS_LOAD(V_, s_)                                                                     \
+  {                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                         \
+      const int row = nbeg + 32 * (s_) + 16 * half + u;                                      \
+      const bool ok = row < nend;                                                            \
+      const float t = src[(long)(ok ? row : nend - 1) * ld + m];                             \
+      V_[u] = (ok || opnd) ? t : 0.f;                                                        \
+    }                                                                                        \
+  }
+  // one K-step: split this thread's 16 values into the image `buf`, barrier, 48 matrix-core passes into ACC_
+#define DWS_STEP(V_, s_, ACC_, NEG_)                                                         \
+  {                                                                                          \
+    {                                                                                        \
+      float w[16];                                                                           \
+      _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                       \
+        if (!opnd) cs += V_[u];                                                              \
+        w[u] = (NEG_ && !opnd) ? -V_[u] : V_[u];                                             \
+      }                                                                                      \
+      unsigned char* wp = wr_base + (size_t)((s_) & 1) * 6 * DWS_IMG;                        \
+      _Pragma("unroll") for (int h8 = 0; h8 < 2; ++h8) {                                     \
+        const float v8[8] = {w[8 * h8], w[8 * h8 + 1], w[8 * h8 + 2], w[8 * h8 + 3],         \
+                             w[8 * h8 + 4], w[8 * h8 + 5], w[8 * h8 + 6], w[8 * h8 + 7]};    \
+        bf16x8 q1, q2, q3;                                                                   \
+        split3_x8(v8, q1, q2, q3);                                                           \
+        *reinterpret_cast<bf16x8*>(wp + 16 * h8) = q1;                                       \
+        *reinterpret_cast<bf16x8*>(wp + DWS_IMG + 16 * h8) = q2;                             \
+        *reinterpret_cast<bf16x8*>(wp + 2 * DWS_IMG + 16 * h8) = q3;                         \
+      }                                                                                      \
+    }                                                                                        \
+    DWS_LOAD(V_, (s_) + 2)   /* unconditional (rows past the end read a valid row and count as 0): branch-free */ \
+    /* NOT __syncthreads(): its s_waitcnt vmcnt(0) would drain the loads just issued for two K-steps ahead */ \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                            \
+    asm volatile("" ::: "memory");                                                           \
+    {                                                                                        \
+      const unsigned char* pa = rdA + (size_t)((s_) & 1) * 6 * DWS_IMG;                      \
+      const unsigned char* pb = rdB + (size_t)((s_) & 1) * 6 * DWS_IMG;                      \
+      bf16x8 a1[2], a2[2], a3[2];                                                            \
+      _Pragma("unroll") for (int ob = 0; ob < 2; ++ob) {                                     \
+        a1[ob] = *reinterpret_cast<const bf16x8*>(pa + (size_t)16 * ob * DWS_PITCH);         \
+        a2[ob] = *reinterpret_cast<const bf16x8*>(pa + DWS_IMG + (size_t)16 * ob * DWS_PITCH);      \
+        a3[ob] = *reinterpret_cast<const bf16x8*>(pa + 2 * DWS_IMG + (size_t)16 * ob * DWS_PITCH);  \
+      }                                                                                      \
+      _Pragma("unroll") for (int ib = 0; ib < 4; ++ib) {                                     \
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(pb + (size_t)16 * ib * DWS_PITCH);               \
+        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(pb + DWS_IMG + (size_t)16 * ib * DWS_PITCH);     \
+        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(pb + 2 * DWS_IMG + (size_t)16 * ib * DWS_PITCH); \
+        _Pragma("unroll") for (int ob = 0; ob < 2; ++ob) {                                   \
+          f32x4 c = ACC_[4 * ob + ib];                                                       \
+          c = mma16<false>(a3[ob], b1, c);             /* smallest terms first */            \
+          c = mma16<false>(a1[ob], b3, c);                                                   \
+          c = mma16<false>(a2[ob], b2, c);                                                   \
+          c = mma16<false>(a2[ob], b1, c);                                                   \
+          c = mma16<false>(a1[ob], b2, c);                                                   \
+          c = mma16<false>(a1[ob], b1, c);                                                   \
+          ACC_[4 * ob + ib] = c;                                                             \
+        }                                                                                    \
+      }                                                                                      \
+    }                                                                                        \
+  }
+  // Branch-free bodies, an even number of K-steps (a step past the end multiplies zeros): with conditional loads the
+  // compiler's wait-count bookkeeping turns conservative at every merge and drains the loads that are meant to stay in
+  // flight (it did: vmcnt(15) .. (0) where (31) .. (16) was expected)
+  DWS_LOAD(va, 0)
+  DWS_LOAD(vb, 1)
+  for (int s = 0; s < nsteps; s += 2) {
+    DWS_STEP(va, s, accp, false)
+    DWS_STEP(vb, s + 1, accn, true)
+  }
+#undef DWS_LOAD
+#undef DWS_STEP
+  // D layout: lane (n16, kg), register t = out[16 ob + 4 kg + t + 32 wo][16 ib + n16 + 64 wi]
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int orow = 32 * wo + 16 * ob + 4 * kg + t, icol = 64 * wi + 16 * ib + n16;
+        float r = accp[4 * ob + ib][t] - accn[4 * ob + ib][t];
+        asm volatile("" : "+v"(r));                    // keep the subtraction out of v_pk_* (note in edgez.hip)
+        o[orow * 128 + icol] = r;
+      }
+  // column sums of G: the two row halves of a column through LDS (the images are free after the last barrier + reads)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);
+  if (!opnd && half == 1) red[m] = cs;
+  __syncthreads();
+  if (!opnd && half == 0) o[16384 + m] = cs + red[m];
+}
+
 // out[o][i] = sum_s slab[item][s][o][i], bsum[o] = sum_s slab[item][s][16384 + o]; grid (516, n items)
 __global__ __launch_bounds__(256) void rows_dw128_reduce_batch_kernel(const float* __restrict__ slab, DwBatchDesc d) {
   __shared__ float part[8][32];
@@ -200,6 +336,9 @@ __global__ __launch_bounds__(256) void rows_dw128_reduce_kernel(const float* __r
   else if (bsum) bsum[i - (long)nx * 16384] = s;
 }
 
+int bilinear_mode();
+static bool dws_enabled();
+int rows_dw128_batch_launch(DwBatchDesc d, void* ws, size_t ws_bytes, hipStream_t stream);
 static int dw_rows_per_wg(int rows) {
   int rps = cdiv(cdiv(rows, 256), 16) * 16;      // one workgroup per CU, whole 16-row double batches
   return rps < 16 ? 16 : rps;
@@ -232,6 +371,13 @@ int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, floa
     cgat_set_error("rows_dw128: workspace too small (%zu < %zu)", ws_bytes, need);
     return CGAT_ERR_WORKSPACE;
   }
+  if (nx == 1 && bilinear_mode() != 0 && dws_enabled()) {   // split arithmetic modes: the bf16 matrix-core form, as a batch of one
+    DwBatchDesc b;
+    memset(&b, 0, sizeof(b));
+    b.n = 1; b.rows = rows; b.ldg = ldg; b.ldx = ldx1; b.ldo = ldo1;
+    b.it[0] = {G, X1, out1, bsum};
+    return rows_dw128_batch_launch(b, ws, ws_bytes, stream);
+  }
   const int rps = dw_rows_per_wg(rows), splits = cdiv(rows, rps);
   const size_t lds = ((size_t)nx * 16384 + 128) * sizeof(float);
   {
@@ -263,6 +409,11 @@ int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, floa
 }
 
 // ---- batched form ----
+static bool dws_enabled() {                            // CGAT_ROWS_DW_F32=1: the f32-input kernel in every mode (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CGAT_ROWS_DW_F32"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
 static int dw_batch_splits(int n_items, int rows) {
   int sp = 256 / (n_items > 0 ? n_items : 1);          // all units resident at once (one workgroup per CU)
   const int most = cdiv(rows, 64);                     // at least 64 rows per unit
@@ -296,14 +447,25 @@ int rows_dw128_batch_launch(DwBatchDesc d, void* ws, size_t ws_bytes, hipStream_
     cgat_set_error("rows_dw128_batch: workspace too small (%zu < %zu)", ws_bytes, need);
     return CGAT_ERR_WORKSPACE;
   }
+  const bool split_form = bilinear_mode() != 0 && dws_enabled();   // bf16 matrix cores (exact fp32 MFMA in the f32 mode)
   d.splits = dw_batch_splits(d.n, d.rows);
-  d.rows_per_unit = cdiv(cdiv(d.rows, d.splits), 16) * 16;   // whole 16-row double batches
+  d.rows_per_unit = cdiv(cdiv(d.rows, d.splits), 32) * 32;   // whole 32-row K-steps (two 16-row double batches)
   // rounding the unit up to 16 rows can leave trailing units that start past the last row (rows = 650, n = 24: unit 9
   // would start at row 720); the kernel's clamped prologue loads would then read past the operands.  Only units that
   // own a row are launched (never more than the bound above, so the workspace check stands).
   d.splits = cdiv(d.rows, d.rows_per_unit);
   const size_t lds = (16384 + 128) * sizeof(float);
-  {
+  if (split_form) {
+    CGAT_PROF("rows_dw", stream);
+    const size_t lds2 = (size_t)2 * 2 * 3 * DWS_IMG;
+    static bool attr2 = false;
+    if (!attr2) {
+      CGAT_HIP(hipFuncSetAttribute((const void*)rows_dw128_split_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(rows_dw128_split_batch_kernel, dim3(d.n * d.splits), dim3(512), lds2, stream, d, (float*)ws);
+    CGAT_LAUNCH_CHECK();
+  } else {
     CGAT_PROF("rows_dw", stream);
     static bool attr = false;
     if (!attr) {
