@@ -15,7 +15,8 @@ What a captured step may contain: anything built from this package's ops on tens
 forward + backward of a layer or of CGAtNet on a batch of fixed shape (gradients land in the .grad tensors allocated
 during the capture).  What it may not: index validation (a host round trip: `set_validate_indices(False)` or plans
 already cached by the warm-up), the optimiser step (its bias corrections are host scalars), device collation of a
-ragged batch (shapes change)."""
+ragged batch (shapes change).  Outputs of EARLIER eager runs of the same step must not be alive when the capture starts
+(drop them or `.detach()` them): their autograd graph pins AccumulateGrad nodes to the stream the eager run used."""
 import torch
 
 from . import ops
@@ -25,6 +26,8 @@ class GraphedStep:
     def __init__(self, fn, warmup=3, device=None):
         dev = torch.device(device if device is not None else torch.cuda.current_device())
         self.fn = fn
+        import gc
+        gc.collect()                                       # autograd graphs of earlier eager runs (see the module docstring)
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

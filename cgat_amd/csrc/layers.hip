@@ -169,6 +169,7 @@ __global__ void edge_gz_kernel(const float* __restrict__ Z, float* __restrict__ 
 // gS[n] is read once per node instead of gathered per edge; Z is read twice but the second
 // read of a 70 KB segment hits L2.  No atomics; fixed summation order.
 #define SEGB_NODES 8
+#define SEGB_LONG 256   // rows above which the softmax backward of a segment is done by the whole workgroup
 __device__ __forceinline__ float wave_sum_l(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -284,9 +285,29 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   if (tid < (n1 - n0) * H) {
     const int n = n0 + tid / H, h = tid % H;
     const int r0 = rowptr[n], r1 = rowptr[n + 1];
-    float dot = 0.f;
-    for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
-    for (int t = r0; t < r1; ++t) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+    if (r1 - r0 <= SEGB_LONG) {
+      float dot = 0.f;
+      for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
+      for (int t = r0; t < r1; ++t) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+    }
+  }
+  // a long segment (a hub atom: 20 000 incoming edges in the test): the whole workgroup strides over its rows, the dot
+  // product through wavefront + LDS reductions in a fixed order -- one thread walking 2 x 20 000 dependent loads per
+  // head took milliseconds
+  for (int n = n0; n < n1; ++n) {                  // (uniform: every thread sees the same segment lengths)
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    if (r1 - r0 <= SEGB_LONG) continue;
+    __shared__ float red4[4];
+    for (int h = 0; h < H; ++h) {
+      float dot = 0.f;
+      for (int t = r0 + tid; t < r1; t += 256) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
+      dot = wave_sum_l(dot);
+      __syncthreads();
+      if (lane == 0) red4[wave] = dot;
+      __syncthreads();
+      dot = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+      for (int t = r0 + tid; t < r1; t += 256) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+    }
   }
   __syncthreads();
   // ---- 3. gZ rows, their segment sum, partial sums for grad wA_out (a thread keeps its columns for all segments) ----

@@ -81,6 +81,10 @@ def test_graphed_stack_step_equals_eager_bitwise():
     out = step()
     torch.cuda.synchronize()
     want = _snap([out] + [p.grad for p in params])
+    # nothing of the eager step's autograd graph may stay alive into the capture: its AccumulateGrad nodes belong to the
+    # stream the eager step ran on, and a capture that meets them crashes inside the HIP graph runtime (torch warns:
+    # "The AccumulateGrad node's stream does not match ...")
+    del out
     gs = P.GraphedStep(step)
     for _ in range(2):
         y = gs.replay()

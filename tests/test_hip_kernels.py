@@ -335,7 +335,8 @@ def _chain(env, rows, x, layers, in_dact=None, in_dact_type=0, in_store=None):
 
 
 @pytest.mark.parametrize("rows,n,strided", [(1, 1, False), (63, 3, False), (1000, 24, False), (20001, 6, True),
-                                            (83340, 24, False)])
+                                            (83340, 24, False), (650, 24, False), (5000, 6, True)])   # (the last two:
+# row counts whose rounded-up units used to leave trailing units starting past the last row)
 def test_dense_wgrad_batch(env, rows, n, strided):
     """Many nn.Linear weight / bias gradients in one launch (csrc/rowsdw.hip, the batched form): out_i = G_i^T X_i and
     bsum_i = column sums of G_i against fp64, for 1 .. 24 items (the 24 of a hypernetwork backward), shared and distinct
