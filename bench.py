@@ -621,15 +621,32 @@ def layer_step_flops(N, E):
 
 
 def layer_step_bytes(N, E):
-    """(compulsory, executed) HBM bytes of one layer step: SURVEY 8(d)'s 4.0 KB per edge, and the Z-sized passes the
-    implementation actually makes (Z written once and read 1.5 times -- the weighted sum reads its message
-    half, the backward all of it once; the gradient gZ is not stored, one bit per element is written once and read three
-    times; 6 x [N, C] saved per predicted layer, operands of the contractions)."""
-    W2b = 2 * HEADS * 256 * 4
+    """(compulsory, executed, by family) HBM bytes of one layer step.  compulsory = SURVEY 8(d)'s 4.0 KB per edge.
+    executed = what the implementation's kernels move when every operand is read / written once per kernel that touches
+    it (itemised below per kernel family, DESIGN.md §4 compares each line with the rocprofv3 FETCH_SIZE / WRITE_SIZE
+    counters: 41 GB here against 52.8 GB by counters at the benchmark shape -- the difference is the prepared T that
+    every contraction workgroup streams from L2 / Infinity Cache, counted at the fabric, and the gathered reads of
+    edge_gw, for which the gfx950 x2 correction of FETCH_SIZE is not calibrated)."""
+    Z, NC, EC, NW = E * 1536 * 4.0, N * 128 * 4.0, E * 128 * 4.0, N * 1536 * 4.0
+    S, T = N * 768 * 4.0, 3 * 8.4e6                     # per-node message sums; prepared T per contraction launch
+    fam = {
+        "edge_zx (per-edge forward: Z written)": (EC + EC + NW, Z + E * 12),
+        "seg_softmax + seg_wsum (message half of Z read)": (Z / 2 + E * 24, S + E * 12),
+        "edge_seg_bwd (Z read once; sign bits, Gi written)": (Z + S + E * 24, E * 192 + NW + E * 24),
+        "edge_ge x3 (g_e, g_x)": (E * 192 + S + 2 * NW, EC + NC),
+        "edge_gw x3 (dW_e, dW_i, dW_j)": (E * 128 * 6 + E * 192 + S + 2 * NW + N * 1024, 24e6),
+        "edge_gj": (E * 192 + S, NW),
+        "hypernet forward: 4 contractions + slabs + LayerNorm": (4 * (3 * NC + T) + 12 * NC, 12 * NC + 7 * NC),
+        "hypernet backward: 4 fused contractions + finish": (4 * (4 * NC + T) + 24 * NC, 20 * NC + 8 * NC),
+        "weight-gradient contraction + operand preparation": (24 * NC + 8 * NC + 4 * NC + 12 * NC, 4 * 8.4e6 + 8 * NC + 16 * NC),
+        "trunk chains (8 launches)": (24 * NC, 40 * NC),
+        "width-128 dense layers (22 launches)": (22 * NC, 22 * NC),
+        "dense-layer weight gradients (2 batched launches)": (48 * NC + 12 * NC, 0.03e9),
+        "LayerNorm backward, mix, column sums, maxima, T planes": (25 * NC, 5 * NC + 0.8e9),
+    }
     compulsory = 4.0e3 * E
-    executed = (E * W2b * 2.5 + E * (W2b // 32) * 4 + E * C_FEA * 4 * 6 + N * C_FEA * 4 * (4 * 6 * 3 + 4 * 12) +
-                N * W2b * 6)
-    return compulsory, executed
+    executed = sum(r + w for r, w in fam.values())
+    return compulsory, executed, {k: {"read_GB": round(r / 1e9, 2), "write_GB": round(w / 1e9, 2)} for k, (r, w) in fam.items()}
 
 
 def main():
@@ -946,14 +963,15 @@ def main():
         }
         if args.workload == "layer":
             fl = layer_step_flops(N, E)
-            comp, execd = layer_step_bytes(N, E)
+            comp, execd, by_family = layer_step_bytes(N, E)
             out["step_roofline"] = {
                 "what": "the whole step against both roofs: executed-algorithmic flop (each product once) over the step time "
                         "vs the matrix roof of the arithmetic mode, and HBM bytes over the step time vs 8 TB/s",
                 "flop_per_step": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "tflops_peak": round(peak, 1),
                 "tflops_frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
                 "hbm_bytes_compulsory": int(comp), "hbm_frac_compulsory": round(comp / (ms * 1e-3) / 8e12, 4),
-                "hbm_bytes_executed": int(execd), "hbm_frac": round(execd / (ms * 1e-3) / 8e12, 4)}
+                "hbm_bytes_executed": int(execd), "hbm_frac": round(execd / (ms * 1e-3) / 8e12, 4),
+                "hbm_bytes_executed_by_kernel_family": by_family}
             out["modes"] = {"what": "ms per step of the same layer step in each arithmetic mode (this process, after the "
                                     "timed region; `value` is the mode named in bilinear_mode)",
                             **{m: round(v, 3) for m, v in modes_ms.items()},
