@@ -454,16 +454,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   constexpr int HP = NP * 256;                  // 16-byte pieces of one (a, half, k-step) block of the prepared T
   constexpr int CH16 = 2 * HP;                  // per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
   constexpr int PST = 8 * 64;
-  // F16 (16-KB chunks): an 8-slot ring, waits and barriers every SECOND k-step.  A wave's k-step is 24 matrix-core passes
-  // (384 cycles) -- half the forward kernel's, because the 8 waves are 4 row groups x 2 column halves -- so with a
-  // barrier per k-step this kernel paid the rendezvous twice as often per flop as the forward kernel (matrix-core
-  // utilisation 0.51 against 0.68, SQ_WAIT_ANY 31 %).  Groups of two k-steps: the loads of group G + 3 are issued at the
-  // start of group G into the slots group G - 1 was read from (its barrier has passed), and group G ends with the wait
-  // for group G + 2 -- one group more than the next one, because the last k-step of group G + 1 reads its first
-  // fragments of group G + 2 ahead, before that group's own rendezvous.
-  // (The six-pass bf16 form keeps the 4-slot ring: 8 slots of its 24-KB chunks do not fit the LDS.)
-  constexpr int RING = F16 ? 8 : 4;
-  __shared__ uint4 smem[RING * CH16 + 4 * PST / 4];
+  __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kg = lane >> 4;
   const int rg = wave & 3, hf = wave >> 2;      // row group, column half
@@ -479,9 +470,9 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     if (split > 0) init = nullptr;
   }
   const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + RING * CH16 * 16 + wave * 256);
+  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
   const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + hf * HP + lane;
-  const float* pst = reinterpret_cast<const float*>(smem + RING * CH16) + wave * 64 + n16;
+  const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
   p += (long)tile * 128 * ldp;
   const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 128) * ldp * 4);
   const unsigned l_off = (unsigned)lane * 16;
@@ -562,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     const long a_ = gi >> 2, s_ = gi & 3;                                                      \
     const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                       \
     const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                       \
-    const unsigned dst = wave_t + (unsigned)((gi_) & (RING - 1)) * (CH16 * 16);                \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
     glds_b128(h0 + P0, l_off, dst);                                                            \
     glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                          \
     if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                                \
@@ -577,11 +568,6 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   DU_TLOAD((long)a_beg * 4 + 0);
   DU_TLOAD((long)a_beg * 4 + 1);
   DU_TLOAD((long)a_beg * 4 + 2);
-  if constexpr (RING == 8) {                                   // groups 0, 1 and 2 before the loop
-    DU_TLOAD((long)a_beg * 4 + 3);
-    DU_TLOAD((long)a_beg * 4 + 4);
-    DU_TLOAD((long)a_beg * 4 + 5);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -610,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                 \
     DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
   }
-  DU_READ(fa1, fa2, fa3, (RING == 8 ? ((a_beg & 1) << 2) : 0), 0);
+  DU_READ(fa1, fa2, fa3, 0, 0);
   f32x4 part[8];
   // dvp[half][a][row]: the 32 rows of a wave are 128 contiguous bytes per `a` (row-major [row][a] would be 4-byte
   // stores at a 512-byte stride: 12x write amplification, measured with WRITE_SIZE).  32-bit offsets: the launcher
@@ -619,25 +605,17 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   for (int a = a_beg; a < a_end; ++a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int sl0 = RING == 8 ? ((a & 1) << 2) : 0;       // k-step (a, s) sits in ring slot sl0 + s
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if constexpr (RING == 8) {
-        if ((s & 1) == 0) {                      // start of a group of two k-steps: the loads of the group after next
-          DU_TLOAD((long)a * 4 + s + 6);
-          DU_TLOAD((long)a * 4 + s + 7);
-        }
-      } else {
-        DU_TLOAD((long)a * 4 + s + 3);
-      }
+    for (int s = 0; s < 4; ++s) {                // k-step (a, s) sits in ring slot s
+      DU_TLOAD((long)a * 4 + s + 3);
       if (s == 0) DU_PLOAD(a + 2);             // AFTER the T loads: see the wait below
 #pragma unroll
       for (int cbp = 0; cbp < 2; ++cbp) {
-        DU_READ(fb1, fb2, fb3, sl0 + s, 2 * cbp + 1);
+        DU_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
         __builtin_amdgcn_sched_barrier(0);
         DU_MFMA(fa1, fa2, fa3, s, 2 * cbp);
-        if (cbp == 0) DU_READ(fa1, fa2, fa3, sl0 + s, 2)
-        else DU_READ(fa1, fa2, fa3, (sl0 + s + 1) & (RING - 1), 0);
+        if (cbp == 0) DU_READ(fa1, fa2, fa3, s, 2)
+        else DU_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
         __builtin_amdgcn_sched_barrier(0);
         DU_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
       }
@@ -671,25 +649,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
       // the p load + T loads (s = 1), T loads (s = 2), T loads + this `a`'s dv stores (s = 3).  With vmcnt(NP)
       // everywhere the s = 3 wait, whose two youngest operations are the stores, drained the T loads issued a
       // quarter of a microsecond earlier.
-      if constexpr (RING == 8) {
-        // End of a group (s odd): the two chunks of the group AFTER NEXT, issued at the start of the previous group, must
-        // have landed.  Younger than them, in issue order: after s = 1 -- the previous `a`'s two dv stores, this group's
-        // four T loads and the p load = 7; after s = 3 -- the p load of s = 0, this group's four T loads and this `a`'s
-        // two dv stores = 7.  (First `a` of a workgroup: the prologue drained groups 0 .. 2, fewer operations are
-        // outstanding than the allowance and what is needed is complete.)
-        if (s & 1) {
-          wait_vmcnt<7>();
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
-      } else {
-        if (s == 0) wait_vmcnt<NP + 3>();
-        else if (s == 1) wait_vmcnt<NP + 1>();
-        else if (s == 2) wait_vmcnt<NP>();
-        else wait_vmcnt<NP + 2>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
+      if (s == 0) wait_vmcnt<NP + 3>();
+      else if (s == 1) wait_vmcnt<NP + 1>();
+      else if (s == 2) wait_vmcnt<NP>();
+      else wait_vmcnt<NP + 2>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
