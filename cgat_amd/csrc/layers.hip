@@ -431,6 +431,180 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same backward as THREE small kernels (round 3; sign-bit form at Hd = 256, fp32 Z): the three steps of
+// edge_seg_bwd_kernel talk through global memory anyway (tt, ga), and as one kernel it needs 106 VGPRs -- one wave per SIMD
+// beside the side stream's dT workgroups (2 x 192 VGPRs), i.e. a quarter of its occupancy when the two share a CU.  At
+// <= 64 VGPRs two waves per SIMD fit beside them: the HBM-bound passes over Z then run ON the CUs the matrix-bound
+// contraction occupies instead of beside them on the other half of the chip (DESIGN.md §5 Streams).  Same operations in
+// the same order per output element: results are bit-identical to the one-kernel form.
+//   seg_bwd_msg_kernel   step 1: one wave per (segment, head): g_alpha, the message half's sign bits, its share of Gi
+//   seg_bwd_soft_kernel  step 2: softmax backward per (segment, head)
+//   seg_bwd_att_kernel   step 3: the attention half: sign bits, Gi share, partial sums for grad fc_out_A
+__global__ __launch_bounds__(256, 8) void seg_bwd_msg_kernel(const float* __restrict__ Z, const float* __restrict__ alpha,
+                                                             const float* __restrict__ gS, const float* __restrict__ gs,
+                                                             const int* __restrict__ rowptr, int N, int H,
+                                                             float* __restrict__ tt, float* __restrict__ Gi,
+                                                             float* __restrict__ gzmax, unsigned* __restrict__ mask,
+                                                             float* __restrict__ gimax) {
+  constexpr int Hd = 256;
+  const int HHd = H * Hd, W2 = 2 * HHd;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform values are made SCALAR (readfirstlane): the row index, the segment bounds and every row base address then
+  // live in SGPRs -- as vector values they cost the 30 VGPRs that did not fit under the 64 this kernel is built for
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float gm = 0.f, gim_max = 0.f;
+  const long ntask = (long)N * H;
+  for (long task = (long)blockIdx.x * 4 + wave; task < ntask; task += (long)gridDim.x * 4) {
+    const int n = (int)(task / H), h = (int)(task - (long)n * H);
+    const int r0 = __builtin_amdgcn_readfirstlane(rowptr[n]), r1 = __builtin_amdgcn_readfirstlane(rowptr[n + 1]);
+    if (r1 == r0) continue;                        // (seg_bwd_att_kernel zero-fills the whole Gi row of an empty segment)
+    const int wcol = HHd + h * Hd + 4 * lane;
+    const float4 g = *reinterpret_cast<const float4*>(gS + (long)n * HHd + h * Hd + 4 * lane);
+    const float gsn = gs[(long)n * H + h];
+    float4 gim = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tb = r0; tb < r1; tb += 4) {
+      float4 zv[4];
+      float al[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tb + u < r1 ? tb + u : r1 - 1;
+        zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + wcol);
+        al[u] = alpha[(long)t * H + h];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tb + u;
+        if (t < r1) {
+          const float4 z = zv[u];
+          float part = (z.x > 0.f ? z.x : 0.01f * z.x) * g.x + (z.y > 0.f ? z.y : 0.01f * z.y) * g.y +
+                       (z.z > 0.f ? z.z : 0.01f * z.z) * g.z + (z.w > 0.f ? z.w : 0.01f * z.w) * g.w;
+          part = wave_sum_l(part);
+          if (lane == 0) tt[(long)t * H + h] = part + gsn;
+          const float a_ = al[u];
+          const float4 gz = make_float4(a_ * g.x * (z.x > 0.f ? 1.f : 0.01f), a_ * g.y * (z.y > 0.f ? 1.f : 0.01f),
+                                        a_ * g.z * (z.z > 0.f ? 1.f : 0.01f), a_ * g.w * (z.w > 0.f ? 1.f : 0.01f));
+          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(gz.x), fabsf(gz.y))), fmaxf(fabsf(gz.z), fabsf(gz.w)));
+          gim.x += gz.x; gim.y += gz.y; gim.z += gz.z; gim.w += gz.w;
+          unsigned w = ((z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u))
+                       << (4 * (lane & 7));
+          w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+          w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+          w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x141, 0xF, 0xF, true);   // row_half_mirror
+          if ((lane & 7) == 0) mask[(long)t * (W2 >> 5) + (wcol >> 5)] = w;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(Gi + (long)n * W2 + wcol) = gim;
+    gim_max = fmaxf(fmaxf(gim_max, fmaxf(fabsf(gim.x), fabsf(gim.y))), fmaxf(fabsf(gim.z), fabsf(gim.w)));
+  }
+  if (gzmax) block_absmax_commit(gm, gzmax);
+  if (gimax) {
+    __syncthreads();                               // (the commit's staging words are shared by the two calls)
+    block_absmax_commit(gim_max, gimax);
+  }
+}
+
+__global__ __launch_bounds__(256, 8) void seg_bwd_soft_kernel(const float* __restrict__ alpha, const float* __restrict__ tt,
+                                                              const int* __restrict__ rowptr, int N, int H,
+                                                              float* __restrict__ ga) {
+  __shared__ float red4[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * SEGB_NODES, n1 = min(N, n0 + SEGB_NODES);
+  if (tid < (n1 - n0) * H) {
+    const int n = n0 + tid / H, h = tid % H;
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    if (r1 - r0 <= SEGB_LONG) {
+      float dot = 0.f;
+      for (int t = r0; t < r1; ++t) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
+      for (int t = r0; t < r1; ++t) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+    }
+  }
+  for (int n = n0; n < n1; ++n) {                  // long segments: the whole workgroup (see edge_seg_bwd_kernel)
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    if (r1 - r0 <= SEGB_LONG) continue;
+    for (int h = 0; h < H; ++h) {
+      float dot = 0.f;
+      for (int t = r0 + tid; t < r1; t += 256) dot += alpha[(long)t * H + h] * tt[(long)t * H + h];
+      dot = wave_sum_l(dot);
+      __syncthreads();
+      if (lane == 0) red4[wave] = dot;
+      __syncthreads();
+      dot = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+      for (int t = r0 + tid; t < r1; t += 256) ga[(long)t * H + h] = alpha[(long)t * H + h] * (tt[(long)t * H + h] - dot);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 8) void seg_bwd_att_kernel(const float* __restrict__ Z, const float* __restrict__ ga,
+                                                             const int* __restrict__ rowptr,
+                                                             const float* __restrict__ wA_out, int N, int H,
+                                                             float* __restrict__ Gi, float* __restrict__ partialW,
+                                                             float* __restrict__ gzmax, unsigned* __restrict__ mask,
+                                                             float* __restrict__ gimax) {
+  constexpr int Hd = 256;
+  extern __shared__ float pw[];                    // [HHd] per-column partial sums of g_a * leaky(zA)
+  const int HHd = H * Hd, W2 = 2 * HHd;
+  const int tid = threadIdx.x, lane = tid & 63;
+  float gm = 0.f, gim_max = 0.f;
+  for (int c = tid; c < HHd; c += 256) pw[c] = 0.f;
+  __syncthreads();
+  const int n0 = blockIdx.x * SEGB_NODES, n1 = min(N, n0 + SEGB_NODES);
+  for (int n = n0; n < n1; ++n) {
+    const int r0 = __builtin_amdgcn_readfirstlane(rowptr[n]), r1 = __builtin_amdgcn_readfirstlane(rowptr[n + 1]);
+    if (r1 == r0) {  // no incoming edge: zero row of the segment sum (both halves)
+      for (int c = tid; c < W2; c += 256) Gi[(long)n * W2 + c] = 0.f;
+      continue;
+    }
+    for (int c4 = tid; c4 < HHd / 4; c4 += 256) {
+      const int col = 4 * c4;
+      const int h = col / Hd;
+      const float4 wv = *reinterpret_cast<const float4*>(wA_out + col);
+      float4 gi = make_float4(0.f, 0.f, 0.f, 0.f), ps = gi;
+      for (int tb = r0; tb < r1; tb += 4) {
+        float4 zv[4];
+        float cf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = tb + u < r1 ? tb + u : r1 - 1;
+          zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+          cf[u] = ga[(long)t * H + h];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = tb + u;
+          if (t < r1) {
+            const float4 z = zv[u];
+            const float4 d = make_float4(z.x > 0.f ? 1.f : 0.01f, z.y > 0.f ? 1.f : 0.01f, z.z > 0.f ? 1.f : 0.01f,
+                                         z.w > 0.f ? 1.f : 0.01f);
+            const float gav = cf[u];
+            const float4 g = make_float4(gav * wv.x * d.x, gav * wv.y * d.y, gav * wv.z * d.z, gav * wv.w * d.w);
+            ps.x += gav * z.x * d.x; ps.y += gav * z.y * d.y; ps.z += gav * z.z * d.z; ps.w += gav * z.w * d.w;
+            unsigned w = ((z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u))
+                         << (4 * (lane & 7));
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+            w |= (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x141, 0xF, 0xF, true);   // row_half_mirror
+            if ((lane & 7) == 0) mask[(long)t * (W2 >> 5) + (col >> 5)] = w;
+            gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
+            gi.x += g.x; gi.y += g.y; gi.z += g.z; gi.w += g.w;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(Gi + (long)n * W2 + col) = gi;
+      gim_max = fmaxf(fmaxf(gim_max, fmaxf(fabsf(gi.x), fabsf(gi.y))), fmaxf(fabsf(gi.z), fabsf(gi.w)));
+      pw[col] += ps.x; pw[col + 1] += ps.y; pw[col + 2] += ps.z; pw[col + 3] += ps.w;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < HHd; c += 256) partialW[(long)blockIdx.x * HHd + c] = pw[c];
+  if (gzmax) block_absmax_commit(gm, gzmax);
+  if (gimax) {
+    __syncthreads();
+    block_absmax_commit(gim_max, gimax);
+  }
+}
+
 struct AttnDims {
   int N, E, C, Ce, H, Hd, D, HHd, W2;
 };
@@ -444,6 +618,11 @@ static AttnDims attn_dims(const cgat_plan* plan, const cgat_attn_params* p) {
 struct AttnSaved {
   float *Z, *alpha, *S, *ssum;
 };
+static bool seg_bwd_split() {                      // CGAT_SEG_BWD_SPLIT=0: the one-kernel form (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CGAT_SEG_BWD_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
 static AttnSaved attn_saved(float* saved, const AttnDims& d) {
   AttnSaved s;
   s.Z = saved;
@@ -773,6 +952,16 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
       CGAT_CHECK_ARG(rc_shape && have_scales, "nodes_attention_backward: the bf16 edge storage needs the vector form");
       hipLaunchKernelGGL((edge_seg_bwd_kernel<true, true>), dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
                          plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask, gimax);
+    } else if (vec && mask && d.Hd == 256 && seg_bwd_split()) {
+      // three small kernels (<= 64 VGPRs: they co-reside with the side stream's dT workgroups); bit-identical results
+      const long tasks = (long)d.N * d.H;
+      hipLaunchKernelGGL(seg_bwd_msg_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, c.s, sv.Z, sv.alpha, gS, gs,
+                         plan->dst_rowptr, d.N, d.H, tt, Gi, gzmax, mask, gimax);
+      CGAT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_bwd_soft_kernel, dim3(chunks), dim3(256), 0, c.s, sv.alpha, tt, plan->dst_rowptr, d.N, d.H, ga);
+      CGAT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_bwd_att_kernel, dim3(chunks), dim3(256), shm, c.s, sv.Z, ga, plan->dst_rowptr, p->A_out_w, d.N,
+                         d.H, Gi, partial, gzmax, mask, gimax);
     } else if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
                          plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask, gimax);

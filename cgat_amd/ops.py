@@ -327,7 +327,8 @@ def side_stream(device, create=True):
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _side_streams and create:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
+        # CGAT_SIDE_PRIORITY=-1: a high-priority side stream (its workgroups are placed ahead of the main stream's)
+        _side_streams[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("CGAT_SIDE_PRIORITY", "0")))
     return _side_streams.get(key)
 
 
