@@ -119,7 +119,7 @@ PROTOTYPES = {
     "cgat_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "cgat_linear_forward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "cgat_linear_forward": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
+                                      C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
     "cgat_linear_backward": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64,
                                        C.c_int32, vp, C.c_int64, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
                                        C.c_size_t, vp]),
@@ -146,7 +146,7 @@ PROTOTYPES = {
                                      C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
     "cgat_edge_hidden_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32]),
     "cgat_edge_hidden_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32]),
-    "cgat_edge_hidden_forward": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp,
+    "cgat_edge_hidden_forward": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp,
                                            C.c_size_t, vp]),
     "cgat_edge_hidden_backward": (C.c_int, [C.POINTER(Plan), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, C.c_size_t, vp]),

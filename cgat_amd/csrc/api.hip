@@ -109,8 +109,8 @@ extern "C" size_t cgat_linear_forward_workspace_bytes(int32_t M, int32_t K, int3
   return (a > b ? a : b) + 256;
 }
 extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
-                                   float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* ws,
-                                   size_t ws_bytes, void* stream) {
+                                   float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act,
+                                   const float* x_absmax, void* ws, size_t ws_bytes, void* stream) {
   CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0, "linear_forward: negative size");
   hipStream_t s = (hipStream_t)stream;
   const bool have_ws = ws && ws_bytes >= cgat_linear_forward_workspace_bytes(M, K, N);
@@ -118,7 +118,7 @@ extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, 
     if (linear_route_z(K, N, act, ldx, ldy, x, y))
       return linear128_launch(x, ldx, w, ldw, 1, bias, act, 0, y, ldy, M, ws, s, N);
     if (linear_route_ge(K, N, act, ldx, ldy, x, y))
-      return edge_ge_launch(x, ldx, 128, w, 1, ldw, (float*)ws, K, y, ldy, nullptr, M, 0, bias, s);
+      return edge_ge_launch(x, ldx, 128, w, 1, ldw, (float*)ws, K, y, ldy, nullptr, M, 0, bias, s, x_absmax);
   }
   GemmParams g = gemm_params(M, N, K, x, ldx, w, ldw, y, ldy);
   g.bias = bias;

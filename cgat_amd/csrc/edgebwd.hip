@@ -537,12 +537,17 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
                    hipStream_t stream, const float* amax, const EdgeRC* rc) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
-  const bool f16 = bilinear_mode() == 2 && amax && s_out == 1 && (s_col % 4) == 0 && (((uintptr_t)We) & 15) == 0;
+  // f16x3 form: with max |gZ| known, for a weight whose 128 outputs are contiguous (s_out == 1: the backward products)
+  // or whose W2 inputs are (s_col == 1: a forward nn.Linear weight [128, W2], round 3)
+  const bool out_contig = s_out == 1 && (s_col % 4) == 0, in_contig = s_col == 1 && (s_out % 4) == 0 && W2 % 128 == 0;
+  const bool f16 = bilinear_mode() == 2 && amax && (out_contig || in_contig) && (((uintptr_t)We) & 15) == 0;
   // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * s_col + c * s_out]
   if (f16) {   // per-tensor weight scale: max |We| behind the two planes
     float* wmax = Wq + (size_t)ncb * 16384;
     if (hipMemsetAsync(wmax, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
-    CGAT_TRY(absmax_rows128_launch(We, s_col, W2, wmax, stream));
+    if (out_contig) CGAT_TRY(absmax_rows128_launch(We, s_col, W2, wmax, stream));
+    else
+      for (int j = 0; j < ncb; ++j) CGAT_TRY(absmax_rows128_launch(We + 128 * j, s_out, 128, wmax, stream));
     CGAT_TRY(prepare_T_f16_scaled_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, wmax, stream));
   } else {
     CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));

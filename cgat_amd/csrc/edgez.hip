@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
                                                         float* __restrict__ Z, long ldz, int E,
                                                         const float* __restrict__ wA, const float* __restrict__ bA,
                                                         int H, int cb_per_head, float* __restrict__ a_out, int act,
-                                                        int accumulate) {
+                                                        int accumulate, float* __restrict__ omax) {
   constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
   constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
   constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   }
   EZ_READ(fa1, fa2, fa3, 0, 0);
   f32x4 part[8];
-  float dot_a = 0.f, dot_b = 0.f;
+  float dot_a = 0.f, dot_b = 0.f, omx = 0.f;
   const int ncbA = a_out ? H * cb_per_head : 0;      // column blocks that belong to the attention network
   for (int cb = 0; cb < ncb; ++cb) {
 #pragma unroll
@@ -239,6 +239,10 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         // DEEP: unconditional (the allowances count eight stores; clamped rows rewrite identical values)
         if (DEEP || row_a < E) *reinterpret_cast<float4*>(za + col) = va;
         if (DEEP || row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
+        if (omax) {   // (kernel argument: uniform) max |stored value|: the per-tensor fp16 scale of the kernels that read it
+          omx = fmaxf(fmaxf(omx, fmaxf(fabsf(va.x), fabsf(va.y))), fmaxf(fabsf(va.z), fabsf(va.w)));
+          omx = fmaxf(fmaxf(omx, fmaxf(fabsf(vb.x), fabsf(vb.y))), fmaxf(fabsf(vb.z), fabsf(vb.w)));
+        }
         if (isA) {
           const float4 w = *reinterpret_cast<const float4*>(wA + col);
           dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
@@ -268,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 #undef EZ_READ
 #undef EZ_MFMA1
 #undef EZ_MFMA
+  if (omax) block_absmax_commit(omx, omax);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -592,7 +597,8 @@ size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
 // the per-node projections of the operand split.
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
-                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int act) {
+                  int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int act,
+                  float* omax) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
@@ -602,7 +608,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
-                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0)
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax)
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
   else if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
@@ -635,7 +641,8 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
 #define L128_GO(P_)                                                                                                   \
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
                      (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
-                     out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate)
+                     out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate, \
+                     (float*)nullptr)
   if (bilinear_mode() == 2) L128_GO(2); else if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
   CGAT_LAUNCH_CHECK();

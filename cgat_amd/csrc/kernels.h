@@ -110,7 +110,8 @@ int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, lo
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
-                  int act = CGAT_ACT_NONE);
+                  int act = CGAT_ACT_NONE, float* omax = nullptr);
+int absmax_launch(const float* src, long n, float* out, hipStream_t stream);   // zeroes out[0] first
 int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream);  // folds into out[0]
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream);
@@ -226,6 +227,7 @@ int layernorm_tanh_fwd_launch(const float* u, float* y, int rows, int W, float e
 int layernorm_tanh_bwd_launch(const float* u, const float* y, const float* gy, float* gu, int rows, int W, float eps,
                               hipStream_t s);
 int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act, hipStream_t s);  // in terms of post-activation y
+int act_bwd_leaky_max_launch(const float* y, const float* gy, float* gpre, long n, float* gmax, hipStream_t s, bool* used);
 int colsum_launch(const float* x, long ldx, int rows, int cols, float* out, float alpha, void* ws, size_t ws_bytes,
                   hipStream_t s);
 size_t colsum_ws_bytes(int rows, int cols);

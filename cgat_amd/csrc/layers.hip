@@ -764,7 +764,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
                                           float* gWcat, float* gbcat, const float* gZ, long gz_ld, long gzb, float* Gi,
                                           float* Gj, bool have_Gi, const float* x, const float* e, float* g_x, float* g_e,
                                           float* Wq, float* gw_ws, const float* scales = nullptr,
-                                          const EdgeRC* rc = nullptr) {
+                                          const EdgeRC* rc = nullptr, bool node_scales = false) {
   // rc: gZ was not stored; the per-edge launches and the source-side sum rebuild its rows (struct EdgeRC, kernels.h)
   // scales (f16x3 mode, optional): device {max |gZ|, max |e|} -> the per-edge products run on two fp16 planes
   const long xb = (gz_ld == d.W2) ? 0 : gzb;   // block stride for the segment sums; 0 = plain row-major gZ
@@ -775,13 +775,22 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   if (!have_Gi)
     RUN(seg_wsum_launch(gZ, d.W2, nullptr, nullptr, 0, 1, plan->dst_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gi, d.W2, c.s, xb));
   // node-side scales {max |Gi|, max |Gj|, max |x|} at scales[2..4] (rebuilt path in the f16x3 mode, see the caller)
-  const float* ns = (rc && scales && d.C == 128 && (((uintptr_t)x) & 15) == 0) ? scales + 2 : nullptr;
+  const float* ns = ((rc || node_scales) && scales && d.C == 128 && (((uintptr_t)x) & 15) == 0) ? scales + 2 : nullptr;
   if (rc) {
     RUN(edge_gj_launch(*rc, plan->src_rowptr, plan->src_pos, d.N, d.W2, Gj, d.W2, c.s,
                        ns ? const_cast<float*>(ns) + 1 : nullptr));
   } else {
     RUN(seg_wsum_launch(gZ, d.W2, plan->src_pos, nullptr, 0, 1, plan->src_rowptr, d.N, d.W2, CGAT_ACT_NONE, Gj, d.W2,
                         c.s, xb));
+    if (ns && node_scales && !c.dry && d.N > 0 && d.W2 % 128 == 0 && ((((uintptr_t)Gi) | ((uintptr_t)Gj)) & 15) == 0) {
+      // stored-gZ path with scales (vector attention): the segment sums carry no maxima, three passes over [N, .] rows
+      float* w = const_cast<float*>(ns);
+      RUN(absmax_rows128_launch(Gi, 128, (int)((long)d.N * d.W2 / 128), w, c.s));
+      RUN(absmax_rows128_launch(Gj, 128, (int)((long)d.N * d.W2 / 128), w + 1, c.s));
+      RUN(absmax_rows128_launch(x, d.C, d.N, w + 2, c.s));
+    } else if (node_scales) {
+      ns = nullptr;
+    }
   }
   // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
   // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
@@ -1003,7 +1012,7 @@ static AttnDims hidden_dims(const cgat_plan* plan, int C, int Ce, int W2) {
 }
 
 static int edge_hidden_forward_impl(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* w_in,
-                                    const float* b_in, const float* x, const float* e, float* Hout) {
+                                    const float* b_in, const float* x, const float* e, float* Hout, float* hmax) {
   float* Pi = c.take<float>((size_t)d.N * d.W2);
   float* Pj = c.take<float>((size_t)d.N * d.W2);
   float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
@@ -1017,7 +1026,7 @@ static int edge_hidden_forward_impl(Ctx& c, const cgat_plan* plan, const AttnDim
     RUN(edge_z_launch(x, d.C, nullptr, w_in + d.C + d.Ce, d.D, Wq, d.W2, nullptr, nullptr, nullptr, nullptr, 0, Pj, d.W2,
                       d.N, nullptr, nullptr, 1, d.W2 / 2, nullptr, c.s));
     RUN(edge_z_launch(e, d.Ce, plan->dst_perm, w_in + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted, d.W2,
-                      Hout, d.W2, d.E, nullptr, nullptr, 1, d.W2 / 2, nullptr, c.s, CGAT_ACT_LEAKY));
+                      Hout, d.W2, d.E, nullptr, nullptr, 1, d.W2 / 2, nullptr, c.s, CGAT_ACT_LEAKY, hmax));
   } else {
     GemmParams g = gemm_params(d.N, d.W2, d.C, x, d.C, w_in, d.D, Pi, d.W2);
     g.bias = b_in;
@@ -1031,6 +1040,7 @@ static int edge_hidden_forward_impl(Ctx& c, const cgat_plan* plan, const AttnDim
     g.ld_add = d.W2;
     g.act = CGAT_ACT_LEAKY;
     CGAT_TRY(c.gemm(g));
+    if (hmax && !c.dry && d.E > 0) RUN(absmax_launch(Hout, (long)d.E * d.W2, hmax, c.s));   // (zeroes and fills the slot)
   }
   return check_ws(c, "edge_hidden_forward");
 }
@@ -1043,10 +1053,21 @@ static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDi
   float* Gj = c.take<float>((size_t)d.N * d.W2);
   float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
   float* gw_ws = c.take<float>(edge_gw_ws_floats(d.E, d.W2));
+  float* scales = c.take<float>(8);       // f16x3: [0] max |gZ|, [1] max |e|, [2..4] max |Gi|, |Gj|, |x| (set by the tail)
   c.seal();
-  RUN(act_bwd_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, CGAT_ACT_LEAKY, c.s));
+  // f16x3 mode: the LeakyReLU backward also yields max |gZ| and one pass over edge_attr max |e| -- with them the per-edge
+  // products of the tail (K = W2 -> 128 and K = E) run on two fp16 planes (three passes) instead of the six-pass bf16
+  // form they fell back to without scales: 43 + 22 ms of the harness-default network's 252-ms step
+  bool have_scales = false;
+  if (!c.dry && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0 && d.E > 0) {
+    CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
+    RUN(act_bwd_leaky_max_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, scales, c.s, &have_scales));
+    if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
+  } else {
+    RUN(act_bwd_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, CGAT_ACT_LEAKY, c.s));
+  }
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, w_in, g_w_in, g_b_in, gZ, d.W2, 128, Gi, Gj, false, x, e, g_x, g_e, Wq,
-                                          gw_ws));
+                                          gw_ws, have_scales ? scales : nullptr, nullptr, /*node_scales=*/have_scales));
   return check_ws(c, "edge_hidden_backward");
 }
 
@@ -1057,7 +1078,7 @@ static int hidden_check(const cgat_plan* plan, int C, int Ce, int W2) {
 }
 extern "C" size_t cgat_edge_hidden_forward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2) {
   Ctx c(nullptr, 0, true, nullptr);
-  edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), nullptr, nullptr, nullptr, nullptr, nullptr);
+  edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   return c.total();
 }
 extern "C" size_t cgat_edge_hidden_backward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2) {
@@ -1068,14 +1089,15 @@ extern "C" size_t cgat_edge_hidden_backward_workspace_bytes(const cgat_plan* pla
 }
 extern "C" int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in,
                                         const float* b_in, const float* x, const float* edge_attr, float* hidden,
-                                        void* ws, size_t ws_bytes, void* stream) {
+                                        float* hidden_absmax, void* ws, size_t ws_bytes, void* stream) {
   CGAT_TRY(hidden_check(plan, C, Ce, W2));
+  if (hidden_absmax) CGAT_HIP(hipMemsetAsync(hidden_absmax, 0, sizeof(float), (hipStream_t)stream));
   if (ws_bytes < cgat_edge_hidden_forward_workspace_bytes(plan, C, Ce, W2)) {
     cgat_set_error("edge_hidden_forward: workspace too small");
     return CGAT_ERR_WORKSPACE;
   }
   Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
-  return edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), w_in, b_in, x, edge_attr, hidden);
+  return edge_hidden_forward_impl(c, plan, hidden_dims(plan, C, Ce, W2), w_in, b_in, x, edge_attr, hidden, hidden_absmax);
 }
 extern "C" int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in,
                                          const float* x, const float* edge_attr, const float* hidden,

@@ -4,6 +4,7 @@
 // All HBM-bound, one wave per row or grid-stride; accurate tanhf/rsqrtf (no fast-math).
 #include "common.h"
 #include "kernels.h"
+#include "mfma_bf16.h"
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -97,9 +98,44 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
   }
 }
 
+int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act, hipStream_t s);
+// the same with max |gpre| folded into gmax[0] (NOT zeroed here): the per-tensor scale the fp16 forms of the kernels
+// that consume gpre need (vector-attention backward, edge_hidden_backward_impl); 16-byte vectors, n % 4 == 0
+__global__ __launch_bounds__(256) void act_bwd_max_kernel(const float4* __restrict__ y, const float4* __restrict__ gy,
+                                                          float4* __restrict__ gpre, long n4, float* __restrict__ gmax) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float m = 0.f;
+  for (; i < n4; i += stride) {
+    const float4 yv = y[i], g = gy[i];
+    const float4 r = make_float4(g.x * (yv.x > 0.f ? 1.f : 0.01f), g.y * (yv.y > 0.f ? 1.f : 0.01f),
+                                 g.z * (yv.z > 0.f ? 1.f : 0.01f), g.w * (yv.w > 0.f ? 1.f : 0.01f));
+    gpre[i] = r;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+  }
+  block_absmax_commit(m, gmax);
+}
+
 static inline int grid_for(long n) {
   long b = (n + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// LeakyReLU backward + max |gpre| (gmax zeroed by the caller); falls back to the plain kernel (gmax untouched, returns
+// CGAT_ERR_UNSUPPORTED-free: the caller checks `*used`) when the vector form does not apply
+int act_bwd_leaky_max_launch(const float* y, const float* gy, float* gpre, long n, float* gmax, hipStream_t s, bool* used) {
+  *used = false;
+  if (n <= 0) return CGAT_OK;
+  if ((n % 4) != 0 || ((((uintptr_t)y) | ((uintptr_t)gy) | ((uintptr_t)gpre)) & 15) != 0)
+    return act_bwd_launch(y, gy, gpre, n, CGAT_ACT_LEAKY, s);
+  const long n4 = n / 4;
+  long b = (n4 + 255) / 256;
+  const int grid = (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+  hipLaunchKernelGGL(act_bwd_max_kernel, dim3(grid), dim3(256), 0, s, (const float4*)y, (const float4*)gy, (float4*)gpre, n4,
+                     gmax);
+  CGAT_LAUNCH_CHECK();
+  *used = true;
+  return CGAT_OK;
 }
 
 int act_bwd_launch(const float* y, const float* gy, float* gpre, long n, int act, hipStream_t s) {

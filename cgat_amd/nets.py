@@ -156,11 +156,11 @@ def _gatconvedges_message_fast(self, x, edge_attr, plan, drop=0.0):
     # multiplies its first column block with x[edge_index[1]] and its last with x[edge_index[0]]: swap the blocks
     w = torch.cat([w[:, C + Ce:], w[:, C:C + Ce], w[:, :C]], dim=1)
     b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
-    hid = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                                # [E, 2*H*Hd], sorted slots
+    hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                          # [E, 2*H*Hd], sorted slots
     if debug.recording():
         debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
     sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd,
-                                 (a.output_dim, Co))
+                                 (a.output_dim, Co), hmax)
     alpha = sa.exp()
     alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction (CGAT.py:219-221)
     if drop:
@@ -230,13 +230,13 @@ class GATConvNodes(nn.Module):
         D = a.input_dim
         w_in = torch.cat([a.fc_in.weight.reshape(H * Hd, D), m.fc_in.weight.reshape(H * Hd, D)], dim=0)
         b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
-        hid = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                             # [E, 2*H*Hd], sorted slots
+        hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                       # [E, 2*H*Hd], sorted slots
         E = hid.shape[0]
         if debug.recording():
             debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
 
         # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
-        sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co)
+        sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co, hmax)
         sa2, sm2 = sa.reshape(E, -1), sm.reshape(E, -1)
         if E > 0 and AttentionPoolFn.supported(sa2, sm2):
             # channel-wise softmax over each atom's incoming edges, times the message, summed per atom: one kernel per

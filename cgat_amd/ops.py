@@ -262,17 +262,19 @@ class EdgeHiddenFn(torch.autograd.Function):
             raise ValueError("EdgeHiddenFn: shapes do not match the plan / the stacked first-layer weight")
         dev = x.device
         hidden = torch.empty(E, W2, dtype=torch.float32, device=dev)
+        hmax = torch.empty(1, dtype=torch.float32, device=dev)     # max |hidden|: the fp16 scale of the second layers
         ws = workspace(lib.cgat_edge_hidden_forward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
         with torch.cuda.device(dev):
             check(lib.cgat_edge_hidden_forward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(b_in), _ptr(x),
-                                               _ptr(edge_attr), _ptr(hidden), _ptr(ws), ws.numel(), _stream()),
+                                               _ptr(edge_attr), _ptr(hidden), _ptr(hmax), _ptr(ws), ws.numel(), _stream()),
                   "cgat_edge_hidden_forward")
         ctx.plan = plan
         ctx.save_for_backward(x, edge_attr, w_in, hidden)
-        return hidden
+        ctx.mark_non_differentiable(hmax)
+        return hidden, hmax
 
     @staticmethod
-    def backward(ctx, g_hidden):
+    def backward(ctx, g_hidden, _g_hmax=None):
         x, edge_attr, w_in, hidden = ctx.saved_tensors
         plan = ctx.plan
         g_hidden = _f32c(g_hidden)
@@ -486,7 +488,7 @@ class LinearFn(torch.autograd.Function):
         ws = workspace(lib.cgat_linear_forward_workspace_bytes(M, K, N), x.device)
         with torch.cuda.device(x.device):
             check(lib.cgat_linear_forward(_ptr(x), x.stride(0), _ptr(w2), w2.stride(0), _ptr(bb), _ptr(y), N, M, K, N, act,
-                                          _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
+                                          None, _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
         ctx.act, ctx.has_b, ctx.wshape = act, b is not None, w.shape
         ctx.save_for_backward(x, w2, y)
         if act in (_lib.ACT_LEAKY, _lib.ACT_RELU) and debug.recording():
@@ -517,8 +519,9 @@ def _cos(Co, n):
     return tuple(Co) if isinstance(Co, (tuple, list)) else (Co,) * n
 
 
-def _heads_forward(hid, nets, H, Hd, Co):
-    """nets: list of (weight [H*Co, Hd], bias [H*Co] or None); network i reads columns [i*H*Hd, (i+1)*H*Hd) of hid."""
+def _heads_forward(hid, nets, H, Hd, Co, hmax=None):
+    """nets: list of (weight [H*Co, Hd], bias [H*Co] or None); network i reads columns [i*H*Hd, (i+1)*H*Hd) of hid.
+    hmax: device scalar max |hid| (EdgeHiddenFn's second output), which lets the Hd > 128 products run in the f16x3 form."""
     E, W2 = hid.shape
     cos = _cos(Co, len(nets))
     outs = [torch.empty(E, H * co, dtype=torch.float32, device=hid.device) for co in cos]
@@ -531,7 +534,7 @@ def _heads_forward(hid, nets, H, Hd, Co):
                 check(lib.cgat_linear_forward(_ptr(xs), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
                                               None if b is None else _ptr(b[h * Co:(h + 1) * Co]),
                                               _ptr(outs[net][:, h * Co:(h + 1) * Co]), H * Co, E, Hd, Co, _lib.ACT_NONE,
-                                              _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
+                                              _ptr(hmax), _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
     return outs
 
 
@@ -567,14 +570,14 @@ class HeadsLinearFn(torch.autograd.Function):
     a full-size 6 GB gradient per head (21 ms of a 75 ms step at E = 1M)."""
 
     @staticmethod
-    def forward(ctx, hid, wa, ba, wm, bm, H, Hd, Co):
+    def forward(ctx, hid, wa, ba, wm, bm, H, Hd, Co, hmax=None):
         _require_gpu(hid, wa, wm)
         hid = _f32c(hid)
         E = hid.shape[0]
         cos = _cos(Co, 2)                   # (Co may be a pair: scalar attention's MH_A emits one logit per head)
         ws_ = [_f32c(w.detach().reshape(H * co, Hd)) for w, co in zip((wa, wm), cos)]
         bs_ = [None if b is None else _f32c(b.detach()) for b in (ba, bm)]
-        outs = _heads_forward(hid, list(zip(ws_, bs_)), H, Hd, cos)
+        outs = _heads_forward(hid, list(zip(ws_, bs_)), H, Hd, cos, hmax)
         ctx.dims = (H, Hd, cos)
         ctx.shapes = (wa.shape, wm.shape)
         ctx.has_b = (ba is not None, bm is not None)
@@ -586,7 +589,7 @@ class HeadsLinearFn(torch.autograd.Function):
         hid, w0, w1 = ctx.saved_tensors
         H, Hd, Co = ctx.dims
         g_hid, g_w, g_b = _heads_backward(hid, (w0, w1), ctx.has_b, (g_a, g_m), H, Hd, Co, ctx.needs_input_grad[0])
-        return (g_hid, g_w[0].reshape(ctx.shapes[0]), g_b[0], g_w[1].reshape(ctx.shapes[1]), g_b[1], None, None, None)
+        return (g_hid, g_w[0].reshape(ctx.shapes[0]), g_b[0], g_w[1].reshape(ctx.shapes[1]), g_b[1], None, None, None, None)
 
 
 class HeadsLinear1Fn(torch.autograd.Function):

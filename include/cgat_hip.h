@@ -182,7 +182,8 @@ size_t cgat_edge_hidden_forward_workspace_bytes(const cgat_plan* plan, int32_t C
 size_t cgat_edge_hidden_backward_workspace_bytes(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2);
 int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in /* [W2,2C+Ce] */,
                              const float* b_in /* [W2] */, const float* x /* [N,C] */, const float* edge_attr /* [E,Ce] */,
-                             float* hidden /* [E,W2] */, void* ws, size_t ws_bytes, void* stream);
+                             float* hidden /* [E,W2] */, float* hidden_absmax /* out [1], optional: max |hidden| */,
+                             void* ws, size_t ws_bytes, void* stream);
 int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in, const float* x,
                               const float* edge_attr, const float* hidden, const float* g_hidden, float* g_x,
                               float* g_edge_attr, float* g_w_in, float* g_b_in, void* ws, size_t ws_bytes, void* stream);
@@ -241,10 +242,12 @@ int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_params* p, const
  * act: 0 none, 1 tanh, 2 LeakyReLU(0.01), 3 ReLU.  ldx/ldw/ldy are row strides in floats. */
 size_t cgat_linear_forward_workspace_bytes(int32_t M, int32_t K, int32_t N);
 size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N);
-/* ws may be NULL (then the generic f32 GEMM engine is used for every shape) */
+/* ws may be NULL (then the generic f32 GEMM engine is used for every shape).  x_absmax (optional, device pointer to
+ * max |x| over the tensor x is a slice of, e.g. cgat_edge_hidden_forward's hidden_absmax): lets the K > 128 -> 128 route
+ * run in the f16x3 form (three matrix passes) instead of the scale-free six-pass bf16 form */
 int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
-                        int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
-                        void* stream);
+                        int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, const float* x_absmax, void* ws,
+                        size_t ws_bytes, void* stream);
 /* gpre = g_y * act'(y) is written to `gpre` [M,N] (caller buffer); g_x += or = per accumulate_gx */
 int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
                          const float* g_y, int64_t ldgy, float* gpre /* [M,N] dense */, float* g_x, int64_t ldgx,
