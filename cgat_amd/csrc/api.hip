@@ -141,11 +141,42 @@ extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int
   return a + 256;
 }
 
+static int linear_backward_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
+                                int64_t ldy, const float* g_y, int64_t ldgy, float* gpre, float* g_x,
+                                int64_t ldgx, int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b,
+                                int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
+                                void* stream, const float* gx_dact, int64_t ld_dact, float* gx_absmax);
 extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
                                     int64_t ldy, const float* g_y, int64_t ldgy, float* gpre, float* g_x,
                                     int64_t ldgx, int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b,
                                     int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
                                     void* stream) {
+  return linear_backward_impl(x, ldx, w, ldw, y, ldy, g_y, ldgy, gpre, g_x, ldgx, accumulate_gx, g_w, ldgw, g_b, M, K, N, act,
+                              ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+// The same with the input gradient multiplied by LeakyReLU'(0.01) at the sign of gx_dact[M, K] (row stride ld_dact) in
+// the product's epilogue, and max |g_x| folded into gx_absmax[0] (caller-zeroed): when x IS a LeakyReLU output (the hidden
+// layer of MultiHeadNetwork, CGAT.py:96) the result is the gradient of its PRE-activation -- what autograd computes with a
+// separate elementwise pass over [M, K] -- ready for cgat_edge_hidden_backward(g_is_pre = 1).  Supported where g_x runs
+// on the dense-layer kernel (N == 128, K a multiple of 128, split arithmetic modes); CGAT_ERR_UNSUPPORTED otherwise.
+extern "C" int cgat_linear_backward_dact(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* g_y,
+                                         int64_t ldgy, float* g_x, int64_t ldgx, const float* gx_dact, int64_t ld_dact,
+                                         float* gx_absmax, float* g_w, int64_t ldgw, float* g_b, int32_t M, int32_t K,
+                                         int32_t N, void* ws, size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(g_x && gx_dact, "linear_backward_dact: g_x and gx_dact are required");
+  if (!(ws && ws_bytes >= cgat_linear_backward_workspace_bytes(M, K, N) && N == 128 &&
+        linear128_fast(N, K, ldgy, ldgx, g_y, g_x) && (ld_dact % 4) == 0 && (((uintptr_t)gx_dact) & 15) == 0)) {
+    cgat_set_error("linear_backward_dact: needs the dense-layer route (N == 128, K %% 128 == 0, aligned operands, split mode)");
+    return CGAT_ERR_UNSUPPORTED;
+  }
+  return linear_backward_impl(x, ldx, w, ldw, nullptr, N, g_y, ldgy, nullptr, g_x, ldgx, 0, g_w, ldgw, g_b, M, K, N,
+                              CGAT_ACT_NONE, ws, ws_bytes, stream, gx_dact, ld_dact, gx_absmax);
+}
+static int linear_backward_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
+                                int64_t ldy, const float* g_y, int64_t ldgy, float* gpre, float* g_x,
+                                int64_t ldgx, int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b,
+                                int32_t M, int32_t K, int32_t N, int32_t act, void* ws, size_t ws_bytes,
+                                void* stream, const float* gx_dact, int64_t ld_dact, float* gx_absmax) {
   hipStream_t s = (hipStream_t)stream;
   CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0, "linear_backward: negative size");
   const float* gp = g_y;
@@ -160,7 +191,8 @@ extern "C" int cgat_linear_backward(const float* x, int64_t ldx, const float* w,
     const bool have_ws = ws && ws_bytes >= cgat_linear_backward_workspace_bytes(M, K, N);
     if (have_ws && N == 128 && linear128_fast(N, K, ldgp, ldgx, gp, g_x)) {
       // weight seen as out(o = k) x in(n): element W[n * ldw + k]  ->  so = 1, sk = ldw
-      CGAT_TRY(linear128_launch(gp, ldgp, w, 1, ldw, nullptr, CGAT_ACT_NONE, accumulate_gx, g_x, ldgx, M, ws, s, K));
+      CGAT_TRY(linear128_launch(gp, ldgp, w, 1, ldw, nullptr, CGAT_ACT_NONE, accumulate_gx, g_x, ldgx, M, ws, s, K, nullptr,
+                                gx_dact, ld_dact, gx_absmax));
     } else if (have_ws && K == 128 && N > 128 && edge_ge_fast(128, N, ldgp, 128, ldgx, gp, g_x)) {
       // inputs n (N of them) -> 128 outputs k: element (col = n, out = k) at W[n * ldw + k]
       CGAT_TRY(edge_ge_launch(gp, ldgp, 128, w, ldw, 1, (float*)ws, N, g_x, ldgx, nullptr, M, accumulate_gx, nullptr, s));

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
                                                         float* __restrict__ Z, long ldz, int E,
                                                         const float* __restrict__ wA, const float* __restrict__ bA,
                                                         int H, int cb_per_head, float* __restrict__ a_out, int act,
-                                                        int accumulate, float* __restrict__ omax) {
+                                                        int accumulate, float* __restrict__ omax,
+                                                        const float* __restrict__ dact, long ld_dact) {
   constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
   constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
   constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
@@ -230,6 +231,15 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
           if (act == CGAT_ACT_TANH) {
             va = make_float4(tanhf(va.x), tanhf(va.y), tanhf(va.z), tanhf(va.w));
             vb = make_float4(tanhf(vb.x), tanhf(vb.y), tanhf(vb.z), tanhf(vb.w));
+          }
+          if (dact) {   // (kernel argument: uniform) times LeakyReLU'(0.01) at the sign of dact[row, col]: the product IS a
+                        // pre-activation gradient (the per-head second layers' input gradient, vector attention)
+            const float4 ha = *reinterpret_cast<const float4*>(dact + (long)rca * ld_dact + col);
+            const float4 hb = *reinterpret_cast<const float4*>(dact + (long)rcb * ld_dact + col);
+            va = make_float4(va.x * (ha.x > 0.f ? 1.f : 0.01f), va.y * (ha.y > 0.f ? 1.f : 0.01f),
+                             va.z * (ha.z > 0.f ? 1.f : 0.01f), va.w * (ha.w > 0.f ? 1.f : 0.01f));
+            vb = make_float4(vb.x * (hb.x > 0.f ? 1.f : 0.01f), vb.y * (hb.y > 0.f ? 1.f : 0.01f),
+                             vb.z * (hb.z > 0.f ? 1.f : 0.01f), vb.w * (hb.w > 0.f ? 1.f : 0.01f));
           }
           if (accumulate) {
             if (row_a < E) { const float4 u = *reinterpret_cast<const float4*>(za + col); va.x += u.x; va.y += u.y; va.z += u.z; va.w += u.w; }
@@ -608,7 +618,7 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
-                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax)
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr, 0l)
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
   else if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
@@ -629,7 +639,8 @@ bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void
 }
 size_t linear128_ws_bytes(int n_out) { return ws_round((size_t)n_out * 128 * 3 / 2 + 4, 4); }
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
-                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out, const void* prepared) {
+                     float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out, const void* prepared,
+                     const float* dact, long ld_dact, float* omax) {
   if (rows <= 0) return CGAT_OK;
   const int ncb = n_out / 128;
   // operand (a = output block, b = k, c = output in block) = W[(128 a + c) * so + b * sk]
@@ -642,7 +653,7 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
                      (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate, \
-                     (float*)nullptr)
+                     omax, dact, ld_dact)
   if (bilinear_mode() == 2) L128_GO(2); else if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
   CGAT_LAUNCH_CHECK();

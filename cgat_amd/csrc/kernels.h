@@ -133,7 +133,9 @@ bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void
 size_t linear128_ws_bytes(int n_out = 128);
 int linear128_launch(const float* in, long ldi, const float* W, long so, long sk, const float* bias, int act, int accumulate,
                      float* out, long ldo, int rows, void* ws, hipStream_t stream, int n_out = 128,
-                     const void* prepared = nullptr);   // prepared: image from prepare_W_f16_batch_launch (f16x3, n_out 128)
+                     const void* prepared = nullptr,    // prepared: image from prepare_W_f16_batch_launch (f16x3, n_out 128)
+                     const float* dact = nullptr, long ld_dact = 0,   // out *= LeakyReLU'(sign of dact[row, col])
+                     float* omax = nullptr);            // max |out| folded into omax[0] (not zeroed here)
 // ---- a chain of width-128 dense layers in one launch (f16x3 mode), chain.hip ----
 #define CHAIN_MAX 5
 struct ChainLayer {

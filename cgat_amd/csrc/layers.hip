@@ -1047,8 +1047,10 @@ static int edge_hidden_forward_impl(Ctx& c, const cgat_plan* plan, const AttnDim
 
 static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDims& d, const float* w_in, const float* x,
                                      const float* e, const float* Hsaved, const float* g_H, float* g_x, float* g_e,
-                                     float* g_w_in, float* g_b_in) {
-  float* gZ = c.take<float>((size_t)d.E * d.W2);
+                                     float* g_w_in, float* g_b_in, int g_is_pre = 0, const float* gpre_absmax = nullptr) {
+  // g_is_pre: g_H already is the gradient of the PRE-activation (cgat_linear_backward_dact folded LeakyReLU' into the
+  // product that made it) and gpre_absmax[0] its maximum: no elementwise pass, no copy -- the tail reads g_H itself
+  float* gZ = g_is_pre ? const_cast<float*>(g_H) : c.take<float>((size_t)d.E * d.W2);
   float* Gi = c.take<float>((size_t)d.N * d.W2);
   float* Gj = c.take<float>((size_t)d.N * d.W2);
   float* Wq = c.take<float>(edge_z_wq_floats(d.W2));
@@ -1059,13 +1061,20 @@ static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDi
   // products of the tail (K = W2 -> 128 and K = E) run on two fp16 planes (three passes) instead of the six-pass bf16
   // form they fell back to without scales: 43 + 22 ms of the harness-default network's 252-ms step
   bool have_scales = false;
-  if (!c.dry && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0 && d.E > 0) {
+  const bool f16_ok = !c.dry && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0 && d.E > 0;
+  if (g_is_pre) {
+    if (f16_ok && gpre_absmax) {
+      CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
+      CGAT_HIP(hipMemcpyAsync(scales, gpre_absmax, sizeof(float), hipMemcpyDeviceToDevice, c.s));
+      have_scales = true;
+    }
+  } else if (f16_ok) {
     CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
     RUN(act_bwd_leaky_max_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, scales, c.s, &have_scales));
-    if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
   } else {
     RUN(act_bwd_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, CGAT_ACT_LEAKY, c.s));
   }
+  if (have_scales) RUN(absmax_rows128_launch(e, d.Ce, d.E, scales + 1, c.s));
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, w_in, g_w_in, g_b_in, gZ, d.W2, 128, Gi, Gj, false, x, e, g_x, g_e, Wq,
                                           gw_ws, have_scales ? scales : nullptr, nullptr, /*node_scales=*/have_scales));
   return check_ws(c, "edge_hidden_backward");
@@ -1101,8 +1110,9 @@ extern "C" int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_
 }
 extern "C" int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in,
                                          const float* x, const float* edge_attr, const float* hidden,
-                                         const float* g_hidden, float* g_x, float* g_edge_attr, float* g_w_in,
-                                         float* g_b_in, void* ws, size_t ws_bytes, void* stream) {
+                                         const float* g_hidden, int32_t g_is_pre, const float* gpre_absmax, float* g_x,
+                                         float* g_edge_attr, float* g_w_in, float* g_b_in, void* ws, size_t ws_bytes,
+                                         void* stream) {
   CGAT_TRY(hidden_check(plan, C, Ce, W2));
   if (ws_bytes < cgat_edge_hidden_backward_workspace_bytes(plan, C, Ce, W2)) {
     cgat_set_error("edge_hidden_backward: workspace too small");
@@ -1110,7 +1120,7 @@ extern "C" int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32
   }
   Ctx c(ws, ws_bytes, false, (hipStream_t)stream);
   return edge_hidden_backward_impl(c, plan, hidden_dims(plan, C, Ce, W2), w_in, x, edge_attr, hidden, g_hidden, g_x,
-                                   g_edge_attr, g_w_in, g_b_in);
+                                   g_edge_attr, g_w_in, g_b_in, g_is_pre, gpre_absmax);
 }
 
 static int attn_check(const cgat_plan* plan, const cgat_attn_params* p) {

@@ -19,6 +19,7 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
+last_hidden = None      # ops.EdgeHiddenHeadsFn leaves its hidden tensor here while a recorder is active
 _active = None          # the recorder of the innermost `with`, or None (the normal state: every hook is one `is None` test)
 
 

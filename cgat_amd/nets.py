@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import _lib, chunked, debug
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
-from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, get_segment_plan, linear, small_embedding,
+from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, EdgeHiddenHeadsFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, get_segment_plan, linear, small_embedding,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
 from .roost import Roost
@@ -156,11 +156,17 @@ def _gatconvedges_message_fast(self, x, edge_attr, plan, drop=0.0):
     # multiplies its first column block with x[edge_index[1]] and its last with x[edge_index[0]]: swap the blocks
     w = torch.cat([w[:, C + Ce:], w[:, C:C + Ce], w[:, :C]], dim=1)
     b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
-    hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                          # [E, 2*H*Hd], sorted slots
-    if debug.recording():
-        debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
-    sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd,
-                                 (a.output_dim, Co), hmax)
+    if EdgeHiddenHeadsFn.eligible(w.shape[0], H, Hd, (a.output_dim, Co)):
+        sa, sm = EdgeHiddenHeadsFn.apply(x, edge_attr, plan, w, b_in, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight,
+                                         m.fc_out.bias, H, Hd, (a.output_dim, Co))
+        if debug.recording():
+            debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, debug.last_hidden)
+    else:
+        hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w, b_in)                      # [E, 2*H*Hd], sorted slots
+        if debug.recording():
+            debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
+        sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd,
+                                     (a.output_dim, Co), hmax)
     alpha = sa.exp()
     alpha = alpha / alpha.sum(dim=1, keepdim=True)        # normalised over heads, no max-subtraction (CGAT.py:219-221)
     if drop:
@@ -230,13 +236,20 @@ class GATConvNodes(nn.Module):
         D = a.input_dim
         w_in = torch.cat([a.fc_in.weight.reshape(H * Hd, D), m.fc_in.weight.reshape(H * Hd, D)], dim=0)
         b_in = torch.cat([a.fc_in.bias, m.fc_in.bias])
-        hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                       # [E, 2*H*Hd], sorted slots
-        E = hid.shape[0]
-        if debug.recording():
-            debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
-
-        # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
-        sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co, hmax)
+        E = plan.E
+        if EdgeHiddenHeadsFn.eligible(w_in.shape[0], H, Hd, (Co, Co)):
+            # first layers + the 2H second layers as ONE autograd node: its backward folds LeakyReLU' into the second
+            # layers' input-gradient products instead of an elementwise pass over [E, 2 H Hd] (ops.EdgeHiddenHeadsFn)
+            sa, sm = EdgeHiddenHeadsFn.apply(x, edge_attr, plan, w_in, b_in, a.fc_out.weight, a.fc_out.bias,
+                                             m.fc_out.weight, m.fc_out.bias, H, Hd, Co)
+            if debug.recording():
+                debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, debug.last_hidden)
+        else:
+            hid, hmax = EdgeHiddenFn.apply(x, edge_attr, plan, w_in, b_in)                   # [E, 2*H*Hd], sorted slots
+            if debug.recording():
+                debug.note_sorted_hidden((a.fc_in.weight, m.fc_in.weight), plan, hid)
+            # second layers of all 2H heads as one autograd node (ops.HeadsLinearFn): [E,H,Co] each
+            sa, sm = HeadsLinearFn.apply(hid, a.fc_out.weight, a.fc_out.bias, m.fc_out.weight, m.fc_out.bias, H, Hd, Co, hmax)
         sa2, sm2 = sa.reshape(E, -1), sm.reshape(E, -1)
         if E > 0 and AttentionPoolFn.supported(sa2, sm2):
             # channel-wise softmax over each atom's incoming edges, times the message, summed per atom: one kernel per

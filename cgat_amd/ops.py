@@ -285,8 +285,8 @@ class EdgeHiddenFn(torch.autograd.Function):
         ws = workspace(lib.cgat_edge_hidden_backward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
         with torch.cuda.device(dev):
             check(lib.cgat_edge_hidden_backward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(x), _ptr(edge_attr),
-                                                _ptr(hidden), _ptr(g_hidden), _ptr(g_x), _ptr(g_e), _ptr(g_w), _ptr(g_b),
-                                                _ptr(ws), ws.numel(), _stream()), "cgat_edge_hidden_backward")
+                                                _ptr(hidden), _ptr(g_hidden), 0, None, _ptr(g_x), _ptr(g_e), _ptr(g_w),
+                                                _ptr(g_b), _ptr(ws), ws.numel(), _stream()), "cgat_edge_hidden_backward")
         return g_x, g_e, None, g_w, g_b
 
 
@@ -590,6 +590,83 @@ class HeadsLinearFn(torch.autograd.Function):
         H, Hd, Co = ctx.dims
         g_hid, g_w, g_b = _heads_backward(hid, (w0, w1), ctx.has_b, (g_a, g_m), H, Hd, Co, ctx.needs_input_grad[0])
         return (g_hid, g_w[0].reshape(ctx.shapes[0]), g_b[0], g_w[1].reshape(ctx.shapes[1]), g_b[1], None, None, None, None)
+
+
+class EdgeHiddenHeadsFn(torch.autograd.Function):
+    """EdgeHiddenFn followed by HeadsLinearFn as ONE autograd node (vector attention: both networks' first layers on
+    [x_i; edge_attr; x_j], then the 2H per-head second layers; reference CGAT.py:96-109 on the message of 316-318).
+    Same forward kernels; the point is the backward: the second layers' input gradient g_hid = g W is the gradient of a
+    LeakyReLU OUTPUT, and autograd turns it into the pre-activation gradient with an elementwise pass over [E, 2 H Hd]
+    (30 GB per layer at the harness-default shape: 12 % of its step).  Here the product's epilogue multiplies by
+    LeakyReLU'(sign of hidden) and takes the tensor maximum on the way (cgat_linear_backward_dact), and the first
+    layers' backward consumes the result as it is (cgat_edge_hidden_backward, g_is_pre = 1)."""
+
+    @staticmethod
+    def eligible(hid_width, H, Hd, cos):
+        return (get_bilinear_mode() != "f32" and Hd % 128 == 0 and all(co == 128 for co in cos) and
+                hid_width == 2 * H * Hd)
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, plan, w_in, b_in, wa, ba, wm, bm, H, Hd, Co):
+        _require_gpu(x, edge_attr, w_in, b_in, wa, wm)
+        x, edge_attr, w_in, b_in = _f32c(x), _f32c(edge_attr), _f32c(w_in.detach()), _f32c(b_in.detach())
+        N, E = plan.N, plan.E
+        Cn, Ce, W2 = x.shape[1], edge_attr.shape[1], w_in.shape[0]
+        if x.shape[0] != N or edge_attr.shape[0] != E or w_in.shape[1] != 2 * Cn + Ce or b_in.numel() != W2:
+            raise ValueError("EdgeHiddenHeadsFn: shapes do not match the plan / the stacked first-layer weight")
+        dev = x.device
+        hidden = torch.empty(E, W2, dtype=torch.float32, device=dev)
+        hmax = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = workspace(lib.cgat_edge_hidden_forward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
+        with torch.cuda.device(dev):
+            check(lib.cgat_edge_hidden_forward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(b_in), _ptr(x),
+                                               _ptr(edge_attr), _ptr(hidden), _ptr(hmax), _ptr(ws), ws.numel(), _stream()),
+                  "cgat_edge_hidden_forward")
+        cos = _cos(Co, 2)
+        ws_ = [_f32c(w.detach().reshape(H * co, Hd)) for w, co in zip((wa, wm), cos)]
+        bs_ = [None if b is None else _f32c(b.detach()) for b in (ba, bm)]
+        outs = _heads_forward(hidden, list(zip(ws_, bs_)), H, Hd, cos, hmax)
+        ctx.plan, ctx.dims = plan, (H, Hd, cos)
+        ctx.shapes = (wa.shape, wm.shape)
+        ctx.has_b = (ba is not None, bm is not None)
+        ctx.save_for_backward(x, edge_attr, w_in, hidden, ws_[0], ws_[1])
+        if debug.recording():
+            debug.last_hidden = hidden             # the calling module records the derivative pattern under its weights' names
+        return outs[0].reshape(E, H, cos[0]), outs[1].reshape(E, H, cos[1])
+
+    @staticmethod
+    def backward(ctx, g_a, g_m):
+        x, edge_attr, w_in, hidden, w0, w1 = ctx.saved_tensors
+        plan = ctx.plan
+        H, Hd, cos = ctx.dims
+        E, W2 = hidden.shape
+        Cn, Ce = x.shape[1], edge_attr.shape[1]
+        dev = x.device
+        gs = [_f32c(g.reshape(E, H * co)) for g, co in zip((g_a, g_m), cos)]
+        gpre = torch.empty_like(hidden)             # gradient of the PRE-activations, written head by head
+        gmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        g_w = [torch.empty(H * co, Hd, dtype=torch.float32, device=dev) for co in cos]
+        g_b = [torch.empty(H * co, dtype=torch.float32, device=dev) if hb else None for hb, co in zip(ctx.has_b, cos)]
+        ws = workspace(max(lib.cgat_linear_backward_workspace_bytes(E, Hd, co) for co in cos), dev)
+        with torch.cuda.device(dev):
+            for net, w in enumerate((w0, w1)):
+                Co = cos[net]
+                for h in range(H):
+                    col = (net * H + h) * Hd
+                    check(lib.cgat_linear_backward_dact(
+                        _ptr(hidden[:, col:col + Hd]), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
+                        _ptr(gs[net][:, h * Co:(h + 1) * Co]), H * Co, _ptr(gpre[:, col:col + Hd]), W2,
+                        _ptr(hidden[:, col:col + Hd]), W2, _ptr(gmax), _ptr(g_w[net][h * Co:(h + 1) * Co]), Hd,
+                        None if g_b[net] is None else _ptr(g_b[net][h * Co:(h + 1) * Co]), E, Hd, Co,
+                        _ptr(ws), ws.numel(), _stream()), "cgat_linear_backward_dact")
+            g_x, g_e = torch.empty_like(x), torch.empty_like(edge_attr)
+            g_win, g_bin = torch.empty_like(w_in), torch.empty(W2, dtype=torch.float32, device=dev)
+            ws2 = workspace(lib.cgat_edge_hidden_backward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)
+            check(lib.cgat_edge_hidden_backward(C.byref(plan.c), Cn, Ce, W2, _ptr(w_in), _ptr(x), _ptr(edge_attr),
+                                                _ptr(hidden), _ptr(gpre), 1, _ptr(gmax), _ptr(g_x), _ptr(g_e), _ptr(g_win),
+                                                _ptr(g_bin), _ptr(ws2), ws2.numel(), _stream()), "cgat_edge_hidden_backward")
+        return (g_x, g_e, None, g_win, g_bin, g_w[0].reshape(ctx.shapes[0]), g_b[0], g_w[1].reshape(ctx.shapes[1]), g_b[1],
+                None, None, None)
 
 
 class HeadsLinear1Fn(torch.autograd.Function):

@@ -184,9 +184,12 @@ int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_t Ce, int32
                              const float* b_in /* [W2] */, const float* x /* [N,C] */, const float* edge_attr /* [E,Ce] */,
                              float* hidden /* [E,W2] */, float* hidden_absmax /* out [1], optional: max |hidden| */,
                              void* ws, size_t ws_bytes, void* stream);
+/* g_is_pre != 0: g_hidden already is the gradient of the pre-activation (made by cgat_linear_backward_dact, which folds
+ * LeakyReLU' into the product) and gpre_absmax[0] (device, optional) its maximum: no elementwise pass over [E, W2] */
 int cgat_edge_hidden_backward(const cgat_plan* plan, int32_t C, int32_t Ce, int32_t W2, const float* w_in, const float* x,
-                              const float* edge_attr, const float* hidden, const float* g_hidden, float* g_x,
-                              float* g_edge_attr, float* g_w_in, float* g_b_in, void* ws, size_t ws_bytes, void* stream);
+                              const float* edge_attr, const float* hidden, const float* g_hidden, int32_t g_is_pre,
+                              const float* gpre_absmax, float* g_x, float* g_edge_attr, float* g_w_in, float* g_b_in,
+                              void* ws, size_t ws_bytes, void* stream);
 
 /* ---- H_Net_0 / H_Net: hypernetwork Pooling_NN -------------------------------------------
  * replaces CGAT/Hypernetworksmp.py:257-313 (HyperFC of n_hyper predicted layers, each with its
@@ -248,6 +251,15 @@ size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N);
 int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
                         int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, const float* x_absmax, void* ws,
                         size_t ws_bytes, void* stream);
+/* The backward of a bias-free-activation nn.Linear whose INPUT x is itself a LeakyReLU(0.01) output (the hidden layer
+ * of MultiHeadNetwork, CGAT/CGAT.py:96-98): g_x = (g_y W) * LeakyReLU'(sign of gx_dact), i.e. the gradient of the
+ * pre-activation behind x, with max |g_x| folded into gx_absmax[0] (device, caller-zeroed, optional); g_w, g_b as in
+ * cgat_linear_backward.  Needs N == 128 and K a multiple of 128 in a split arithmetic mode (CGAT_ERR_UNSUPPORTED
+ * otherwise: use cgat_linear_backward and an elementwise pass). */
+int cgat_linear_backward_dact(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* g_y, int64_t ldgy,
+                              float* g_x, int64_t ldgx, const float* gx_dact, int64_t ld_dact, float* gx_absmax,
+                              float* g_w, int64_t ldgw, float* g_b, int32_t M, int32_t K, int32_t N, void* ws,
+                              size_t ws_bytes, void* stream);
 /* gpre = g_y * act'(y) is written to `gpre` [M,N] (caller buffer); g_x += or = per accumulate_gx */
 int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
                          const float* g_y, int64_t ldgy, float* gpre /* [M,N] dense */, float* g_x, int64_t ldgx,
