@@ -170,7 +170,7 @@ def test_hub_segment_timing():
         x.grad = e.grad = None
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "r03_hub_timing.json"), "w") as f:
+        with open(os.path.join(out, f"r03_hub_timing_{P.get_bilinear_mode()}.json"), "w") as f:
             json.dump({"what": "GATConvNodes fwd+bwd, N = 20000, E = 240000, ms (median of 3 after 1 warm-up)", **times,
                        "kernel_ms": kernels}, f)
     # the two kernels that were one THREAD / one small workgroup per segment: with the long-segment forms the hub costs

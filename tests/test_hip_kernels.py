@@ -544,6 +544,50 @@ def test_linear_routes(env, M, K, N, act, mode):
     assert rel(gww, rw) <= TOL and rel(gb, rb) <= TOL
 
 
+@pytest.mark.parametrize("M,Hd,mode", [(1000, 256, "f16x3"), (777, 128, "f16x3"), (4099, 256, "bf16x6")])
+def test_linear_backward_dact_and_hidden_maximum(env, M, Hd, mode):
+    """Round 3, vector attention: (i) cgat_linear_backward_dact -- the input gradient of a per-head second layer times
+    LeakyReLU'(sign of the hidden activations) in the product's epilogue, with max |g_x| folded into a device slot, and
+    the weight / bias gradients (K = Hd multiple of 128, N = 128: the batched rows kernel) -- against fp64;
+    (ii) cgat_linear_forward with the tensor maximum of x (the K > 128 -> 128 route in the f16x3 form) against fp64."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(M + Hd)
+        wide = torch.randn(M, 2 * Hd, generator=g).to(dev)           # hidden of two heads; this head = second block
+        hid = torch.where(wide > 0, wide, 0.01 * wide)
+        x = hid[:, Hd:]
+        w = (torch.randn(128, Hd, generator=g) / Hd ** 0.5).to(dev)
+        b = torch.randn(128, generator=g).to(dev)
+        gy_w = torch.randn(M, 256, generator=g).to(dev)
+        gy = gy_w[:, 128:]                                            # strided cotangent slice
+        gpre = torch.zeros(M, 2 * Hd, device=dev)
+        gmax = torch.zeros(1, device=dev)
+        gw, gb = torch.empty(128, Hd, device=dev), torch.empty(128, device=dev)
+        ws = torch.empty(_lib.lib.cgat_linear_backward_workspace_bytes(M, Hd, 128), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.cgat_linear_backward_dact(x.data_ptr(), 2 * Hd, w.data_ptr(), Hd, gy.data_ptr(), 256,
+                                                      gpre[:, Hd:].data_ptr(), 2 * Hd, x.data_ptr(), 2 * Hd, gmax.data_ptr(),
+                                                      gw.data_ptr(), Hd, gb.data_ptr(), M, Hd, 128, ws.data_ptr(), ws.numel(),
+                                                      None), "cgat_linear_backward_dact")
+        torch.cuda.synchronize()
+        xd, wd, gd = x.double(), w.double(), gy.double()
+        want = (gd @ wd) * torch.where(xd > 0, 1.0, 0.01)
+        assert rel(gpre[:, Hd:], want) <= TOL and float(gpre[:, :Hd].abs().max()) == 0.0
+        assert abs(float(gmax) - float(want.abs().max())) <= 1e-5 * float(want.abs().max())
+        assert rel(gw, gd.t() @ xd) <= TOL and rel(gb, gd.sum(0)) <= TOL
+        # (ii) forward with the maximum of the whole hidden tensor
+        hmax = hid.abs().max().reshape(1)
+        y = torch.empty(M, 128, device=dev)
+        ws2 = torch.empty(_lib.lib.cgat_linear_forward_workspace_bytes(M, Hd, 128), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.cgat_linear_forward(x.data_ptr(), 2 * Hd, w.data_ptr(), Hd, b.data_ptr(), y.data_ptr(), 128, M, Hd,
+                                                128, _lib.ACT_NONE, hmax.data_ptr(), ws2.data_ptr(), ws2.numel(), None),
+                   "cgat_linear_forward")
+        torch.cuda.synchronize()
+        assert rel(y, xd @ wd.t() + b.double()) <= TOL
+    finally:
+        ops.set_bilinear_mode(ops.DEFAULT_MODE)
+
+
 @pytest.mark.parametrize("rows", [255, 257, 4099, 83340])
 def test_ring_kernels_race_screen(env, rows):
     """The LDS-DMA ring kernels order their loads with counted vmcnt waits and raw barriers (no compiler help): screen
