@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcgat_hip.so")
 
 MAX_FC = 8
 MAX_HYPER = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_TANH, ACT_LEAKY, ACT_RELU = 0, 1, 2, 3
 

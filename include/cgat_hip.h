@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define CGAT_ABI_VERSION 1
+#define CGAT_ABI_VERSION 2   /* 2: cgat_linear_forward / cgat_edge_hidden_forward / _backward carry tensor maxima (round 3) */
 #define CGAT_MAX_FC 8      /* Linear+Tanh layers per hypernetwork trunk */
 #define CGAT_MAX_HYPER 8   /* predicted layers per hypernetwork */
 
