@@ -517,218 +517,6 @@ __global__ __launch_bounds__(256, 2) void edge_zx_kernel(const float* __restrict
 #undef EX_MFMA
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 3: the same kernel with the weight stream double-buffered PER 64-COLUMN SLICE instead of ringed per k-step.
-// One 8-wave workgroup per CU (256 rows) instead of two 4-wave ones; LDS = two banks of eight 8-KB chunks (128 KB); at the
-// start of a slice every thread issues the eight LDS-DMA loads of the NEXT slice's chunks into the other bank, the
-// eight k-steps of the slice then run with NO wait and NO barrier, and the slice ends -- after its epilogue -- with one
-// counted wait and one barrier.  Why: vmcnt retires in order and counts stores, so in the ring form every ring wait
-// that came after an epilogue had to drain that epilogue's Z stores (~0.85 ms of store latency exposed per launch, header
-// above).  Here the loads a wait is for were issued BEFORE the epilogue's stores of the same slice (they are older: the
-// wait does not involve those stores), and the stores of slice s are next looked at by the wait at the end of slice
-// s + 1, a whole slice (~3 us) after they were issued.  Also: 1 barrier per slice instead of 8, and half the L2 -> LDS
-// weight traffic (each workgroup streams the 1.5 MB of planes once per 256 rows instead of once per 128).
-template <int ABL, bool ZB = false>
-__global__ __launch_bounds__(512, 2) void edge_zx2_kernel(const float* __restrict__ e, long lde,
-                                                         const int* __restrict__ perm, const float* __restrict__ xn,
-                                                         long ldx, const uint4* __restrict__ Wq, int ncb,
-                                                         const float* __restrict__ Pi, const int* __restrict__ dsti,
-                                                         const int* __restrict__ srci, long ld_add,
-                                                         float* __restrict__ Z, long ldz, int E,
-                                                         const float* __restrict__ wA, const float* __restrict__ bA,
-                                                         int H, int cb_per_head, float* __restrict__ a_out) {
-  constexpr int CH16 = 2 * 4 * 64;              // 16-byte pieces per chunk = 8 KB
-  constexpr int RING = 16;                      // two banks of eight chunks: bank = slice parity, slot in bank = k-step
-  __shared__ uint4 smem[RING * CH16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n16 = lane & 15, kg = lane >> 4;
-  const int row_w = blockIdx.x * 256 + wave * 32;
-  const int row_a = row_w + n16, row_b = row_a + 16;
-  const int rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
-  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);   // 512 threads x 16 B = one 8-KB chunk
-  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
-  const unsigned t_off = (unsigned)tid * 16;
-  const long last_chunk = (long)ncb * 16 - 1;
-  const float* wmax = reinterpret_cast<const float*>(Wq + (long)ncb * 16 * CH16);
-
-  // q[plane][2 s + nb]: s < 4 from e[perm[row]], s >= 4 from x[src[row]]
-  bf16x8 q1[16], q2[16];
-  float rs_a, rs_b;
-  {
-    const float* ra[2] = {e + (perm ? (long)perm[rca] : (long)rca) * lde, e + (perm ? (long)perm[rcb] : (long)rcb) * lde};
-    const float* rx[2] = {xn + (long)srci[rca] * ldx, xn + (long)srci[rcb] * ldx};
-    float qv[2][64];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const float4* qp = reinterpret_cast<const float4*>((s < 4 ? ra[nb] : rx[nb]) + 32 * (s & 3) + 8 * kg);
-        const float4 t0 = qp[0], t1 = qp[1];
-        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
-        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
-      }
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      float m = 0.f;
-#pragma unroll
-      for (int j = 0; j < 64; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float sq, iq;
-      pow2_scale(m, sq, iq);
-      if (nb) rs_b = iq; else rs_a = iq;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
-        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
-      }
-    }
-  }
-  const float* pia = Pi + (long)dsti[rca] * ld_add;
-  const float* pib = Pi + (long)dsti[rcb] * ld_add;
-  float* za = Z + (long)rca * ldz;
-  float* zb = Z + (long)rcb * ldz;
-  __bf16* za16 = reinterpret_cast<__bf16*>(Z) + (long)rca * ldz;
-  __bf16* zb16 = reinterpret_cast<__bf16*>(Z) + (long)rcb * ldz;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#define EX_TLOAD(gi_)                                                                          \
-  {                                                                                            \
-    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
-    const uint4* tb = Wq + gi * CH16;                                                          \
-    const unsigned dst = wave_t + (unsigned)((gi_) & (RING - 1)) * (CH16 * 16);                \
-    glds_b128(tb, t_off, dst);                                                                 \
-  }
-#pragma unroll
-  for (int s = 0; s < 8; ++s) EX_TLOAD((long)s);          // slice 0 into bank 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  bf16x8 fa1, fa2, fb1, fb2;
-#define EX_READ(F1_, F2_, slot_, cb_)                                                          \
-  {                                                                                            \
-    const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
-    F1_ = fp[0];                                                                               \
-    F2_ = fp[4 * 64];                                                                          \
-  }
-#define EX_MFMA1(F1_, F2_, qi_, P_)                                                            \
-  {                                                                                            \
-    P_ = mma16<true>(F2_, q1[qi_], P_);                                                        \
-    P_ = mma16<true>(F1_, q2[qi_], P_);                                                        \
-    P_ = mma16<true>(F1_, q1[qi_], P_);                                                        \
-  }
-#define EX_MFMA(F1_, F2_, s_, cb_)                                                             \
-  {                                                                                            \
-    EX_MFMA1(F1_, F2_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                      \
-    EX_MFMA1(F1_, F2_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                      \
-  }
-  EX_READ(fa1, fa2, 0, 0);
-  f32x4 part[8];
-  float dot_a = 0.f, dot_b = 0.f;
-  const int ncbA = a_out ? H * cb_per_head : 0;
-  for (int cb = 0; cb < ncb; ++cb) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int bank = half * 8;                 // slice = 2 cb + half: its parity is `half`
-#pragma unroll
-      for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {                  // chunk (cb, half, s) sits in slot bank + s; no wait, no barrier
-        // one chunk of the NEXT slice per k-step into the other bank (read last during the previous slice; its barrier
-        // has passed): spread over the k-steps so that the LDS-DMA issue hides beside the matrix passes
-        EX_TLOAD((long)cb * 16 + half * 8 + 8 + s);
-#pragma unroll
-        for (int cbp = 0; cbp < 2; ++cbp) {
-          EX_READ(fb1, fb2, bank + s, 2 * cbp + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          EX_MFMA(fa1, fa2, s, 2 * cbp);
-          if (cbp == 0) EX_READ(fa1, fa2, bank + s, 2)
-          else if (s < 7) EX_READ(fa1, fa2, bank + s + 1, 0);   // (s == 7: the next slice's first fragments are read
-          __builtin_amdgcn_sched_barrier(0);                   //  after its rendezvous, below)
-          EX_MFMA(fb1, fb2, s, 2 * cbp + 1);
-        }
-      }
-      {
-        float sw, iw;
-        pow2_scale(wmax[cb], sw, iw);
-        const float ma = rs_a * iw, mb = rs_b * iw;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { part[2 * i + 0] = part[2 * i + 0] * ma; part[2 * i + 1] = part[2 * i + 1] * mb; }
-      }
-      // ---- epilogue of the 64-column slice: z = part + Pi[dst]; store; logits ----
-      const int col0 = cb * 128 + half * 64 + 4 * kg;
-      const bool isA = cb < ncbA;
-      // all Pi loads of the slice before its first store: a load issued after a store cannot be waited for without
-      // draining that store (in-order vmcnt)
-      float4 pia4[4], pib4[4];
-#pragma unroll
-      for (int c16 = 0; c16 < 4; ++c16) {
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        pia4[c16] = (ABL & 2) ? zero4 : *reinterpret_cast<const float4*>(pia + col0 + 16 * c16);
-        pib4[c16] = (ABL & 2) ? zero4 : *reinterpret_cast<const float4*>(pib + col0 + 16 * c16);
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int c16 = 0; c16 < 4; ++c16) {
-        const int col = col0 + 16 * c16;
-        const float4 ia = pia4[c16], ib = pib4[c16];
-        const f32x4 pa = part[2 * c16 + 0], pb = part[2 * c16 + 1];
-        const float4 va = make_float4(pa[0] + ia.x, pa[1] + ia.y, pa[2] + ia.z, pa[3] + ia.w);
-        const float4 vb = make_float4(pb[0] + ib.x, pb[1] + ib.y, pb[2] + ib.z, pb[3] + ib.w);
-        // (non-temporal stores of Z were tried at the end of round 2: 2.77 -> 3.27 ms -- the 64-byte pieces of a row that
-        // four consecutive store instructions write are merged into full lines by L2 only when they allocate there)
-        // no `row < E` guard: the ring's vmcnt allowances count exactly eight stores per epilogue, and a wave whose
-        // second row block lies past the end would skip four of them (lanes past the end hold the clamped row E - 1
-        // and rewrite it with identical values)
-        if constexpr (ZB) {
-          store4_bf16(za16 + col, va);
-          store4_bf16(zb16 + col, vb);
-        } else {
-          if (!(ABL & 1) || va.x == 1234.5f) *reinterpret_cast<float4*>(za + col) = va;
-          if (!(ABL & 1) || vb.x == 1234.5f) *reinterpret_cast<float4*>(zb + col) = vb;
-        }
-        if (isA && !(ABL & 4)) {
-          const float4 w = *reinterpret_cast<const float4*>(wA + col);
-          dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y +
-                   (va.z > 0.f ? va.z : 0.01f * va.z) * w.z + (va.w > 0.f ? va.w : 0.01f * va.w) * w.w;
-          asm volatile("" : "+v"(dot_a));   // keep the two accumulations apart: see the note on packed math above
-          dot_b += (vb.x > 0.f ? vb.x : 0.01f * vb.x) * w.x + (vb.y > 0.f ? vb.y : 0.01f * vb.y) * w.y +
-                   (vb.z > 0.f ? vb.z : 0.01f * vb.z) * w.z + (vb.w > 0.f ? vb.w : 0.01f * vb.w) * w.w;
-          asm volatile("" : "+v"(dot_b));
-        }
-      }
-      if (isA && half == 1 && (cb + 1) % cb_per_head == 0) {
-        const int h = cb / cb_per_head;
-        float da = dot_a, db = dot_b;
-        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
-        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
-        if (kg == 0) {
-          const float bh = bA ? bA[h] : 0.f;
-          if (row_a < E) a_out[(long)row_a * H + h] = da + bh;
-          if (row_b < E) a_out[(long)row_b * H + h] = db + bh;
-        }
-        dot_a = 0.f; dot_b = 0.f;
-      }
-      // End of the slice: the next slice's eight loads (issued at this slice's start) must have landed.  Younger than
-      // them, in issue order: this slice's eight Pi loads and eight Z stores (and, for some slices, two logit stores,
-      // which only make the wait stricter): vmcnt(16).  The stores just issued are not waited for here.
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      EX_READ(fa1, fa2, 8 - bank, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef EX_TLOAD
-#undef EX_READ
-#undef EX_MFMA1
-#undef EX_MFMA
-}
-
 // planes of the two 128 x 128 blocks W_e[a], W_j[a] (element (k, c) = W[(128 a + c) * ldw + k]) under one scale
 __global__ __launch_bounds__(256) void prepare_W2_f16_kernel(const float* __restrict__ We, const float* __restrict__ Wj,
                                                              long ldw, _Float16* __restrict__ dst,
@@ -796,13 +584,8 @@ int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, lo
     default: EZX_GO(0, false); break;
   }
 #else
-  static int v2 = -1;                              // CGAT_EDGE_ZX2=0: the ring form (A/B switch)
-  if (v2 < 0) { const char* ev = getenv("CGAT_EDGE_ZX2"); v2 = (ev && ev[0] == '0') ? 0 : 1; }
-#define EZX2_GO(ZB_) hipLaunchKernelGGL((edge_zx2_kernel<0, ZB_>), dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, x, ldx, (const uint4*)Wq, ncb, Pi, dsti, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out)
-  if (v2) { if (z_bf16) EZX2_GO(true); else EZX2_GO(false); }
-  else if (z_bf16) EZX_GO(0, true);
+  if (z_bf16) EZX_GO(0, true);
   else EZX_GO(0, false);
-#undef EZX2_GO
 #endif
 #undef EZX_GO
   CGAT_LAUNCH_CHECK();
