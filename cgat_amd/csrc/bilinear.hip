@@ -2152,15 +2152,58 @@ size_t bilinear_wgrad_batch_ws_bytes(int n_layers, int nrows, int NA, int NB, in
 // out[l][a,b,c] = sum_n p[l][n,a] q[l][n,b] r[l][n,c] for l < n_layers in ONE launch (f16x3 mode; other modes: one
 // launch per layer).  max_wgs: workgroups of the grid (0 = 256, one per CU; 128 = half of the chip for running beside
 // an HBM-bound kernel on another stream -- every workgroup then walks two units)
+// The operand preparation (maxima, scaled transposes, fp16 planes) of ONE layer -- slot `slot` of an `n_layers` batch --
+// so that a caller whose layers become ready one after the other can issue each layer's share early, on any stream,
+// and finish with bilinear_wgrad_batch_launch(..., prepared = true) on the same workspace.  CGAT_ERR_UNSUPPORTED when
+// the batched f16x3 kernel would not take these operands (the caller then launches unprepared).
+int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, const float* q, long ldq, const float* r,
+                              long ldr, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  if (slot < 0 || slot >= n_layers || ((((uintptr_t)q) | ((uintptr_t)r)) & 15) != 0 || nrows <= 0 || nrows > 8000000 ||
+      !bilinear_wgrad_batch_fast(n_layers, NA, NB, NC, ldq, ldr))
+    return CGAT_ERR_UNSUPPORTED;
+  const int np = cdiv(nrows, 32) * 32;
+  int rps = 0;
+  const int splits = wgrad_batch_pick(n_layers, nrows, NA, &rps);
+  size_t o_pT, o_qT, o_Rq, o_slab, o_mx;
+  const size_t need = wgrad_batch_ws(n_layers, nrows, NA, splits, &o_pT, &o_qT, &o_Rq, &o_slab, &o_mx);
+  if (!ws || ws_bytes < need) {
+    cgat_set_error("bilinear_wgrad_batch_prep: workspace too small (%zu < %zu)", ws_bytes, need);
+    return CGAT_ERR_WORKSPACE;
+  }
+  const long sT = (long)np * 128, sR8 = (long)np * 128 * 2;   // per-layer strides: floats of pT / qT, halves of Rq
+  float* pT = (float*)((char*)ws + o_pT) + (size_t)slot * sT;
+  float* qT = (float*)((char*)ws + o_qT) + (size_t)slot * sT;
+  _Float16* Rq = (_Float16*)((char*)ws + o_Rq) + (size_t)slot * sR8;
+  float* mx = (float*)((char*)ws + o_mx) + 4 * slot;
+  WgradPrepDesc pd;
+  memset(&pd, 0, sizeof(pd));
+  pd.p[0] = p; pd.q[0] = q; pd.r[0] = r;
+  CGAT_HIP(hipMemsetAsync(mx, 0, 16, stream));
+  hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA, mx);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(transpose_pad_batch_kernel, dim3(np / 32, 4, 2), dim3(256), 0, stream, pd, ldp, ldq, nrows, NA, np, rps,
+                     pT, qT, sT, (const float*)mx);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(split_rows_f16_batch_kernel, dim3(cdiv((long)np * 128, 256), 1), dim3(256), 0, stream, pd, ldr, nrows, np,
+                     Rq, sR8, (const float*)mx);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, const float* const* q, long ldq,
                                 const float* const* r, long ldr, float* const* out, int nrows, int NA, int NB, int NC,
-                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs) {
+                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs, bool prepared) {
   if (n_layers <= 0) return CGAT_OK;
   bool aligned = true;
   for (int l = 0; l < n_layers && l < WGB_MAX; ++l)
     aligned = aligned && ((((uintptr_t)q[l]) | ((uintptr_t)r[l])) & 15) == 0;
   // (the q^T tile is fetched with 32-bit lane offsets: 128 rows of rows_pad floats must stay below 4 GB)
   if (!aligned || nrows <= 0 || nrows > 8000000 || !bilinear_wgrad_batch_fast(n_layers, NA, NB, NC, ldq, ldr)) {
+    if (prepared) {
+      cgat_set_error("bilinear_wgrad_batch: prepared operands but not the batched form");
+      return CGAT_ERR_ARG;
+    }
     for (int l = 0; l < n_layers; ++l)
       CGAT_TRY(bilinear_wgrad_launch(p[l], ldp, q[l], ldq, r[l], ldr, out[l], nrows, NA, NB, NC, ws, ws_bytes, stream,
                                      max_wgs > 0 && max_wgs < 256 ? max_wgs / cdiv(NA, 2) : 0));
@@ -2190,15 +2233,18 @@ int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, c
   u.sT = (long)np * 128;
   u.sR = (long)np * 128 * 2 * 2 / 16;
   u.n_layers = n_layers; u.splits = splits; u.npairs = npairs; u.NA = NA; u.rows_pad = np; u.rows_per_split = rps;
-  CGAT_HIP(hipMemsetAsync(mx, 0, 256, stream));
-  hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA, mx);
-  CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(transpose_pad_batch_kernel, dim3(np / 32, 4, 2 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, nrows, NA,
-                     np, rps, pT, qT, u.sT, (const float*)mx);
-  CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(split_rows_f16_batch_kernel, dim3(cdiv((long)np * 128, 256), n_layers), dim3(256), 0, stream, pd, ldr,
-                     nrows, np, Rq, u.sR * 8, (const float*)mx);
-  CGAT_LAUNCH_CHECK();
+  if (!prepared) {
+    CGAT_HIP(hipMemsetAsync(mx, 0, 256, stream));
+    hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA,
+                       mx);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(transpose_pad_batch_kernel, dim3(np / 32, 4, 2 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, nrows,
+                       NA, np, rps, pT, qT, u.sT, (const float*)mx);
+    CGAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(split_rows_f16_batch_kernel, dim3(cdiv((long)np * 128, 256), n_layers), dim3(256), 0, stream, pd, ldr,
+                       nrows, np, Rq, u.sR * 8, (const float*)mx);
+    CGAT_LAUNCH_CHECK();
+  }
   const int units = n_layers * splits * npairs;
   int grid = units < max_wgs ? units : max_wgs;
   {

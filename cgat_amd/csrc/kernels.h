@@ -91,7 +91,11 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
 size_t bilinear_wgrad_batch_ws_bytes(int n_layers, int nrows, int NA, int NB, int NC);
 int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, const float* const* q, long ldq,
                                 const float* const* r, long ldr, float* const* out, int nrows, int NA, int NB, int NC,
-                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs = 0);
+                                void* ws, size_t ws_bytes, hipStream_t stream, int max_wgs = 0, bool prepared = false);
+// one layer's operand preparation for that launch (slot of n_layers), issued separately -- e.g. early, on a side
+// stream; CGAT_ERR_UNSUPPORTED when the batched form does not take the operands
+int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, const float* q, long ldq, const float* r,
+                              long ldr, int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream);
 // three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
 int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
                           hipStream_t stream);

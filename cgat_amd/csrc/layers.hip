@@ -1411,6 +1411,28 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   RUN(fill_launch(g_hin, 0.f, (long)rw, c.s));
   struct { const float *gu, *vin, *z; float* out; } deferred[CGAT_MAX_HYPER];
   int n_deferred = 0;
+  // makes the side stream wait for everything issued on the main stream so far.  Events come from a small ring created
+  // once and never destroyed: under a hipGraph capture (cgat_amd.GraphedStep) the captured dependency keeps referring to
+  // the event object, and destroying it right after the wait -- legal in eager mode -- crashed hipStreamEndCapture on
+  // the second capture of a process.
+  auto side_sync = [&]() -> int {
+    static hipEvent_t ring[64];
+    static unsigned next = 0, made = 0;
+    const unsigned slot = next++ % 64;
+    if (slot >= made) {
+      CGAT_HIP(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming));
+      made = slot + 1;
+    }
+    CGAT_HIP(hipEventRecord(ring[slot], c.s));
+    CGAT_HIP(hipStreamWaitEvent(side->s, ring[slot], 0));
+    return CGAT_OK;
+  };
+  // dT operands are prepared (maxima, scaled transposes, fp16 planes: HBM-bound, 0.25 ms a layer) on the side stream as
+  // soon as a layer's gu exists, beside that layer's matrix-bound contraction on the main stream, so that the dT launch
+  // itself can start the moment this function has issued its last kernel (CGAT_SIDE_EARLY_PREP=0: all at the end)
+  static const bool early_env = [] { const char* e = getenv("CGAT_SIDE_EARLY_PREP"); return !(e && e[0] == '0'); }();
+  bool early_prep = side && !c.dry && early_env;
+  int n_prepped = 0;
   const float* gout = g_y;  // gradient wrt the output of predicted layer l (post norm for l < last)
   for (int l = p->n_hyper - 1; l >= 0; --l) {
     const cgat_hyperlinear_params& L = p->layer[l];
@@ -1427,6 +1449,14 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     // ---- head parameter gradients ----
     // dT[o][i][k] = sum_n gu[n,o] vin[n,i] z[n,k]: deferred, all predicted layers in one launch (end of this function)
     deferred[n_deferred++] = {gu, vin, z, G.head_w};
+    if (early_prep) {
+      CGAT_TRY(side_sync());
+      const int rc_ = bilinear_wgrad_batch_prep(n_deferred - 1, p->n_hyper, gu, W, vin, W, z, W, rows, W, W, W,
+                                                (char*)side->ws + SL.wgrad, side->bytes - SL.wgrad, side->s);
+      if (rc_ == CGAT_OK) ++n_prepped;
+      else if (rc_ == CGAT_ERR_UNSUPPORTED) early_prep = false;
+      else return rc_;
+    }
     // Bm grad [o][i] = gu^T vin, U grad [o][k] = gu^T z, bias grad = column sums of gu: one pass over the three operands
     int fused = -1;
     if (c.dry && defer_dw) fused = 0;
@@ -1539,20 +1569,8 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   bool side_waits = false;   // the side stream has been made to wait for everything issued above
   auto side_wait = [&]() -> int {
     if (side_waits) return CGAT_OK;
-    // Events come from a small ring created once and never destroyed: under a hipGraph capture (cgat_amd.GraphedStep) the
-    // captured dependency keeps referring to the event object, and destroying it right after the wait -- legal in eager
-    // mode -- crashed hipStreamEndCapture on the second capture of a process.
-    static hipEvent_t ring[64];
-    static unsigned next = 0, made = 0;
-    const unsigned slot = next++ % 64;
-    if (slot >= made) {
-      CGAT_HIP(hipEventCreateWithFlags(&ring[slot], hipEventDisableTiming));
-      made = slot + 1;
-    }
-    CGAT_HIP(hipEventRecord(ring[slot], c.s));
-    CGAT_HIP(hipStreamWaitEvent(side->s, ring[slot], 0));
     side_waits = true;
-    return CGAT_OK;
+    return side_sync();
   };
   if (n_deferred > 0) {
     const float *dp[CGAT_MAX_HYPER], *dq[CGAT_MAX_HYPER], *dr[CGAT_MAX_HYPER];
@@ -1563,7 +1581,8 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       // with whatever the caller enqueues next (the HBM-bound attention backward), on `wgrad_wgs` workgroups.
       CGAT_TRY(side_wait());
       CGAT_TRY(bilinear_wgrad_batch_launch(n_deferred, dp, W, dq, W, dr, W, dout, rows, W, W, W,
-                                           (char*)side->ws + SL.wgrad, side->bytes - SL.wgrad, side->s, side->wgrad_wgs));
+                                           (char*)side->ws + SL.wgrad, side->bytes - SL.wgrad, side->s, side->wgrad_wgs,
+                                           early_prep && n_prepped == n_deferred));
     } else {
       CGAT_TRY(c.wgrad_batch(n_deferred, dp, dq, dr, dout, rows, W));
     }
