@@ -106,7 +106,9 @@ extern "C" size_t cgat_linear_forward_workspace_bytes(int32_t M, int32_t K, int3
   (void)M;
   const size_t a = (K == 128 && N % 128 == 0) ? linear128_ws_bytes(N) : 0;
   const size_t b = (N == 128 && K % 128 == 0) ? edge_z_wq_floats(K) * sizeof(float) : 0;
-  return (a > b ? a : b) + 256;
+  const int sk = gemm_pick_splits_skinny(M, N, K);
+  const size_t c = sk > 1 ? ws_round((size_t)sk * M * N, 4) : 0;
+  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) + 256;
 }
 extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                    float* y, int64_t ldy, int32_t M, int32_t K, int32_t N, int32_t act,
@@ -123,7 +125,8 @@ extern "C" int cgat_linear_forward(const float* x, int64_t ldx, const float* w, 
   GemmParams g = gemm_params(M, N, K, x, ldx, w, ldw, y, ldy);
   g.bias = bias;
   g.act = act;
-  return gemm_launch(g, nullptr, 0, s);
+  if (have_ws) g.splits = gemm_pick_splits_skinny(M, N, K);
+  return gemm_launch(g, g.splits > 1 ? ws : nullptr, g.splits > 1 ? ws_bytes : 0, s);
 }
 extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int32_t N) {
   int splits = gemm_pick_splits(N, K, M);
@@ -134,6 +137,10 @@ extern "C" size_t cgat_linear_backward_workspace_bytes(int32_t M, int32_t K, int
   if (K == 128 && N % 128 == 0 && edge_z_wq_floats(N) * sizeof(float) > c) c = edge_z_wq_floats(N) * sizeof(float);
   if (b > a) a = b;
   if (c > a) a = c;
+  {  // g_x on the generic kernel with few output tiles: split over N
+    const int sk = gemm_pick_splits_skinny(M, K, N);
+    if (sk > 1 && ws_round((size_t)sk * M * K, 4) > a) a = ws_round((size_t)sk * M * K, 4);
+  }
   if (K == 128 && N == 128 && rows_dw128_ws_bytes(M, 1) > a) a = rows_dw128_ws_bytes(M, 1);
   if (K % 128 == 0 && N % 128 == 0 && (K / 128) * (N / 128) <= DW_BATCH_MAX &&
       rows_dw128_batch_ws_bytes((K / 128) * (N / 128), M) > a)
@@ -200,7 +207,8 @@ static int linear_backward_impl(const float* x, int64_t ldx, const float* w, int
       GemmParams g = gemm_params(M, K, N, gp, ldgp, w, ldw, g_x, ldgx);
       g.b_kmajor = 1;
       g.beta = accumulate_gx ? 1.f : 0.f;
-      CGAT_TRY(gemm_launch(g, nullptr, 0, s));
+      if (have_ws) g.splits = gemm_pick_splits_skinny(M, K, N);
+      CGAT_TRY(gemm_launch(g, g.splits > 1 ? ws : nullptr, g.splits > 1 ? ws_bytes : 0, s));
     }
   }
   if (g_w && K == 128 && N == 128 && M > 0 && ws && ws_bytes >= rows_dw128_ws_bytes(M, 1) &&

@@ -437,6 +437,19 @@ int gemm_pick_splits(int M, int N, int K) {
   return 8 * best_q;
 }
 
+// Few output tiles and a long reduction -- the G-row networks at the harness' shipped batch of 64 crystals: M = 64 rows
+// against 1024 x 1024 weights = 8 workgroups, each a 32-step dependent load -> LDS -> MFMA chain on an otherwise empty
+// chip (130 us).  K is cut so that every workgroup runs two chunks and the partial tiles are summed in split order by
+// splitk_reduce (which also applies bias / activation / beta): same result whatever else runs, a different -- fixed --
+// summation order than the unsplit product.
+int gemm_pick_splits_skinny(int M, int N, int K) {
+  const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
+  if (tiles > 32 || K < 512) return 1;
+  int s = K / (2 * BK);
+  while (s > 1 && tiles * s > 512) s >>= 1;
+  return s < 2 ? 1 : s;
+}
+
 int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(p.K >= 0, "gemm: K<0");

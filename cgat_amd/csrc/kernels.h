@@ -47,6 +47,8 @@ static inline GemmParams gemm_params(int M, int N, int K, const float* A, long l
 
 int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream);
 int gemm_pick_splits(int M, int N, int K);
+// split count for products with <= 32 output tiles and K >= 512 (1 otherwise): see gemm.hip
+int gemm_pick_splits_skinny(int M, int N, int K);
 // C[m*ldc + n] = act(alpha * sum_z slab[z][m][n] + bias[n]) + beta * C   (fixed summation tree)
 int splitk_reduce_launch(const float* slab, int splits, int M, int N, float* C, long ldc, hipStream_t stream,
                          float alpha = 1.f, float beta = 0.f, const float* bias = nullptr, int act = 0);

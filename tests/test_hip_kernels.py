@@ -507,7 +507,10 @@ def test_segment_softmax(env, F, with_mult):
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 128, 128), (777, 256, 128), (513, 128, 256), (300, 384, 128), (64, 96, 40),
-                                   (1, 128, 128), (17, 128, 128), (83340, 128, 128)])
+                                   (1, 128, 128), (17, 128, 128), (83340, 128, 128),
+                                   # few output tiles, long reduction: the split-K form of the generic engine (the output
+                                   # head at 64 crystals), forward over K and input gradient over N
+                                   (64, 1024, 1024), (64, 1024, 200), (130, 640, 512), (64, 200, 1024)])
 @pytest.mark.parametrize("act", ["none", "leaky", "tanh"])
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
 def test_linear_routes(env, M, K, N, act, mode):
