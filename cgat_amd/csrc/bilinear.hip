@@ -1331,6 +1331,16 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
                          (const float*)ws, sp, stride, nrows, out, ldo);
       CGAT_LAUNCH_CHECK();
     }
+  } else if (!force_generic()) {
+    // Widths other than 128: out = init + (p (x) q) T, the row-wise outer product [nrows, NA * NB] formed in the operand
+    // loader of the fp32 engine (gemm.hip) and T [NA * NB, NC] as it lies: 0.6 ms at 83 340 rows of width 64 where the
+    // one-thread-per-output kernel below took 5.4 (and 850 ms at width 256)
+    if (init && (init != out || ldi != ldo)) CGAT_TRY(copy2d_launch(init, ldi, out, ldo, nrows, NC, stream));
+    GemmParams g = gemm_params(nrows, NC, NA * NB, q, ldq, T, NC, out, ldo);
+    g.b_kmajor = 1;
+    g.a_outer = p; g.ld_a_outer = ldp; g.outer_n = NB;
+    g.beta = init ? 1.f : 0.f;
+    CGAT_TRY(gemm_launch(g, nullptr, 0, stream));
   } else {
     CGAT_PROF("bilinear_rows_generic", stream);
     hipLaunchKernelGGL(bilinear_rows_generic_kernel, dim3(cdiv((long)nrows * NC, 256)), dim3(256), 0, stream, p, ldp,
@@ -2263,6 +2273,10 @@ int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, c
 }
 
 size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
+  if (!(NB == 128 && NC == 128) && nrows > 0 && NA > 0 && NB > 0 && NC > 0) {   // fp32 engine, split over the rows
+    const int sp = gemm_pick_splits(NA, NB * NC, nrows);
+    return sp > 1 ? ws_round((size_t)sp * NA * NB * NC, 4) : 0;
+  }
   if (NB == 128 && NC == 128) {
     size_t a, b, c, d;
     size_t bf = wgrad_bf16_ws(nrows, NA, &a, &b, &c, &d);
@@ -2368,6 +2382,15 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     long n = (long)NA * NB * NC;
     hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const float*)ws, splits, n, out);
     CGAT_LAUNCH_CHECK();
+  } else if (!force_generic()) {
+    // widths other than 128: out [NA, NB * NC] = p^T (q (x) r) on the fp32 engine, rows split over workgroups when the
+    // output has few tiles (33 ms -> 0.7 at 83 340 rows of width 64)
+    GemmParams g = gemm_params(NA, NB * NC, nrows, p, ldp, r, ldr, out, (long)NB * NC);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.b_outer = q; g.ld_b_outer = ldq; g.outer_n = NC;
+    g.splits = gemm_pick_splits(NA, NB * NC, nrows);
+    if (g.splits > 1 && (!ws || ws_bytes < ws_round((size_t)g.splits * NA * NB * NC, 4))) g.splits = 1;
+    CGAT_TRY(gemm_launch(g, ws, ws_bytes, stream));
   } else {
     CGAT_PROF("bilinear_wgrad_generic", stream);
     long n = (long)NA * NB * NC;

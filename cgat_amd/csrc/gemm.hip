@@ -33,7 +33,9 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // Loads one 128 x 32 operand tile into 4 float4 registers per thread.
 //  KM == false : element (r, k) at base[row(r) * ld + k]      (k contiguous)
 //  KM == true  : element (r, k) at base[krow(k) * ld + r]     (r contiguous)
-template <bool KM>
+// OUT: the operand is a row-wise outer product (GemmParams::a_outer / b_outer): the element at flat index j of a row is
+// obase[row * old_ + j / on] * base[row * ld + j % on]; no gather, no blocked layout in that form.
+template <bool KM, bool OUT = false>
 struct TileLoader {
   const float* base;
   long ld;
@@ -46,10 +48,16 @@ struct TileLoader {
   long roff[4];      // !KM: precomputed row offsets (elements), -1 = out of range
   bool fast;         // the whole 128-row tile is in range and 16-byte loads are legal: no per-piece predicates
   long coff;         // KM: precomputed offset of this thread's 4 columns
+  const float* obase;  // OUT: the outer factor, its row stride and the width of the inner factor
+  long old_;
+  int on;
+  long oroff[4];     // OUT, !KM: row offsets into obase
+  int ocol;          // OUT, KM: this thread's column of obase (coff / on; coff then holds coff % on)
 
   __device__ void init(int tid) {
     fast = vec && (r0 + 128 <= R);
     coff = 0;
+    ocol = 0;
     if (!KM) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -58,19 +66,39 @@ struct TileLoader {
         if (r < R) {
           long row = rgather ? (long)rgather[r] : (long)r;
           roff[i] = row * ld;
+          if (OUT) oroff[i] = (long)r * old_;
         } else {
           roff[i] = -1;
+          if (OUT) oroff[i] = 0;
         }
       }
     } else {
       const int r = r0 + 4 * (tid & 31);
       coff = blk ? (long)(r >> 7) * blk + (r & 127) : (long)r;
+      if (OUT) { ocol = r / on; coff = r - ocol * on; }
     }
+  }
+
+  // one element of the outer-product operand: flat index j of row `row` (KM: `row` is the k index)
+  __device__ float outer_at(long row, int j) const {
+    const int a = j / on;
+    return obase[row * old_ + a] * base[row * ld + (j - a * on)];
   }
 
   __device__ void load(int tid, int k0, int kend, float4 (&v)[4]) const {
     if (fast && k0 + 32 <= kend) {  // wave-uniform: interior tile and chunk, straight 16-byte loads
       if (!KM) {
+        if (OUT) {
+          const int kk = k0 + 4 * (tid & 7);
+          const int a = kk / on, b = kk - a * on;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(base + roff[i] + b);
+            const float s = obase[oroff[i] + a];
+            v[i] = make_float4(t.x * s, t.y * s, t.z * s, t.w * s);
+          }
+          return;
+        }
         const long ko = (blk ? (long)(k0 >> 7) * blk + (k0 & 127) : (long)k0) + 4 * (tid & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(base + roff[i] + ko);
@@ -80,7 +108,37 @@ struct TileLoader {
           const int k = k0 + (tid >> 5) + 8 * i;
           const long krow = kgather ? (long)kgather[k] : (long)k;
           v[i] = *reinterpret_cast<const float4*>(base + krow * ld + coff);
+          if (OUT) {
+            const float s = obase[krow * old_ + ocol];
+            v[i] = make_float4(v[i].x * s, v[i].y * s, v[i].z * s, v[i].w * s);
+          }
         }
+      }
+      return;
+    }
+    if (OUT) {   // edges of the outer-product form: element by element
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!KM) {
+          const int k = k0 + 4 * (f & 7);
+          if (roff[i] >= 0) {
+            const long row = r0 + (f >> 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (k + j < kend) t[j] = outer_at(row, k + j);
+          }
+        } else {
+          const int k = k0 + (f >> 5);
+          const int r = r0 + 4 * (f & 31);
+          if (k < kend) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (r + j < R) t[j] = outer_at(k, r + j);
+          }
+        }
+        v[i] = make_float4(t[0], t[1], t[2], t[3]);
       }
       return;
     }
@@ -142,7 +200,8 @@ struct TileLoader {
   }
 };
 
-template <bool AKM, bool BKM, int ABL = 0>  // ABL: timing-only ablations (1 no barrier, 2 no global loads, 4 no LDS stores)
+// ABL: timing-only ablations (1 no barrier, 2 no global loads, 4 no LDS stores); OUTER: 1 = A, 2 = B is an outer product
+template <bool AKM, bool BKM, int ABL = 0, int OUTER = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int PA = AKM ? 132 : 129;
   constexpr int PB = BKM ? 132 : 129;
@@ -187,8 +246,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   const int kbeg = z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
 
-  TileLoader<AKM> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, p.a_block, {0, 0, 0, 0}, false, 0};
-  TileLoader<BKM> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, 0, {0, 0, 0, 0}, false, 0};
+  TileLoader<AKM, OUTER == 1> la{p.A, p.lda, p.M, m0, p.a_rgather, nullptr, p.a_vec != 0, p.a_block, {0, 0, 0, 0}, false, 0,
+                                p.a_outer, p.ld_a_outer, p.outer_n, {0, 0, 0, 0}, 0};
+  TileLoader<BKM, OUTER == 2> lb{p.B, p.ldb, p.N, n0, nullptr, p.b_kgather, p.b_vec != 0, 0, {0, 0, 0, 0}, false, 0,
+                                p.b_outer, p.ld_b_outer, p.outer_n, {0, 0, 0, 0}, 0};
   la.init(tid);
   lb.init(tid);
 
@@ -478,6 +539,14 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   }
   p.a_vec = aligned(p.A, p.lda) ? 1 : 0;
   p.b_vec = aligned(p.B, p.ldb) ? 1 : 0;
+  if (p.a_outer || p.b_outer) {
+    CGAT_CHECK_ARG(p.outer_n > 0 && !(p.a_outer && p.b_outer) && !p.a_rgather && !p.a_block && !p.b_kgather && p.b_kmajor &&
+                       (p.a_outer ? !p.a_kmajor : p.a_kmajor),
+                   "gemm: outer-product operands come as (A outer, row-major; B k-major) or (A k-major; B outer, k-major)");
+    // a 16-byte piece must stay inside one block of the inner factor
+    if (p.a_outer && p.outer_n % 4 != 0) p.a_vec = 0;
+    if (p.b_outer && p.outer_n % 4 != 0) p.b_vec = 0;
+  }
   {
     bool cv = (p.N % 4) == 0;
     if (p.splits > 1) cv = cv && ((((uintptr_t)p.slab) & 15) == 0);
@@ -502,7 +571,9 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
 #else
     const int abl = 0;
 #endif
-    if (abl == 1 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
+    if (p.a_outer) hipLaunchKernelGGL((gemm_f32_kernel<false, true, 0, 1>), grid, dim3(256), 0, stream, p);
+    else if (p.b_outer) hipLaunchKernelGGL((gemm_f32_kernel<true, true, 0, 2>), grid, dim3(256), 0, stream, p);
+    else if (abl == 1 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 1>), grid, dim3(256), 0, stream, p);
     else if (abl == 2 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 2>), grid, dim3(256), 0, stream, p);
     else if (abl == 4 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4>), grid, dim3(256), 0, stream, p);
     else if (abl == 6 && !p.a_kmajor && !p.b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 6>), grid, dim3(256), 0, stream, p);

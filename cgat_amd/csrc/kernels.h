@@ -31,6 +31,14 @@ struct GemmParams {
   long ld_add;
   int act;
   int splits;            // >1: split the K range, partial slabs in workspace, then reduce
+  // Row-wise outer-product (Khatri-Rao) operands: the bilinear contractions at widths other than 128 as plain products
+  //   a_outer (a_kmajor == 0, b_kmajor == 1): A(m,k) = a_outer[m*ld_a_outer + k / outer_n] * A[m*lda + k % outer_n]
+  //   b_outer (a_kmajor == 1, b_kmajor == 1): B(k,n) = b_outer[k*ld_b_outer + n / outer_n] * B[k*ldb + n % outer_n]
+  const float* a_outer;
+  long ld_a_outer;
+  const float* b_outer;
+  long ld_b_outer;
+  int outer_n;
   // filled by gemm_launch
   int k_per_split, a_vec, b_vec, c_vec;
   float* slab;

@@ -130,7 +130,10 @@ def test_gemm_blocked_A(env, kmajor):
     assert rel(Cm, ref) <= TOL
 
 
-@pytest.mark.parametrize("W,rows", [(128, 128), (128, 300), (128, 1), (16, 45), (128, 1000), (128, 83340)])
+@pytest.mark.parametrize("W,rows", [(128, 128), (128, 300), (128, 1), (16, 45), (128, 1000), (128, 83340),
+                                    # other widths: the outer-product operand of the fp32 engine (full tiles, ragged
+                                    # tiles, a width off the 16-byte grid)
+                                    (64, 1000), (96, 333), (22, 130), (256, 130)])
 @pytest.mark.parametrize("with_init", [False, True])
 @pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
 def test_bilinear_rows(env, W, rows, with_init, mode):
@@ -195,7 +198,8 @@ def test_bilinear_dual(env, rows, with_init, mode):
     assert rel(o2[sel], r2) <= TOL
 
 
-@pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45), (128, 33), (128, 20001)])
+@pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45), (128, 33), (128, 20001),
+                                    (64, 20001), (96, 1000), (22, 130), (256, 300)])
 @pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
 def test_bilinear_wgrad(env, W, rows, mode):
     _, _lib, ops, dev = env
