@@ -222,12 +222,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   int tile_m, tile_n, z;
   {
-    const int inner = p.splits > 1 ? tiles_m * tiles_n : tiles_n;
-    const int outer = p.splits > 1 ? p.splits : tiles_m;
+    // (fewer than 8 row tiles: the column tiles are striped instead -- with two row tiles and 512 column tiles, the
+    // weight gradient of a width-256 contraction, the row-striped order put all the work on two of the eight XCDs)
+    const bool swap = p.splits <= 1 && tiles_m < 8 && tiles_n > tiles_m;
+    const int inner = p.splits > 1 ? tiles_m * tiles_n : (swap ? tiles_m : tiles_n);
+    const int outer = p.splits > 1 ? p.splits : (swap ? tiles_n : tiles_m);
     const int L = blockIdx.x;
-    const int j = L >> 3;
-    const int o = (L & 7) + 8 * (j / inner);
-    const int i = j % inner;
+    int o, i;
+    if (outer >= 8) {
+      const int j = L >> 3;
+      o = (L & 7) + 8 * (j / inner);
+      i = j % inner;
+    } else {   // fewer outer indices than XCDs (2..7 K-splits, tiny products): plain order, every XCD gets work
+      o = L % outer;
+      i = L / outer;
+    }
     if (o >= outer) return;
     if (p.splits > 1) {
       z = o;
@@ -235,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
       tile_n = i % tiles_n;
     } else {
       z = 0;
-      tile_m = o;
-      tile_n = i;
+      tile_m = swap ? i : o;
+      tile_n = swap ? o : i;
     }
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -560,9 +569,10 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   }
   // 1-D grid in XCD-striped order (see the kernel): 8 * inner * ceil(outer / 8) workgroups
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
-  const int inner = p.splits > 1 ? tiles_m * tiles_n : tiles_n;
-  const int outer = p.splits > 1 ? p.splits : tiles_m;
-  dim3 grid(8 * inner * cdiv(outer, 8));
+  const bool swap = p.splits <= 1 && tiles_m < 8 && tiles_n > tiles_m;   // (as in the kernel)
+  const int inner = p.splits > 1 ? tiles_m * tiles_n : (swap ? tiles_m : tiles_n);
+  const int outer = p.splits > 1 ? p.splits : (swap ? tiles_n : tiles_m);
+  dim3 grid(outer >= 8 ? 8 * inner * cdiv(outer, 8) : outer * inner);
   {
     CGAT_PROF("gemm_f32", stream);
 #ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/gemm_probe.py
