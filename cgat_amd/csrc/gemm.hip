@@ -573,7 +573,15 @@ int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream) {
   const int inner = p.splits > 1 ? tiles_m * tiles_n : (swap ? tiles_m : tiles_n);
   const int outer = p.splits > 1 ? p.splits : (swap ? tiles_n : tiles_m);
   dim3 grid(outer >= 8 ? 8 * inner * cdiv(outer, 8) : outer * inner);
-  {
+  // split arithmetic modes: the six-pass bf16 form of the same product (gemmsplit.hip; CGAT_GEMM_SPLIT=0: this engine)
+  static const bool split_on = [] { const char* e = getenv("CGAT_GEMM_SPLIT"); return !(e && e[0] == '0'); }();
+  bool on_split = split_on && bilinear_mode() != 0;
+#ifdef CGAT_DEV_ABLATIONS
+  if (getenv("CGAT_GEMM_ABL")) on_split = false;
+#endif
+  if (on_split) {
+    CGAT_TRY(gemm_split_launch(p, grid.x, stream));
+  } else {
     CGAT_PROF("gemm_f32", stream);
 #ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/gemm_probe.py
     const char* ab = getenv("CGAT_GEMM_ABL");

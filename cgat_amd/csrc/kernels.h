@@ -54,6 +54,9 @@ static inline GemmParams gemm_params(int M, int N, int K, const float* A, long l
 }
 
 int gemm_launch(GemmParams p, void* ws, size_t ws_bytes, hipStream_t stream);
+// the same product on the bf16 matrix cores (exact three-plane split, six passes: gemmsplit.hip); called by gemm_launch
+// in the split arithmetic modes with p's derived fields filled in
+int gemm_split_launch(const GemmParams& p, unsigned grid, hipStream_t stream);
 int gemm_pick_splits(int M, int N, int K);
 // split count for products with <= 32 output tiles and K >= 512 (1 otherwise): see gemm.hip
 int gemm_pick_splits_skinny(int M, int N, int K);
