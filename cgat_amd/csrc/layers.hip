@@ -1431,7 +1431,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   // soon as a layer's gu exists, beside that layer's matrix-bound contraction on the main stream, so that the dT launch
   // itself can start the moment this function has issued its last kernel (CGAT_SIDE_EARLY_PREP=0: all at the end)
   static const bool early_env = [] { const char* e = getenv("CGAT_SIDE_EARLY_PREP"); return !(e && e[0] == '0'); }();
-  bool early_prep = side && !c.dry && early_env;
+  bool early_prep = side && !c.dry && early_env && rows >= 16384;   // (small batches: 9 more launches cost more than they hide)
   int n_prepped = 0;
   const float* gout = g_y;  // gradient wrt the output of predicted layer l (post norm for l < last)
   for (int l = p->n_hyper - 1; l >= 0; --l) {
