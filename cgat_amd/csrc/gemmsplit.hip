@@ -2,8 +2,8 @@
 // blocked A, row-wise outer-product operands, split-K slabs, bias / gathered addends / activation / beta epilogue), the
 // same 128 x 128 x 32 workgroup tile and XCD-aware tile order, but the fp32 operands are split EXACTLY into three bf16
 // planes (x = x1 + x2 + x3, mfma_bf16.h) on their way into LDS and the product runs as the six v_mfma_f32_16x16x32_bf16
-// passes whose partial products are >= 2^-24 of the largest (a1b1, a1b2, a2b1, a2b2, a1b3, a3b1; fp32 accumulation,
-// smallest first).  bf16 keeps fp32's exponent, so there are no scales to find and no pre-pass over the operands.
+// passes whose partial products are >= 2^-24 of the largest (a1b1, a1b2, a2b1, a2b2, a1b3, a3b1; smallest first, from a
+// zero accumulator per 32-deep chunk; the chunk sums are added in fp32 by the vector ALU -- see the loop).  bf16 keeps fp32's exponent, so there are no scales to find and no pre-pass over the operands.
 //
 // Why: the f32-input matrix instruction (v_mfma_f32_32x32x2_f32) has a 157 TFLOP/s roof, the six bf16 passes 2 500 / 6
 // = 417.  Everything that is not a width-128 special case runs here -- the G-row networks (output head, Roost, crystal
@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
   }
   const char* ap = As + (wm + i16) * SPITCH + kg * 16;
   const char* bp = Bs + (wn + i16) * SPITCH + kg * 16;
+  // The bf16 matrix instruction's fp32 accumulator rounds with a sign-independent bias (towards -inf-like, ~ -5e-11 of
+  // the running sum per accumulation: DESIGN.md §2, tools/bf16x3_probe.hip), coherent over all outputs of a long
+  // reduction: -1.9e-6 of the result at K = 83 340 when the six passes of every chunk accumulated straight into the
+  // running sum (tools/gemm_engine_probe.py).  So the six passes of a chunk accumulate from ZERO (the instruction only
+  // ever sees a 32-deep partial sum) and the chunk's sum is added to the running sum by the vector ALU, which rounds
+  // to nearest: no bias, and one rounding at full magnitude per chunk instead of six (64 v_add_f32 per 96 passes).
   for (int c = 0; c < nchunks; ++c) {
     la.store(tid, As, ra);
     lb.store(tid, Bs, rb);
@@ -264,20 +270,19 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
       // first operand = the B-tile fragment: the lane then holds C[m = i16][n = 4 kg .. 4 kg + 3] (16-byte epilogue pieces)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        f32x4 t = acc[r][cb];
+        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
         t = mma16<false>(b1, a3[r], t);
         t = mma16<false>(b3, a1[r], t);
         t = mma16<false>(b2, a2[r], t);
         t = mma16<false>(b1, a2[r], t);
         t = mma16<false>(b2, a1[r], t);
         t = mma16<false>(b1, a1[r], t);
-        acc[r][cb] = t;
+        acc[r][cb] += t;
       }
     }
     __syncthreads();
   }
 #undef SCHUNK_K
-
   // ---- epilogue: the accumulator tile through LDS, then row pieces (16-byte where legal) ----
   float* Cbase = p.C;
   const bool slab = p.splits > 1;

@@ -39,9 +39,29 @@ def run(name, M, N, K, akm, bkm, reps=5):
     print(f"{name:40s} {ms:8.3f} ms {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s  err {err:.1e}", flush=True)
 
 
+def bias(M, N, K):
+    """Mean SIGNED relative error of a product of positive operands (every running sum grows with one sign): rounding
+    noise averages out over the M x N outputs, a biased accumulator does not."""
+    g = torch.Generator().manual_seed(1)
+    A = torch.rand(M, K, generator=g).to(dev) + 0.5
+    B = torch.rand(N, K, generator=g).to(dev) + 0.5
+    Cm = torch.empty(M, N, device=dev)
+    d = _lib.GemmDesc()
+    d.alpha, d.beta, d.splits = 1.0, 0.0, 1
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = A.data_ptr(), K, B.data_ptr(), K, Cm.data_ptr(), N
+    _lib.check(_lib.lib.cgat_gemm(C.byref(d), ws.data_ptr(), ws.numel(), None), "bias")
+    torch.cuda.synchronize()
+    ref = A.double() @ B.double().t()
+    rel = (Cm.double() - ref) / ref
+    print(f"signed error of {M}x{N}x{K}, positive operands: mean {float(rel.mean()):+.2e}  rms {float(rel.pow(2).mean().sqrt()):.2e}", flush=True)
+
+
 print("CGAT_GEMM_SPLIT =", os.environ.get("CGAT_GEMM_SPLIT", "(default: on)"))
 for akm in (False, True):
     for bkm in (False, True):
         run(f"8192x4096x4096 akm={int(akm)} bkm={int(bkm)}", 8192, 4096, 4096, akm, bkm)
 run("1000080x1536x128 (per-edge fwd)", 1000080, 1536, 128, False, False, reps=3)
 run("83340x128x4096 (outer-like K)", 83340, 128, 4096, False, True, reps=3)
+bias(2048, 2048, 16384)
+bias(512, 512, 83340)
