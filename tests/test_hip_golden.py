@@ -166,6 +166,24 @@ def test_nodes_layer_other_head_counts_vs_oracle(heads):
                          lambda: O.GATConvNodes(128, 128, 128, heads, concat=True), inputs, call)
 
 
+@pytest.mark.parametrize("C,vector", [(64, False), (96, False), (64, True), (40, False)])
+def test_nodes_layer_other_widths_vs_oracle(C, vector):
+    """Feature widths other than 128 (the harness' --atom-fea-len is free): per-edge products, stored gZ and the
+    hypernetwork's contractions as outer-product operands of the generic engine (gemm.hip / gemmsplit.hip), one layer
+    forward + every gradient against the oracle at the flat tolerance.  40 is off the 16-byte grid of the engine's
+    fast loader (hidden width 80)."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = P.synthetic_batch(30, 20, 12, seed=11)
+    g = torch.Generator().manual_seed(12)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    inputs = {"x": torch.randn(N, C, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, C, generator=g), "x_0": torch.randn(N, C, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(C, C, C, 3, concat=True, vector_attention=vector),
+                         lambda: O.GATConvNodes(C, C, C, 3, concat=True, vector_attention=vector), inputs, call)
+
+
 @pytest.mark.parametrize("first", [True, False])
 def test_nodes_layer_vs_oracle_random_init(first):
     """Config 1 -> 2 of BASELINE.json at a size the oracle finishes in seconds: 60 crystals
