@@ -152,6 +152,14 @@ PROTOTYPES = {
                                             vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "cgat_linear_backward_dact": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp,
                                             vp, C.c_int64, vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t, vp]),
+    "cgat_heads_linear_forward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "cgat_heads_linear_forward": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_int64, vp, C.c_int64,
+                                            C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
+    "cgat_heads_linear_backward_dact_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "cgat_heads_linear_backward_dact": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64,
+                                                  vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64,
+                                                  C.c_int64, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
+                                                  C.c_size_t, vp]),
     "cgat_mt_chunk_elems": (C.c_int32, []),
     "cgat_adamw_step": (C.c_int, [vp, vp, vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int64, vp]),

@@ -179,6 +179,82 @@ extern "C" int cgat_linear_backward_dact(const float* x, int64_t ldx, const floa
   return linear_backward_impl(x, ldx, w, ldw, nullptr, N, g_y, ldgy, nullptr, g_x, ldgx, 0, g_w, ldgw, g_b, M, K, N,
                               CGAT_ACT_NONE, ws, ws_bytes, stream, gx_dact, ld_dact, gx_absmax);
 }
+// ---- the H per-head second layers of one MultiHeadNetwork as ONE call (reference CGAT/CGAT.py:97-98, 103-109: fc_out
+// is a grouped Conv1d, i.e. H independent Linear(Hd, Co) on the H column blocks of the hidden matrix).  Head h works on
+// x + h * s_x, w + h * s_w, bias + h * s_bias, y + h * s_y (strides in elements): with the operands of a head an affine
+// function of h, the whole layer is three launches (batched weight maxima + planes, one product launch with grid.y = h)
+// instead of 4-5 per head -- at the harness' shipped batch (15-30 k edge rows) those launches are 20-40 us each and
+// fill a fraction of the chip.  Shapes the batched kernels do not take run head by head through cgat_linear_forward.
+static bool heads_strides_ok(int64_t a, int64_t b, int64_t c, int64_t d) { return ((a | b | c | d) & 3) == 0; }
+extern "C" size_t cgat_heads_linear_forward_workspace_bytes(int32_t M, int32_t K, int32_t N, int32_t H) {
+  size_t a = cgat_linear_forward_workspace_bytes(M, K, N);
+  if (N == 128 && K % 128 == 0 && H >= 1 && H <= TPREP_MAX) {
+    const size_t b = ((size_t)H * edge_ge_heads_image_floats(K) + bilinear_prepare_T_batch_ws_floats(H)) * sizeof(float) + 256;
+    if (b > a) a = b;
+  }
+  return a;
+}
+extern "C" int cgat_heads_linear_forward(const float* x, int64_t ldx, int64_t s_x, const float* w, int64_t ldw, int64_t s_w,
+                                         const float* bias, int64_t s_bias, float* y, int64_t ldy, int64_t s_y, int32_t M,
+                                         int32_t K, int32_t N, int32_t H, const float* x_absmax, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0 && H >= 0, "heads_linear_forward: negative size");
+  hipStream_t s = (hipStream_t)stream;
+  const bool have_ws = ws && ws_bytes >= cgat_heads_linear_forward_workspace_bytes(M, K, N, H);
+  if (have_ws && H > 1 && N == 128 && K > 128 && heads_strides_ok(s_x, s_w, s_bias, s_y) &&
+      (!bias || (((uintptr_t)bias) & 15) == 0) && edge_ge_heads_fast(H, K, ldx, ldy, ldw, x, w, y, x_absmax))
+    return edge_ge_heads_launch(H, x, ldx, s_x, w, s_w, bias, s_bias, y, ldy, s_y, M, K, (float*)ws, s, x_absmax);
+  for (int h = 0; h < H; ++h)
+    CGAT_TRY(cgat_linear_forward(x + h * s_x, ldx, w + h * s_w, ldw, bias ? bias + h * s_bias : nullptr, y + h * s_y, ldy, M,
+                                 K, N, CGAT_ACT_NONE, x_absmax, ws, ws_bytes, stream));
+  return CGAT_OK;
+}
+// The backward of the same layer with LeakyReLU' of the hidden activations folded in (cgat_linear_backward_dact per
+// head): all heads' input gradients in one launch pair, all heads' weight / bias gradients in one batched launch.
+extern "C" size_t cgat_heads_linear_backward_dact_workspace_bytes(int32_t M, int32_t K, int32_t N, int32_t H) {
+  size_t a = cgat_linear_backward_workspace_bytes(M, K, N);
+  if (N == 128 && K % 128 == 0 && H >= 1 && H * (K / 128) <= DW_BATCH_MAX) {
+    size_t b = (size_t)H * linear128_heads_image_floats(K) * sizeof(float);
+    const size_t c = rows_dw128_batch_ws_bytes(H * (K / 128), M);
+    if (c > b) b = c;
+    if (b + 256 > a) a = b + 256;
+  }
+  return a;
+}
+extern "C" int cgat_heads_linear_backward_dact(const float* x, int64_t ldx, int64_t s_x, const float* w, int64_t ldw,
+                                               int64_t s_w, const float* g_y, int64_t ldgy, int64_t s_gy, float* g_x,
+                                               int64_t ldgx, int64_t s_gx, const float* gx_dact, int64_t ld_dact,
+                                               int64_t s_dact, float* gx_absmax, float* g_w, int64_t ldgw, int64_t s_gw,
+                                               float* g_b, int64_t s_gb, int32_t M, int32_t K, int32_t N, int32_t H,
+                                               void* ws, size_t ws_bytes, void* stream) {
+  CGAT_CHECK_ARG(M >= 0 && K >= 0 && N >= 0 && H >= 0, "heads_linear_backward_dact: negative size");
+  CGAT_CHECK_ARG(g_x && gx_dact && g_w, "heads_linear_backward_dact: g_x, gx_dact and g_w are required");
+  hipStream_t s = (hipStream_t)stream;
+  const bool have_ws = ws && ws_bytes >= cgat_heads_linear_backward_dact_workspace_bytes(M, K, N, H);
+  const int kb = K / 128;
+  if (have_ws && H > 1 && M > 0 && bilinear_mode() == 2 && N == 128 && K % 128 == 0 && H * kb <= DW_BATCH_MAX &&
+      heads_strides_ok(s_x, s_w, s_gy, s_gx) && heads_strides_ok(s_dact, s_gw, s_gb, ld_dact) &&
+      linear128_fast(N, K, ldgy, ldgx, g_y, g_x) && (((uintptr_t)gx_dact) & 15) == 0) {
+    DwBatchDesc b;
+    memset(&b, 0, sizeof(b));
+    b.rows = M; b.ldg = ldgy; b.ldx = ldx; b.ldo = ldgw;
+    for (int h = 0; h < H; ++h)
+      for (int j = 0; j < kb; ++j)
+        b.it[b.n++] = {g_y + h * s_gy, x + h * s_x + 128 * j, g_w + h * s_gw + 128 * j,
+                       (g_b && j == 0) ? g_b + h * s_gb : nullptr};
+    if (rows_dw128_batch_fast(b)) {
+      // weight seen as out(o = k) x in(n): element W_h[n * ldw + k]  ->  so = 1, sk = ldw
+      CGAT_TRY(linear128_heads_launch(H, g_y, ldgy, s_gy, w, 1, ldw, s_w, nullptr, 0, CGAT_ACT_NONE, 0, g_x, ldgx, s_gx, M, ws,
+                                      s, K, gx_dact, ld_dact, s_dact, gx_absmax));
+      return rows_dw128_batch_launch(b, ws, ws_bytes, s);
+    }
+  }
+  for (int h = 0; h < H; ++h)
+    CGAT_TRY(cgat_linear_backward_dact(x + h * s_x, ldx, w + h * s_w, ldw, g_y + h * s_gy, ldgy, g_x + h * s_gx, ldgx,
+                                       gx_dact + h * s_dact, ld_dact, gx_absmax, g_w + h * s_gw, ldgw,
+                                       g_b ? g_b + h * s_gb : nullptr, M, K, N, ws, ws_bytes, stream));
+  return CGAT_OK;
+}
 static int linear_backward_impl(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y,
                                 int64_t ldy, const float* g_y, int64_t ldgy, float* gpre, float* g_x,
                                 int64_t ldgx, int32_t accumulate_gx, float* g_w, int64_t ldgw, float* g_b,

@@ -765,10 +765,15 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
 // in registers, takes its largest magnitude, and writes the two planes of 2^k(a) W[a] in the bf16 kernel's order with
 // two planes per k-step; max |W[a]| goes to wmax[a] behind the planes (the consumer undoes 2^k(a) per column block).
 // No atomics, no second pass, one launch.
+// (blockIdx.y = head of a batch of weights: per-head source and image offsets, see prepare_W_f16_heads_launch)
 __global__ __launch_bounds__(256) void prepare_W_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
-                                                            long sa, long sb, long sc, float* __restrict__ wmax) {
+                                                            long sa, long sb, long sc, float* __restrict__ wmax,
+                                                            long s_head, long image_floats) {
   __shared__ float wm[4];
   const int a = blockIdx.x, tid = threadIdx.x;
+  src += (long)blockIdx.y * s_head;
+  dst += (long)blockIdx.y * image_floats * 2;
+  wmax += (long)blockIdx.y * image_floats;
   float v[64];
   float m = 0.f;
 #pragma unroll
@@ -857,7 +862,15 @@ int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stre
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream) {
   if (NA <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_W_f16_kernel, dim3(NA), dim3(256), 0, stream, src, (_Float16*)dst, sa, sb, sc,
-                     (float*)dst + (size_t)NA * 16384);
+                     (float*)dst + (size_t)NA * 16384, 0l, 0l);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+int prepare_W_f16_heads_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int heads, long s_head,
+                               long image_floats, hipStream_t stream) {
+  if (NA <= 0 || heads <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_W_f16_kernel, dim3(NA, heads), dim3(256), 0, stream, src, (_Float16*)dst, sa, sb, sc,
+                     (float*)dst + (size_t)NA * 16384, s_head, image_floats);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -1021,7 +1034,7 @@ size_t bilinear_prepare_T_batch_ws_floats(int n) { return (size_t)(n > 0 ? n : 1
 // f16x3 mode, 128-wide interleaved layout only (returns CGAT_ERR_UNSUPPORTED otherwise: prepare one by one);
 // dst[i]: bilinear_T_floats(...) floats each; part: bilinear_prepare_T_batch_ws_floats(n) floats
 int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, int n0, int n1, int n2, int perm0,
-                             int perm1, int perm2, float* part, hipStream_t stream) {
+                             int perm1, int perm2, float* part, hipStream_t stream, int alternate) {
   int dims[3] = {n0, n1, n2};
   if (n < 1 || n > TPREP_MAX || bilinear_mode() != 2 || !bilinear_T_interleaved(dims[perm1], dims[perm2]))
     return CGAT_ERR_UNSUPPORTED;
@@ -1037,7 +1050,7 @@ int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, 
   hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(TPREP_PARTS, n), dim3(256), 0, stream, b, total, part);
   CGAT_LAUNCH_CHECK();
   hipLaunchKernelGGL(prepare_T_f16_batch_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, stream, b, NA, st[perm0],
-                     st[perm1], st[perm2], 1, (const float*)part);
+                     st[perm1], st[perm2], alternate, (const float*)part);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -26,7 +26,12 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
                                                          float* __restrict__ out, long ldo,
                                                          const int* __restrict__ scatter, int E, int accumulate,
                                                          const float* __restrict__ bias,
-                                                         const float* __restrict__ amax, const EdgeRC rc) {
+                                                         const float* __restrict__ amax, const EdgeRC rc, HeadBatch hb) {
+  // grid.y = head of a multi-head second layer (edge_ge_heads_launch): per-head operand offsets
+  gZ += (long)blockIdx.y * hb.in;
+  Wq += (long)blockIdx.y * hb.w;
+  out += (long)blockIdx.y * hb.out;
+  if (bias) bias += (long)blockIdx.y * hb.bias;
   // PASSES == 2: two fp16 planes, three passes (mfma_bf16.h).  The rows of gZ are consumed k-step by k-step, so their
   // scale is per tensor: amax[0] = max |gZ| from the kernel that produced it; the weight's max sits behind its planes.
   constexpr bool F16 = PASSES == 2;
@@ -557,10 +562,43 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   const EdgeRC none = {};
 #define GE_GO(P_, R_)                                                                                                 \
   hipLaunchKernelGGL((edge_ge_kernel<P_, R_>), dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, \
-                     out, ldo, scatter, E, accumulate, bias, amax, R_ ? *rc : none)
+                     out, ldo, scatter, E, accumulate, bias, amax, R_ ? *rc : none, HeadBatch{})
   if (rc) { if (f16) GE_GO(2, true); else if (bilinear_mode() != 3) GE_GO(6, true); else GE_GO(3, true); }
   else { if (f16) GE_GO(2, false); else if (bilinear_mode() != 3) GE_GO(6, false); else GE_GO(3, false); }
 #undef GE_GO
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// `heads` products y_h = x_h W_h^T + b_h (x_h = x + h * s_x: W2 columns of a wider matrix; W_h = W + h * s_w: [128, W2]
+// row-major with leading dimension W2, contiguous; y_h = y + h * s_y) in three launches instead of 4-5 per head: the
+// heads' weight maxima and fp16 planes through the batched preparation of the contraction kernels (bilinear.hip), then
+// ONE launch of the kernel above with grid.y = head.  f16x3 mode with max |x| known (amax), heads <= TPREP_MAX.
+// ws: heads * edge_ge_heads_image_floats(W2) + bilinear_prepare_T_batch_ws_floats(heads) floats.
+size_t edge_ge_heads_image_floats(int W2) { return (size_t)(W2 / 128) * 16384 + 4; }
+bool edge_ge_heads_fast(int heads, int W2, long ldx, long ldy, long ldw, const void* x, const void* w, const void* y,
+                        const float* amax) {
+  return bilinear_mode() == 2 && amax && heads >= 1 && heads <= TPREP_MAX && W2 % 128 == 0 && ldw == W2 &&
+         (((uintptr_t)w) & 15) == 0 && edge_ge_fast(128, W2, ldx, 128, ldy, x, y);
+}
+int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const float* W, long s_w, const float* bias,
+                         long s_bias, float* y, long ldy, long s_y, int E, int W2, float* ws, hipStream_t stream,
+                         const float* amax) {
+  if (E <= 0 || heads <= 0) return CGAT_OK;
+  const int ncb = W2 / 128;
+  const size_t img = edge_ge_heads_image_floats(W2);
+  float* part = ws + (size_t)heads * img;
+  const float* src[TPREP_MAX];
+  float* dst[TPREP_MAX];
+  for (int h = 0; h < heads; ++h) { src[h] = W + (long)h * s_w; dst[h] = ws + (size_t)h * img; }
+  // operand (a = column block, b = column in block, c = output k) = W_h[c * W2 + 128 a + b]: source dims (k, a, b)
+  const int rc_ = bilinear_prepare_T_batch(heads, src, dst, 128, ncb, 128, 1, 2, 0, part, stream, /*alternate=*/0);
+  if (rc_ != CGAT_OK) return rc_;
+  CGAT_PROF("rows_ge", stream);
+  const HeadBatch hb = {s_x, (long)(img / 4), s_bias, s_y, 0};
+  const EdgeRC none = {};
+  hipLaunchKernelGGL((edge_ge_kernel<2, false>), dim3(cdiv(E, 256), heads), dim3(512), 0, stream, x, ldx, 128l,
+                     (const uint4*)ws, ncb, y, ldy, (const int*)nullptr, E, 0, bias, amax, none, hb);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

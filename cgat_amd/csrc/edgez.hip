@@ -36,7 +36,13 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
                                                         const float* __restrict__ wA, const float* __restrict__ bA,
                                                         int H, int cb_per_head, float* __restrict__ a_out, int act,
                                                         int accumulate, float* __restrict__ omax,
-                                                        const float* __restrict__ dact, long ld_dact) {
+                                                        const float* __restrict__ dact, long ld_dact, HeadBatch hb) {
+  // grid.y = head of a multi-head second layer (linear128_heads_launch): every operand moves by its per-head offset
+  e += (long)blockIdx.y * hb.in;
+  Wq += (long)blockIdx.y * hb.w;
+  Z += (long)blockIdx.y * hb.out;
+  if (Pi) Pi += (long)blockIdx.y * hb.bias;
+  if (dact) dact += (long)blockIdx.y * hb.dact;
   constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
   constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
   constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
@@ -618,7 +624,8 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
-                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr, 0l)
+                     Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr, 0l, \
+                     HeadBatch{})
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
   else if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
@@ -653,9 +660,34 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
                      (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate, \
-                     omax, dact, ld_dact)
+                     omax, dact, ld_dact, HeadBatch{})
   if (bilinear_mode() == 2) L128_GO(2); else if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// The same product for `heads` independent (input, weight, output) triples in ONE launch pair (f16x3 mode): head h
+// reads in + h * s_in, W + h * s_w (the same (so, sk) element strides), bias + h * s_bias, dact + h * s_dact and writes
+// out + h * s_out.  The per-head second layers of a vector-attention layer at the harness' shipped batch are 2 H chains
+// of [prepare, product] launches of 20-40 us each that fill a fraction of the chip; as grid.y they are one.
+// ws: heads * linear128_heads_image_floats(n_out) floats.
+size_t linear128_heads_image_floats(int n_out) { return (size_t)(n_out / 128) * 16384 + ((n_out / 128 + 3) & ~3); }
+int linear128_heads_launch(int heads, const float* in, long ldi, long s_in, const float* W, long so, long sk, long s_w,
+                           const float* bias, long s_bias, int act, int accumulate, float* out, long ldo, long s_out, int rows,
+                           void* ws, hipStream_t stream, int n_out, const float* dact, long ld_dact, long s_dact,
+                           float* omax) {
+  if (rows <= 0 || heads <= 0) return CGAT_OK;
+  CGAT_CHECK_ARG(bilinear_mode() == 2 && n_out % 128 == 0, "linear128_heads: f16x3 mode and 128-wide output blocks only");
+  const int ncb = n_out / 128;
+  const long img = (long)linear128_heads_image_floats(n_out);
+  CGAT_TRY(prepare_W_f16_heads_launch(W, ws, ncb, 128 * so, sk, so, heads, s_w, img, stream));
+  CGAT_PROF("linear128", stream);
+  const HeadBatch hb = {s_in, img / 4, s_bias, s_out, s_dact};
+  hipLaunchKernelGGL((edge_z_kernel<2, false>), dim3(cdiv(rows, 128), heads), dim3(256), 0, stream, in, ldi,
+                     (const int*)nullptr, (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr,
+                     (const int*)nullptr, 0l, out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1,
+                     (float*)nullptr, act, accumulate, omax, dact, ld_dact, hb);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -81,7 +81,7 @@ struct TPrepBatch {
 };
 size_t bilinear_prepare_T_batch_ws_floats(int n);
 int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, int n0, int n1, int n2, int perm0,
-                             int perm1, int perm2, float* part, hipStream_t stream);
+                             int perm1, int perm2, float* part, hipStream_t stream, int alternate = 1);
 int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int perm0, int perm1, int perm2,
                        hipStream_t stream);
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC);
@@ -132,6 +132,20 @@ int absmax_launch(const float* src, long n, float* out, hipStream_t stream);   /
 int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream);  // folds into out[0]
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]
 int prepare_W_f16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, hipStream_t stream);
+// the same for `heads` weights of NA blocks each in ONE launch: head h reads src + h * s_head and writes the image
+// (NA planes blocks, then NA maxima) at (float*)dst + h * image_floats
+int prepare_W_f16_heads_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int heads, long s_head,
+                               long image_floats, hipStream_t stream);
+// Per-head offsets of a launch whose grid.y runs over the heads of a multi-head second layer (elements of each operand;
+// w in 16-byte pieces): all zero = the single-operand launch
+struct HeadBatch {
+  long in, w, bias, out, dact;
+};
+size_t linear128_heads_image_floats(int n_out);
+int linear128_heads_launch(int heads, const float* in, long ldi, long s_in, const float* W, long so, long sk, long s_w,
+                           const float* bias, long s_bias, int act, int accumulate, float* out, long ldo, long s_out, int rows,
+                           void* ws, hipStream_t stream, int n_out, const float* dact, long ld_dact, long s_dact,
+                           float* omax);
 // batched form for 128 x 128 dense-layer weights W(o, k) = src[o * so + k * sk]: image i at dst + i * WPREP_IMAGE_FLOATS
 #define WPREP_MAX 48
 #define WPREP_IMAGE_FLOATS (16384 + 4)
@@ -206,6 +220,12 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
                    const float* emax = nullptr,            // device maxima of |gZ| and |e| -> fp16 form in the f16x3 mode
                    const EdgeRC* rc = nullptr);
 bool edge_ge_fast(int Ce, int W2, long ldg, long gzb, long ldo, const void* gZ, const void* out);
+size_t edge_ge_heads_image_floats(int W2);
+bool edge_ge_heads_fast(int heads, int W2, long ldx, long ldy, long ldw, const void* x, const void* w, const void* y,
+                        const float* amax);
+int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const float* W, long s_w, const float* bias,
+                         long s_bias, float* y, long ldy, long s_y, int E, int W2, float* ws, hipStream_t stream,
+                         const float* amax);
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
                    hipStream_t stream,

@@ -525,16 +525,15 @@ def _heads_forward(hid, nets, H, Hd, Co, hmax=None):
     E, W2 = hid.shape
     cos = _cos(Co, len(nets))
     outs = [torch.empty(E, H * co, dtype=torch.float32, device=hid.device) for co in cos]
-    ws = workspace(max(lib.cgat_linear_forward_workspace_bytes(E, Hd, co) for co in cos), hid.device)
+    ws = workspace(max(lib.cgat_heads_linear_forward_workspace_bytes(E, Hd, co, H) for co in cos), hid.device)
     with torch.cuda.device(hid.device):
         for net, (w, b) in enumerate(nets):
             Co = cos[net]
-            for h in range(H):
-                xs = hid[:, (net * H + h) * Hd:(net * H + h + 1) * Hd]
-                check(lib.cgat_linear_forward(_ptr(xs), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
-                                              None if b is None else _ptr(b[h * Co:(h + 1) * Co]),
-                                              _ptr(outs[net][:, h * Co:(h + 1) * Co]), H * Co, E, Hd, Co, _lib.ACT_NONE,
-                                              _ptr(hmax), _ptr(ws), ws.numel(), _stream()), "cgat_linear_forward")
+            # the H heads of a network as ONE call: head h reads the column block (net * H + h) * Hd of hid, rows
+            # [h * Co, (h + 1) * Co) of the weight / bias, and writes columns [h * Co, (h + 1) * Co) of the output
+            check(lib.cgat_heads_linear_forward(_ptr(hid[:, net * H * Hd:]), W2, Hd, _ptr(w), Hd, Co * Hd, _ptr(b), Co,
+                                                _ptr(outs[net]), H * Co, Co, E, Hd, Co, H, _ptr(hmax), _ptr(ws), ws.numel(),
+                                                _stream()), "cgat_heads_linear_forward")
     return outs
 
 
@@ -647,18 +646,15 @@ class EdgeHiddenHeadsFn(torch.autograd.Function):
         gmax = torch.zeros(1, dtype=torch.float32, device=dev)
         g_w = [torch.empty(H * co, Hd, dtype=torch.float32, device=dev) for co in cos]
         g_b = [torch.empty(H * co, dtype=torch.float32, device=dev) if hb else None for hb, co in zip(ctx.has_b, cos)]
-        ws = workspace(max(lib.cgat_linear_backward_workspace_bytes(E, Hd, co) for co in cos), dev)
+        ws = workspace(max(lib.cgat_heads_linear_backward_dact_workspace_bytes(E, Hd, co, H) for co in cos), dev)
         with torch.cuda.device(dev):
             for net, w in enumerate((w0, w1)):
                 Co = cos[net]
-                for h in range(H):
-                    col = (net * H + h) * Hd
-                    check(lib.cgat_linear_backward_dact(
-                        _ptr(hidden[:, col:col + Hd]), W2, _ptr(w[h * Co:(h + 1) * Co]), Hd,
-                        _ptr(gs[net][:, h * Co:(h + 1) * Co]), H * Co, _ptr(gpre[:, col:col + Hd]), W2,
-                        _ptr(hidden[:, col:col + Hd]), W2, _ptr(gmax), _ptr(g_w[net][h * Co:(h + 1) * Co]), Hd,
-                        None if g_b[net] is None else _ptr(g_b[net][h * Co:(h + 1) * Co]), E, Hd, Co,
-                        _ptr(ws), ws.numel(), _stream()), "cgat_linear_backward_dact")
+                col = net * H * Hd
+                check(lib.cgat_heads_linear_backward_dact(
+                    _ptr(hidden[:, col:]), W2, Hd, _ptr(w), Hd, Co * Hd, _ptr(gs[net]), H * Co, Co,
+                    _ptr(gpre[:, col:]), W2, Hd, _ptr(hidden[:, col:]), W2, Hd, _ptr(gmax), _ptr(g_w[net]), Hd, Co * Hd,
+                    _ptr(g_b[net]), Co, E, Hd, Co, H, _ptr(ws), ws.numel(), _stream()), "cgat_heads_linear_backward_dact")
             g_x, g_e = torch.empty_like(x), torch.empty_like(edge_attr)
             g_win, g_bin = torch.empty_like(w_in), torch.empty(W2, dtype=torch.float32, device=dev)
             ws2 = workspace(lib.cgat_edge_hidden_backward_workspace_bytes(C.byref(plan.c), Cn, Ce, W2), dev)

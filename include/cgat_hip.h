@@ -260,6 +260,21 @@ int cgat_linear_backward_dact(const float* x, int64_t ldx, const float* w, int64
                               float* g_x, int64_t ldgx, const float* gx_dact, int64_t ld_dact, float* gx_absmax,
                               float* g_w, int64_t ldgw, float* g_b, int32_t M, int32_t K, int32_t N, void* ws,
                               size_t ws_bytes, void* stream);
+/* The H per-head second layers of one MultiHeadNetwork in ONE call (CGAT/CGAT.py:97-98, 103-109: fc_out is a grouped
+ * Conv1d = H independent Linear(K, N) on the H column blocks of the hidden matrix): head h works on x + h * s_x,
+ * w + h * s_w, bias + h * s_bias, y + h * s_y (strides in elements).  Same results as H calls of cgat_linear_forward /
+ * cgat_linear_backward_dact, which is also what runs for shapes the batched kernels do not take; batched (f16x3 mode,
+ * N == 128, K a multiple of 128, contiguous per-head weights) the layer is 3 launches instead of 4-5 per head. */
+size_t cgat_heads_linear_forward_workspace_bytes(int32_t M, int32_t K, int32_t N, int32_t H);
+int cgat_heads_linear_forward(const float* x, int64_t ldx, int64_t s_x, const float* w, int64_t ldw, int64_t s_w,
+                              const float* bias, int64_t s_bias, float* y, int64_t ldy, int64_t s_y, int32_t M, int32_t K,
+                              int32_t N, int32_t H, const float* x_absmax, void* ws, size_t ws_bytes, void* stream);
+size_t cgat_heads_linear_backward_dact_workspace_bytes(int32_t M, int32_t K, int32_t N, int32_t H);
+int cgat_heads_linear_backward_dact(const float* x, int64_t ldx, int64_t s_x, const float* w, int64_t ldw, int64_t s_w,
+                                    const float* g_y, int64_t ldgy, int64_t s_gy, float* g_x, int64_t ldgx, int64_t s_gx,
+                                    const float* gx_dact, int64_t ld_dact, int64_t s_dact, float* gx_absmax, float* g_w,
+                                    int64_t ldgw, int64_t s_gw, float* g_b, int64_t s_gb, int32_t M, int32_t K, int32_t N,
+                                    int32_t H, void* ws, size_t ws_bytes, void* stream);
 /* gpre = g_y * act'(y) is written to `gpre` [M,N] (caller buffer); g_x += or = per accumulate_gx */
 int cgat_linear_backward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
                          const float* g_y, int64_t ldgy, float* gpre /* [M,N] dense */, float* g_x, int64_t ldgx,

@@ -595,6 +595,84 @@ def test_linear_backward_dact_and_hidden_maximum(env, M, Hd, mode):
         ops.set_bilinear_mode(ops.DEFAULT_MODE)
 
 
+@pytest.mark.parametrize("M,H,Hd", [(1000, 5, 256), (77, 3, 256), (3000, 2, 384), (500, 5, 128), (640, 9, 256)])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
+def test_heads_linear_batched(env, M, H, Hd, mode):
+    """cgat_heads_linear_forward / _backward_dact (all heads of a network's second layer in one call; grid.y = head in the
+    f16x3 mode, head by head otherwise -- Hd = 128 and 9 heads take the loop in every mode) against H single-head
+    calls -- forward and input gradient bit for bit, weight / bias gradients to the tolerance (their row splits depend
+    on the batch) -- and against fp64."""
+    _, _lib, ops, dev = env
+    lib = _lib.lib
+    ops.set_bilinear_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(M + H + Hd)
+        Co, W2 = 128, 2 * H * Hd                               # the hidden matrix of two networks; this is the second
+        pre = torch.randn(M, W2, generator=g).to(dev)
+        hid = torch.where(pre > 0, pre, 0.01 * pre)
+        col0 = H * Hd
+        w = (torch.randn(H * Co, Hd, generator=g) / Hd ** 0.5).to(dev)
+        b = torch.randn(H * Co, generator=g).to(dev)
+        hmax = hid.abs().max().reshape(1)
+        P = lambda t: None if t is None else t.data_ptr()
+
+        def forward(batched):
+            y = torch.full((M, H * Co), float("nan"), device=dev)
+            if batched:
+                ws = torch.empty(lib.cgat_heads_linear_forward_workspace_bytes(M, Hd, Co, H), dtype=torch.uint8, device=dev)
+                _lib.check(lib.cgat_heads_linear_forward(P(hid[:, col0:]), W2, Hd, P(w), Hd, Co * Hd, P(b), Co, P(y), H * Co, Co,
+                                                         M, Hd, Co, H, P(hmax), P(ws), ws.numel(), None), "heads fwd")
+            else:
+                ws = torch.empty(lib.cgat_linear_forward_workspace_bytes(M, Hd, Co), dtype=torch.uint8, device=dev)
+                for h in range(H):
+                    _lib.check(lib.cgat_linear_forward(P(hid[:, col0 + h * Hd:]), W2, P(w[h * Co:]), Hd, P(b[h * Co:]),
+                                                       P(y[:, h * Co:]), H * Co, M, Hd, Co, _lib.ACT_NONE, P(hmax), P(ws),
+                                                       ws.numel(), None), "linear fwd")
+            torch.cuda.synchronize()
+            return y
+        yb, ys = forward(True), forward(False)
+        assert torch.equal(yb, ys)
+        ref = torch.einsum("mhk,hok->mho", hid[:, col0:].double().reshape(M, H, Hd), w.double().reshape(H, Co, Hd)) \
+            + b.double().reshape(1, H, Co)
+        assert rel(yb, ref.reshape(M, H * Co)) <= TOL
+        if mode == "f32":
+            return                                             # (the dact entries need a split mode)
+        gy = torch.randn(M, H * Co, generator=g).to(dev)
+
+        def backward(batched):
+            gpre = torch.zeros(M, W2, device=dev)
+            gmax = torch.zeros(1, device=dev)
+            gw, gb = torch.full((H * Co, Hd), float("nan"), device=dev), torch.full((H * Co,), float("nan"), device=dev)
+            if batched:
+                ws = torch.empty(lib.cgat_heads_linear_backward_dact_workspace_bytes(M, Hd, Co, H), dtype=torch.uint8,
+                                 device=dev)
+                _lib.check(lib.cgat_heads_linear_backward_dact(
+                    P(hid[:, col0:]), W2, Hd, P(w), Hd, Co * Hd, P(gy), H * Co, Co, P(gpre[:, col0:]), W2, Hd,
+                    P(hid[:, col0:]), W2, Hd, P(gmax), P(gw), Hd, Co * Hd, P(gb), Co, M, Hd, Co, H, P(ws), ws.numel(), None),
+                    "heads bwd")
+            else:
+                ws = torch.empty(lib.cgat_linear_backward_workspace_bytes(M, Hd, Co), dtype=torch.uint8, device=dev)
+                for h in range(H):
+                    c = col0 + h * Hd
+                    _lib.check(lib.cgat_linear_backward_dact(
+                        P(hid[:, c:]), W2, P(w[h * Co:]), Hd, P(gy[:, h * Co:]), H * Co, P(gpre[:, c:]), W2, P(hid[:, c:]), W2,
+                        P(gmax), P(gw[h * Co:]), Hd, P(gb[h * Co:]), M, Hd, Co, P(ws), ws.numel(), None), "linear bwd")
+            torch.cuda.synchronize()
+            return gpre, gmax, gw, gb
+        B, S = backward(True), backward(False)
+        assert torch.equal(B[0], S[0]) and torch.equal(B[1], S[1])
+        assert float(B[0][:, :col0].abs().max()) == 0.0
+        gd = gy.double().reshape(M, H, Co)
+        hd = hid[:, col0:].double().reshape(M, H, Hd)
+        want = torch.einsum("mho,hok->mhk", gd, w.double().reshape(H, Co, Hd)) * torch.where(hd > 0, 1.0, 0.01)
+        assert rel(B[0][:, col0:], want.reshape(M, H * Hd)) <= TOL
+        for got in (B, S):
+            assert rel(got[2], torch.einsum("mho,mhk->hok", gd, hd).reshape(H * Co, Hd)) <= TOL
+            assert rel(got[3], gd.sum(0).reshape(-1)) <= TOL
+    finally:
+        ops.set_bilinear_mode(ops.DEFAULT_MODE)
+
+
 @pytest.mark.parametrize("rows", [255, 257, 4099, 83340])
 def test_ring_kernels_race_screen(env, rows):
     """The LDS-DMA ring kernels order their loads with counted vmcnt waits and raw barriers (no compiler help): screen
