@@ -24,6 +24,8 @@ python3 $R/bench.py --workload edge_hyper --steps 3 --warmup 1 > $O/bench_edge_h
 # the harness' shipped default network, and its shipped batch size (64 crystals per GPU): launch-bound regime, hipGraph replay
 python3 $R/bench.py --workload lightning --steps 3 --warmup 1 > $O/bench_lightning.json 2> $O/bench_lightning.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lightning_stats -- python3 $R/bench.py --workload lightning --steps 2 --warmup 1 > $O/lightning_stats.log 2>&1
+python3 $R/bench.py --workload lightning --graphs 64 --steps 20 --warmup 5 > $O/bench_lightning64.json 2> $O/bench_lightning64.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lightning64_stats -- python3 $R/bench.py --workload lightning --graphs 64 --steps 10 --warmup 2 > $O/lightning64_stats.log 2>&1
 python3 $R/bench.py --workload stack --graphs 64 --steps 20 --warmup 5 $Q > $O/bench_stack64.json 2> $O/bench_stack64.err
 python3 $R/bench.py --workload layer --graphs 64 --steps 20 --warmup 5 $Q > $O/bench_layer64.json 2> $O/bench_layer64.err
 python3 $R/bench.py --workload train --graphs 64 --steps 20 --warmup 5 > $O/bench_train64.json 2> $O/bench_train64.err

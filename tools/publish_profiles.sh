@@ -20,8 +20,9 @@ if d.get("roofline"):
     d["roofline"]["mfma_utilisation_from_counters"] = json.load(open("$P/mfma_counters.json"))
 open(b, "w").write(json.dumps(d) + "\n")
 PY
-for w in stress train stack edge_hyper lightning stack64 layer64 train64 rccl1 norccl train_rccl1; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/${T}_bench_$w.json; done
+for w in stress train stack edge_hyper lightning lightning64 stack64 layer64 train64 rccl1 norccl train_rccl1; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/${T}_bench_$w.json; done
 [ -d $D/lightning_stats ] && cp $(ls $D/lightning_stats/*/*_kernel_stats.csv | head -1) $P/${T}_lightning_kernel_stats.csv
+[ -d $D/lightning64_stats ] && cp $(ls $D/lightning64_stats/*/*_kernel_stats.csv | head -1) $P/${T}_lightning64_kernel_stats.csv
 [ -d $D/stack64_stats ] && cp $(ls $D/stack64_stats/*/*_kernel_stats.csv | head -1) $P/${T}_stack64_kernel_stats.csv
 for w in 2ranks_one_gpu train_2ranks_one_gpu; do [ -s $D/bench_$w.json ] && cp $D/bench_$w.json $P/${T}_bench_$w.json; done
 [ -s $D/bench_stress_bf16.json ] && cp $D/bench_stress_bf16.json $P/${T}_bench_stress_bf16.json
