@@ -161,26 +161,26 @@ struct SplitLoader {
     }
   }
   // four consecutive k of one row -> 8 bytes in each of the three planes
-  __device__ static void put(char* lds, int row, int kq, float a, float b, float c, float d) {
+  // sx = 0 or 0x80008000: flips the sign of every stored bf16 (exact: the planes of -x are the negated planes of x)
+  __device__ static void put(char* lds, int row, int kq, float a, float b, float c, float d, unsigned sx) {
     unsigned w1a, w2a, w3a, w1b, w2b, w3b;
     split3_pair(a, b, w1a, w2a, w3a);
     split3_pair(c, d, w1b, w2b, w3b);
     char* p = lds + row * SPITCH + kq * 8;
-    *reinterpret_cast<uint2*>(p) = make_uint2(w1a, w1b);
-    *reinterpret_cast<uint2*>(p + SPLANE) = make_uint2(w2a, w2b);
-    *reinterpret_cast<uint2*>(p + 2 * SPLANE) = make_uint2(w3a, w3b);
+    *reinterpret_cast<uint2*>(p) = make_uint2(w1a ^ sx, w1b ^ sx);
+    *reinterpret_cast<uint2*>(p + SPLANE) = make_uint2(w2a ^ sx, w2b ^ sx);
+    *reinterpret_cast<uint2*>(p + 2 * SPLANE) = make_uint2(w3a ^ sx, w3b ^ sx);
   }
-  // sg = +-1 multiplies every element (exact; the planes of -x are the negated planes of x)
-  __device__ void store(int tid, char* lds, const float4 (&v)[4], float sg = 1.f) const {
+  __device__ void store(int tid, char* lds, const float4 (&v)[4], unsigned sx = 0u) const {
     if (!KM) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) put(lds, (tid >> 3) + 32 * i, tid & 7, sg * v[i].x, sg * v[i].y, sg * v[i].z, sg * v[i].w);
+      for (int i = 0; i < 4; ++i) put(lds, (tid >> 3) + 32 * i, tid & 7, v[i].x, v[i].y, v[i].z, v[i].w, sx);
     } else {
       const int r = 4 * (tid >> 3), kq = tid & 7;
-      put(lds, r + 0, kq, sg * v[0].x, sg * v[1].x, sg * v[2].x, sg * v[3].x);
-      put(lds, r + 1, kq, sg * v[0].y, sg * v[1].y, sg * v[2].y, sg * v[3].y);
-      put(lds, r + 2, kq, sg * v[0].z, sg * v[1].z, sg * v[2].z, sg * v[3].z);
-      put(lds, r + 3, kq, sg * v[0].w, sg * v[1].w, sg * v[2].w, sg * v[3].w);
+      put(lds, r + 0, kq, v[0].x, v[1].x, v[2].x, v[3].x, sx);
+      put(lds, r + 1, kq, v[0].y, v[1].y, v[2].y, v[3].y, sx);
+      put(lds, r + 2, kq, v[0].z, v[1].z, v[2].z, v[3].z, sx);
+      put(lds, r + 3, kq, v[0].w, v[1].w, v[2].w, v[3].w, sx);
     }
   }
 };
@@ -253,13 +253,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
   // -- a weighted sum of many outputs, such as the gradient of a scale parameter, collects it).  Odd chunks therefore
   // multiply -A (stored negated: exact) and their sum is SUBTRACTED: the chunk biases alternate in sign and cancel.
   for (int c = 0; c < nchunks; ++c) {
-    la.store(tid, As, ra, (c & 1) ? -1.f : 1.f);
+    la.store(tid, As, ra, (c & 1) ? 0x80008000u : 0u);
     lb.store(tid, Bs, rb);
     __syncthreads();
     if (c + 1 < nchunks) {
       la.load(tid, SCHUNK_K(c + 1), kend, ra);
       lb.load(tid, SCHUNK_K(c + 1), kend, rb);
     }
+    const float sgf = (c & 1) ? -1.f : 1.f;
     bf16x8 a1[4], a2[4], a3[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -276,17 +277,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.split_passes == 8) {                 // (wave-uniform) the two cross terms of weight 2^-24
-          t = mma16<false>(b2, a3[r], t);
-          t = mma16<false>(b3, a2[r], t);
-        }
         t = mma16<false>(b1, a3[r], t);
         t = mma16<false>(b3, a1[r], t);
         t = mma16<false>(b2, a2[r], t);
         t = mma16<false>(b1, a2[r], t);
         t = mma16<false>(b2, a1[r], t);
         t = mma16<false>(b1, a1[r], t);
-        if (c & 1) acc[r][cb] -= t; else acc[r][cb] += t;
+        acc[r][cb] += t * sgf;                      // (one fused multiply-add per element: +-1 * t is exact)
       }
     }
     __syncthreads();
@@ -362,10 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
 }
 
 // called by gemm_launch (gemm.hip) with every derived field of p filled in and the grid it computed
-int gemm_split_launch(const GemmParams& p_, unsigned grid, hipStream_t stream) {
-  static const int passes = [] { const char* e = getenv("CGAT_GEMM_SPLIT_PASSES"); return (e && atoi(e) == 8) ? 8 : 6; }();
-  GemmParams p = p_;
-  p.split_passes = passes;
+int gemm_split_launch(const GemmParams& p, unsigned grid, hipStream_t stream) {
   CGAT_PROF("gemm_split", stream);
   if (p.a_outer) hipLaunchKernelGGL((gemm_split_kernel<false, true, 1>), dim3(grid), dim3(256), 0, stream, p);
   else if (p.b_outer) hipLaunchKernelGGL((gemm_split_kernel<true, true, 2>), dim3(grid), dim3(256), 0, stream, p);

@@ -41,7 +41,6 @@ struct GemmParams {
   int outer_n;
   // filled by gemm_launch
   int k_per_split, a_vec, b_vec, c_vec;
-  int split_passes;      // gemmsplit.hip: 6 or 8 matrix passes per product (8 adds the two 2^-24 cross terms)
   float* slab;
 };
 
