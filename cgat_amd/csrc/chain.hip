@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
         split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+        if (s & 1) { q1[2 * s + nb] = neg_x8(q1[2 * s + nb]); q2[2 * s + nb] = neg_x8(q2[2 * s + nb]); }   // (see CN_MFMA)
       }
     }
   }
@@ -147,13 +148,21 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
     P_ = mma16<true>(F1_, q2[qi_], P_);                                                        \
     P_ = mma16<true>(F1_, q1[qi_], P_);                                                        \
   }
+  // The matrix instruction's accumulator rounds with a sign-independent bias (tools/f16_bias_probe.py): the
+  // odd k-steps multiply the NEGATED row fragments into a second accumulator set that is subtracted before the epilogue,
+  // so their bias enters the result with the opposite sign and cancels the even k-steps' pairwise.
 #define CN_MFMA(F1_, F2_, s_, cb_)                                                             \
   {                                                                                            \
-    CN_MFMA1(F1_, F2_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                      \
-    CN_MFMA1(F1_, F2_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                      \
+    if ((s_) & 1) {                                                                            \
+      CN_MFMA1(F1_, F2_, 2 * (s_) + 0, partn[2 * (cb_) + 0])                                   \
+      CN_MFMA1(F1_, F2_, 2 * (s_) + 1, partn[2 * (cb_) + 1])                                   \
+    } else {                                                                                   \
+      CN_MFMA1(F1_, F2_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                    \
+      CN_MFMA1(F1_, F2_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                    \
+    }                                                                                          \
   }
   CN_READ(fa1, fa2, 0, 0);
-  f32x4 part[8];
+  f32x4 part[8], partn[8];
   f32x4 vals[2][8];                              // vals[nb][b] = this layer's out[row(nb), 16 b + 4 kg .. + 3]
   for (int l = 0; l < d.n_layers; ++l) {
     const ChainLayer L = d.layer[l];
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 8; ++i) { part[i] = f32x4{0.f, 0.f, 0.f, 0.f}; partn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                  // chunk (l, half, s) sits in ring slot s
         CN_TLOAD(l * 8 + half * 4 + s + 3);
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
 #pragma unroll
       for (int c16 = 0; c16 < 4; ++c16) {
         const int col = col0 + 16 * c16;
-        const f32x4 pa = part[2 * c16 + 0] * ma, pb = part[2 * c16 + 1] * mb;
+        const f32x4 pa = (part[2 * c16 + 0] - partn[2 * c16 + 0]) * ma, pb = (part[2 * c16 + 1] - partn[2 * c16 + 1]) * mb;
         float4 va = make_float4(pa[0], pa[1], pa[2], pa[3]), vb = make_float4(pb[0], pb[1], pb[2], pb[3]);
         if (L.bias) {
           const float4 b4 = *reinterpret_cast<const float4*>(L.bias + col);
@@ -262,6 +271,10 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
             const float f = sq[nb];
             const float v[8] = {lo.x * f, lo.y * f, lo.z * f, lo.w * f, hi4.x * f, hi4.y * f, hi4.z * f, hi4.w * f};
             split2_x8_f16(v, q1[2 * (2 * h + sl) + nb], q2[2 * (2 * h + sl) + nb]);
+            if (sl & 1) {                            // k-step s = 2 h + sl is odd
+              q1[2 * (2 * h + sl) + nb] = neg_x8(q1[2 * (2 * h + sl) + nb]);
+              q2[2 * (2 * h + sl) + nb] = neg_x8(q2[2 * (2 * h + sl) + nb]);
+            }
           }
       }
     }

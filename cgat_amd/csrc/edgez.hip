@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   // DEEP (the per-edge launch in the fp16 form): 8 ring slots, vmcnt allowances that let the epilogue's stores stay
   // in flight, all gathers of a slice before its first store, unconditional stores (see edge_zx_kernel's header)
   constexpr bool DEEP = F16 && ADDS;
+  constexpr bool ALT = true;                    // odd k-steps into a second, subtracted accumulator set (see below)
   constexpr int RING = DEEP ? 8 : 4;
   __shared__ uint4 smem[RING * CH16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,6 +110,20 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         }
     }
   }
+  // The matrix instruction's accumulator rounds with a sign-independent bias (-0.9e-9 of sum |x||w| on every
+  // output of this kernel when the four k-steps of a slice accumulated straight into one accumulator: 50-100 x the
+  // statistical level, tools/f16_bias_probe.py).  The odd k-steps therefore multiply the NEGATED row fragments into a
+  // second accumulator set that is subtracted before the epilogue: their bias has the opposite sign in the result.
+  if constexpr (ALT) {
+#pragma unroll
+    for (int s = 1; s < 4; s += 2)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        q1[2 * s + nb] = neg_x8(q1[2 * s + nb]);
+        q2[2 * s + nb] = neg_x8(q2[2 * s + nb]);
+        if constexpr (!F16) q3[2 * s + nb] = neg_x8(q3[2 * s + nb]);
+      }
+  }
   // ADDS: gathered addends Pi[dst], Pj[src] (the edge kernel).  !ADDS: a plain product plus bias, Pi = the bias
   // vector or null (the per-node projections x W_i^T + b and x W_j^T, same kernel with e = x)
   const float* pia = ADDS ? Pi + (long)dsti[rca] * ld_add : Pi;
@@ -158,11 +173,16 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   }
 #define EZ_MFMA(F1_, F2_, F3_, s_, cb_)                                                        \
   {                                                                                            \
-    EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                                 \
-    EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
+    if (ALT && ((s_) & 1)) {                                                                   \
+      EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, partn[2 * (cb_) + 0])                              \
+      EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, partn[2 * (cb_) + 1])                              \
+    } else {                                                                                   \
+      EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb_) + 0])                               \
+      EZ_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                               \
+    }                                                                                          \
   }
   EZ_READ(fa1, fa2, fa3, 0, 0);
-  f32x4 part[8];
+  f32x4 part[8], partn[ALT ? 8 : 1];
   float dot_a = 0.f, dot_b = 0.f, omx = 0.f;
   const int ncbA = a_out ? H * cb_per_head : 0;      // column blocks that belong to the attention network
   for (int cb = 0; cb < ncb; ++cb) {
@@ -170,6 +190,10 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (ALT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) partn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                  // chunk (cb, half, s) sits in ring slot (4 half + s) % RING
         constexpr int SM = RING - 1;
@@ -194,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+      }
+      if constexpr (ALT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[i] -= partn[i];
       }
       if constexpr (F16) {                           // undo the row and column-block scales
         float sw, iw;

@@ -74,6 +74,12 @@ __device__ __forceinline__ void split2_x8_f16(const float (&v)[8], bf16x8& q1, b
   q1 = __builtin_bit_cast(bf16x8, w1);
   q2 = __builtin_bit_cast(bf16x8, w2);
 }
+// sign flip of the eight 16-bit floats (bf16 or fp16) of a fragment: exact
+__device__ __forceinline__ bf16x8 neg_x8(bf16x8 q) {
+  uint4 w = __builtin_bit_cast(uint4, q);
+  w.x ^= 0x80008000u; w.y ^= 0x80008000u; w.z ^= 0x80008000u; w.w ^= 0x80008000u;
+  return __builtin_bit_cast(bf16x8, w);
+}
 // one 16x16x32 matrix-core pass on 16-byte fragments held in the bf16x8 carrier type
 template <bool F16>
 __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
