@@ -962,11 +962,11 @@ int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb,
 }
 // fp16 form with the maximum already known (tmax[0], device memory): strided sources
 int prepare_T_f16_scaled_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, const float* tmax,
-                                hipStream_t stream) {
+                                hipStream_t stream, int alternate) {
   long total = (long)NA * 128 * 128;
   if (total <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_T_bf16_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
-                     sa, sb, sc, 0, tmax);
+                     sa, sb, sc, alternate, tmax);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -198,11 +198,23 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     asm volatile("" ::: "memory");                                                                       \
     qa1 = na1; qa2 = na2; qa3 = na3; qb1 = nb1; qb2 = nb2; qb3 = nb3;                                    \
   }
-  for (int ks = 0; ks < nk; ks += 2) {       // nk = 4 ncb is even
+  // One 128-column block of the operand (four k-steps) per trip.  The matrix instruction's accumulator rounds with a
+  // sign-independent bias (-0.9e-9 ... -1.5e-9 of sum |g||w| on every output when all k-steps accumulated
+  // with one sign, tools/f16_bias_probe.py): the weight planes of odd blocks are prepared NEGATED (edge_ge_launch) and
+  // the accumulators change sign between blocks (exact), so a block's bias enters the result with the sign (-1)^a and
+  // consecutive blocks cancel; after the last block the accumulators hold (-1)^ncb times the sum.
+  for (int a = 0; a < ncb; ++a) {
+    const int ks = 4 * a;
     GE_ITER(ks, 0, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m,
             sb0, sb1, sb2, tb0, tb1, tb2)
     GE_ITER(ks + 1, 1, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m,
             tb0, tb1, tb2, sb0, sb1, sb2)
+    GE_ITER(ks + 2, 0, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m,
+            sb0, sb1, sb2, tb0, tb1, tb2)
+    GE_ITER(ks + 3, 1, sa0, sa1, sb0_, sb1_, sca_c, scb_c, sca_m, scb_m, ra0, ra1, rb0, rb1, rca_c, rcb_c, rca_m, rcb_m,
+            tb0, tb1, tb2, sb0, sb1, sb2)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = -acc[i];
   }
 #undef GE_ITER
 #undef GE_BLOAD
@@ -212,9 +224,10 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #undef GE_MFMA1
   // acc[2 g + nb][j] = out[row(nb)][16 g + 4 kg + j]
   const long oa = scatter ? (long)scatter[rca] : rca, ob = scatter ? (long)scatter[rcb] : rcb;
-  if constexpr (F16) {
+  {
+    const float fin = (F16 ? inv_all : 1.f) * ((ncb & 1) ? -1.f : 1.f);   // undo the scales (fp16 form) and the last sign
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = acc[i] * inv_all;
+    for (int i = 0; i < 16; ++i) acc[i] = acc[i] * fin;
   }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
@@ -553,9 +566,9 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
     if (out_contig) CGAT_TRY(absmax_rows128_launch(We, s_col, W2, wmax, stream));
     else
       for (int j = 0; j < ncb; ++j) CGAT_TRY(absmax_rows128_launch(We + 128 * j, s_out, 128, wmax, stream));
-    CGAT_TRY(prepare_T_f16_scaled_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, wmax, stream));
+    CGAT_TRY(prepare_T_f16_scaled_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, wmax, stream, /*alternate=*/1));
   } else {
-    CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, 0, stream));
+    CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, /*alternate=*/1, stream));
   }
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);   // the per-edge launch / node-side and dense-layer uses
   const int grid = cdiv(E, 256);
@@ -592,7 +605,7 @@ int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const fl
   float* dst[TPREP_MAX];
   for (int h = 0; h < heads; ++h) { src[h] = W + (long)h * s_w; dst[h] = ws + (size_t)h * img; }
   // operand (a = column block, b = column in block, c = output k) = W_h[c * W2 + 128 a + b]: source dims (k, a, b)
-  const int rc_ = bilinear_prepare_T_batch(heads, src, dst, 128, ncb, 128, 1, 2, 0, part, stream, /*alternate=*/0);
+  const int rc_ = bilinear_prepare_T_batch(heads, src, dst, 128, ncb, 128, 1, 2, 0, part, stream, /*alternate=*/1);
   if (rc_ != CGAT_OK) return rc_;
   CGAT_PROF("rows_ge", stream);
   const HeadBatch hb = {s_x, (long)(img / 4), s_bias, s_y, 0};

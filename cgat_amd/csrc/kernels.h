@@ -158,7 +158,7 @@ int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stre
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream, const float* emax = nullptr);   // emax: fp16 form scaled by max |rows|
 int prepare_T_f16_scaled_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, const float* tmax,
-                                hipStream_t stream);
+                                hipStream_t stream, int alternate = 0);
 // dense layer at width 128 on the split-bf16 kernel: out = act(in W^T + bias) (+ out),  W(o, k) = W[o*so + k*sk]
 bool linear128_fast(int K, int N, long ldi, long ldo, const void* in, const void* out);
 size_t linear128_ws_bytes(int n_out = 128);
