@@ -437,8 +437,9 @@ extern "C" int cgat_gemm(const cgat_gemm_desc* d, void* ws, size_t ws_bytes, voi
 }
 extern "C" void cgat_set_bilinear_mode(int32_t mode) { bilinear_set_mode(mode); }
 extern "C" int32_t cgat_get_bilinear_mode(void) { return bilinear_mode(); }
+static size_t cgat_T_image_floats(int NA, int NB, int NC) { return bilinear_T_floats_max(NA, NB, NC); }
 extern "C" size_t cgat_bilinear_dual_workspace_bytes(int32_t rows) {
-  const size_t tq = ws_round((size_t)128 * 128 * 128 * 3 / 2 + 4, 4);
+  const size_t tq = ws_round(cgat_T_image_floats(128, 128, 128), 4);
   const size_t a = bilinear_dual_ws_bytes(rows), b = bilinear_rows_ws_bytes(rows, 128, 128, 128);
   return tq + (a > b ? a : b) + 256;
 }
@@ -452,7 +453,7 @@ extern "C" int cgat_bilinear_dual(const float* p, int64_t ldp, const float* q, i
     return CGAT_ERR_WORKSPACE;
   }
   float* Tq = (float*)ws;
-  const size_t off = ws_round((size_t)128 * 128 * 128 * 3 / 2 + 4, 4);
+  const size_t off = ws_round(cgat_T_image_floats(128, 128, 128), 4);
   void* rest = (char*)ws + off;
   hipStream_t s = (hipStream_t)stream;
   if (bilinear_dual_fast(128, 128, 128)) {
@@ -466,7 +467,7 @@ extern "C" int cgat_bilinear_dual(const float* p, int64_t ldp, const float* q, i
   return bilinear_rows_launch(zz, ldz, q, ldq, Tq, init2, ldi2, out2, ldo2, rows, 128, 128, 128, rest, ws_bytes - off, s);
 }
 extern "C" size_t cgat_bilinear_rows_workspace_bytes(int32_t rows, int32_t NA, int32_t NB, int32_t NC) {
-  return ws_round((size_t)NA * NB * NC * 3 / 2 + 4, 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
+  return ws_round(cgat_T_image_floats(NA, NB, NC), 4) + bilinear_rows_ws_bytes(rows, NA, NB, NC) + 256;
 }
 extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, int64_t ldq, const float* T,
                                   const float* init, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t NA,
@@ -476,7 +477,7 @@ extern "C" int cgat_bilinear_rows(const float* p, int64_t ldp, const float* q, i
     return CGAT_ERR_WORKSPACE;
   }
   float* Tq = (float*)ws;
-  size_t off = ws_round((size_t)NA * NB * NC * 3 / 2 + 4, 4);
+  size_t off = ws_round(cgat_T_image_floats(NA, NB, NC), 4);
   CGAT_TRY(bilinear_prepare_T(T, Tq, NA, NB, NC, 0, 1, 2, (hipStream_t)stream));
   return bilinear_rows_launch(p, ldp, q, ldq, Tq, init, ldi, out, ldo, rows, NA, NB, NC, (char*)ws + off,
                               ws_bytes - off, (hipStream_t)stream);

@@ -432,6 +432,246 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// f16x3c form of the forward contraction (round 4): 24-bit operands at 1.25 x the matrix time of the fp16 form.
+// Same workgroup shape, ring, scale-after flush and sign alternation as bilinear_rows128_ring16_kernel<2>; what differs:
+//  * a chunk is (a, column half, PAIR of 16-column blocks) over the whole K = 128 (prepare_T_f16c_kernel's image: 16 KB of
+//    fp16 planes + 9 KB of 6-bit images, contiguous), so the partial accumulators of a chunk are 2 blocks x 2 row blocks
+//    = 16 registers instead of 32 and are flushed at the end of every chunk -- that is what makes room for the 36 registers
+//    of the row operand's 6-bit images;
+//  * per chunk 8 groups of 6 fp16 MFMAs (k-step s, block cb2) and, riding with the first six groups, the three
+//    correction terms (t6 x h6, h6 x t6, l6 x l6: one v_mfma_f32_16x16x128_f8f6f4 per row block each) of the chunk's two
+//    column blocks; every fragment is read one group ahead;
+//  * 25 LDS-DMA pieces of 1 KB per chunk: three per wave and a fourth by wave 0 (its counted waits allow one more).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
+    const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const uint4* __restrict__ Tq,
+    const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo, int nrows, int NA, int tiles, int asplit,
+    long slab_stride, int vec_io, const float* __restrict__ tmax) {
+  constexpr int CH16 = F16C_CHUNK16;
+  constexpr int PST = 8 * 64;
+  __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
+  const int row_w = tile * 256 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;           // the lane's two output rows
+  const long rowc_a = row_a < nrows ? row_a : nrows - 1, rowc_b = row_b < nrows ? row_b : nrows - 1;
+  const int row_st = row_w + (lane & 31);                            // the row whose p this lane stages
+  const long rowc_st = row_st < nrows ? row_st : nrows - 1;
+  if (asplit > 1) {
+    out += (long)split * slab_stride;
+    if (split > 0) init = nullptr;
+  }
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned char* cring = reinterpret_cast<const unsigned char*>(smem) + 16384;
+  const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
+  p += (long)tile * 256 * ldp;                                       // scalar tile base + 32-bit lane offsets
+  const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 256) * ldp * 4);
+  const unsigned t_off = (unsigned)tid * 16;
+  const long last_chunk = (long)a_end * 4 - 1;
+
+  // q[row, 32 s + 8 kg + j] of both row blocks, scaled per row: two fp16 planes qf[2 s + nb] + the three 6-bit images
+  bf16x8 q1[8], q2[8];
+  frag6 ql6[2], qh6[2], qt6[2];
+  float rs_a, rs_b;                             // 1 / (scale of the lane's q row * scale of T)
+  {
+    float qv[2][32];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+    float st, it;
+    pow2_scale(tmax[0], st, it);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));          // the row's 128 values live in the four lanes n16 + 16 kg
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      (nb ? rs_b : rs_a) = iq * it;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) qv[nb][j] *= sq;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j];
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+      }
+      f16c_pack32(qv[nb], ql6[nb], qh6[nb], qt6[nb]);   // element 8 s + j <-> k = 32 s + 8 kg + j, as in the image
+    }
+  }
+  // acc[2 cb8 + nb][t] = out[row(nb)][16 cb8 + 4 kg + t]
+  f32x4 acc[16];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = nb ? row_b : row_a;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (init && row < nrows) {
+        const float* ip = init + (long)row * ldi + 16 * cb + 4 * kg;
+        if (vec_io) v = *reinterpret_cast<const float4*>(ip);
+        else v = make_float4(ip[0], ip[1], ip[2], ip[3]);
+      }
+      acc[2 * cb + nb][0] = v.x; acc[2 * cb + nb][1] = v.y; acc[2 * cb + nb][2] = v.z; acc[2 * cb + nb][3] = v.w;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define RC_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Tq + gi * CH16;                                                          \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+    glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
+    if (wave_u == 0) glds_b128(tb + 1536, t_off, dst + 24576);                                 \
+  }
+#define RC_PLOAD(a_)                                                                           \
+  {                                                                                            \
+    const int aa = (a_) < a_end ? (a_) : a_end - 1;                                            \
+    glds_b32(p + aa, prow_off, wave_p + (unsigned)((a_) & 3) * (PST * 4));                     \
+  }
+  // everything except the N_ youngest vector-memory operations of this wave (wave 0: + its extra piece) has landed
+#define RC_WAIT(N_) { if (wave_u == 0) wait_vmcnt<(N_) + 1>(); else wait_vmcnt<(N_)>(); }
+  RC_PLOAD(a_beg);
+  RC_PLOAD(a_beg + 1);
+  RC_TLOAD((long)a_beg * 4 + 0);
+  RC_TLOAD((long)a_beg * 4 + 1);
+  RC_TLOAD((long)a_beg * 4 + 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fb1, fb2;
+  frag6 ce;
+  // group g = 2 s + cb2 of a chunk: the two planes of block cb2 at k-step s
+#define RC_READ(F1_, F2_, slot_, g_)                                                           \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * CH16 + ((((g_) >> 1) * 2) * 2 + ((g_) & 1)) * 64;      \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[2 * 64];                                                                          \
+  }
+  // 6-bit fragment j = 3 cb2 + term of a chunk
+#define RC_CREAD(slot_, j_)                                                                    \
+  {                                                                                            \
+    const unsigned char* cp = cring + (slot_) * (CH16 * 16) + (j_) * 1536;                     \
+    const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
+    const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
+    ce.w[0] = u_.x; ce.w[1] = u_.y; ce.w[2] = u_.z; ce.w[3] = u_.w; ce.w[4] = w_.x; ce.w[5] = w_.y; \
+  }
+#define RC_MFMA(F1_, F2_, g_)                                                                  \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = part[2 * ((g_) & 1) + nb];                                                   \
+      P_ = mma16<true>(F2_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q2[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+    }                                                                                          \
+  }
+  // correction fragment j (held in ce) into the partial accumulators of its block
+#define RC_CORR(j_)                                                                            \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = part[2 * ((j_) / 3) + nb];                                                   \
+      if ((j_) % 3 == 0) P_ = f16c_mma_th(ce, qh6[nb], P_);                                    \
+      else if ((j_) % 3 == 1) P_ = f16c_mma_ht(ce, qt6[nb], P_);                               \
+      else P_ = f16c_mma_ll(ce, ql6[nb], P_);                                                  \
+    }                                                                                          \
+  }
+  RC_READ(fa1, fa2, 0, 0);
+  RC_CREAD(0, 0);
+  f32x4 part[4];
+  for (int a = a_beg; a < a_end; ++a) {
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {           // chunk (a, half = ch >> 1, block pair ch & 1) sits in ring slot ch
+      RC_TLOAD((long)a * 4 + ch + 3);
+      if (ch == 0) RC_PLOAD(a + 2);            // AFTER the T loads: see the wait below
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {         // groups 2 gp (set A) and 2 gp + 1 (set B)
+        RC_READ(fb1, fb2, ch, 2 * gp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * gp < 6) { RC_CORR(2 * gp); RC_CREAD(ch, 2 * gp + 1); }
+        RC_MFMA(fa1, fa2, 2 * gp);
+        if (gp < 3) RC_READ(fa1, fa2, ch, 2 * gp + 2)
+        else RC_READ(fa1, fa2, (ch + 1) & 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * gp + 1 < 6) {
+          RC_CORR(2 * gp + 1);
+          if (2 * gp + 2 < 6) RC_CREAD(ch, 2 * gp + 2)
+          else RC_CREAD((ch + 1) & 3, 0);
+        }
+        RC_MFMA(fb1, fb2, 2 * gp + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // the flush stays HERE: moved into the next chunk it would keep two sets
+      {                                        // of partial accumulators alive
+        float pva = pst[(a & 3) * PST] * rs_a, pvb = pst[(a & 3) * PST + 16] * rs_b;
+        const float pas_a = (a & 1) ? -pva : pva, pas_b = (a & 1) ? -pvb : pvb;
+#pragma unroll
+        for (int cb2 = 0; cb2 < 2; ++cb2)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[2 * (2 * ch + cb2) + 0][t] = fmaf(pas_a, part[2 * cb2 + 0][t], acc[2 * (2 * ch + cb2) + 0][t]);
+            acc[2 * (2 * ch + cb2) + 1][t] = fmaf(pas_b, part[2 * cb2 + 1][t], acc[2 * (2 * ch + cb2) + 1][t]);
+          }
+        // ... and is COMPLETE here: the wave-dependent wait below is control flow, and without this the compiler sinks
+        // all four flushes of an `a` behind its last barrier (64 partial accumulators alive instead of 16)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[4 * ch + i]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // chunk i + 2 (issued one iteration ago) must have landed.  Younger than it: this iteration's three (four) T loads
+      // and, for ch < 2, the p load issued right behind the T loads of ch == 0
+      if (ch < 2) RC_WAIT(4)
+      else RC_WAIT(3)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef RC_TLOAD
+#undef RC_PLOAD
+#undef RC_WAIT
+#undef RC_READ
+#undef RC_CREAD
+#undef RC_MFMA
+#undef RC_CORR
+  // the thread id is laundered so that the output addresses are computed HERE instead of being hoisted above the main
+  // loop and kept alive (= spilled) across it
+  int tl = tid;
+  asm volatile("" : "+v"(tl));
+  const int e_row = tile * 256 + (tl >> 6) * 32 + (tl & 15), e_kg = (tl >> 4) & 3;
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row = e_row + 16 * nb;
+      if (row < nrows) {
+        float* op = out + (long)row * ldo + 16 * cb + 4 * e_kg;
+        const f32x4 v = acc[2 * cb + nb];
+        if (vec_io) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Two gradients from one contraction (hypernetwork backward, reference Hypernetworksmp.py:77-83 under autograd):
 //     out1[n,c] = init1[n,c] + sum_a p[n,a] * M[n,a,c]              M[n,a,c] = sum_b q[n,b] T[a,b,c]
 //     dv  [n,a] =              sum_c zz[n,c] * M[n,a,c]
@@ -449,10 +689,14 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
     float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io,
     const float* __restrict__ tmax) {
-  constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes; tmax = max |T|
+  constexpr bool CORR = PASSES == 4;            // f16x3c: the fp16 form + the three 6-bit correction terms (mfma_bf16.h)
+  constexpr bool F16 = PASSES == 2 || CORR;     // two fp16 planes, three passes; tmax = max |T|
   constexpr int NP = F16 ? 2 : 3;
   constexpr int HP = NP * 256;                  // 16-byte pieces of one (a, half, k-step) block of the prepared T
-  constexpr int CH16 = 2 * HP;                  // per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
+  constexpr int CHM = 2 * HP;                   // planes per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
+  constexpr int CHC = CORR ? 576 : 0;           // + 9 KB: the 6-bit images of column block cb = s of both halves
+  constexpr int CH16 = CHM + CHC;
+  constexpr int NPL = CORR ? 3 : NP;            // LDS-DMA instructions per wave and k-step (wave 0: one more with CORR)
   constexpr int PST = 8 * 64;
   __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,8 +725,17 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the LDS-DMA base pointers must be SGPRs
   const int P0 = 64 * wave_u, P1 = 64 * wave_u + 512, P2 = 64 * wave_u + 1024;
   const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + (unsigned)P0 * 16);
+  // CORR: the prepared T is prepare_T_f16c_kernel's image, chunk (a, half, block pair) = 1600 pieces: the plane block
+  // (half, plane, cb) of k-step s lies at chunk(a, half, cb / 2) + ((2 s + plane) 2 + cb % 2) 64, the 6-bit images of
+  // block cb = s at chunk(a, half, s / 2) + 1024 + (s % 2) 288.  Piece P = 64 w + lane of the slot's [half0 | half1]
+  // images (288 pieces each) comes from half 0 or, two chunks further, from half 1; wave w moves piece block w, wave 0
+  // also block 8
+  const int wc = ((wave_u & 3) >> 1) * F16C_CHUNK16 + ((wave_u >> 2) * 2 + (wave_u & 1)) * 64;
+  const unsigned c_off = (unsigned)(tid * 16 + (tid >= 288 ? (2 * F16C_CHUNK16 - 288) * 16 : 0));
+  const unsigned c_off8 = (unsigned)((512 + lane) * 16 + (2 * F16C_CHUNK16 - 288) * 16);
 
   bf16x8 q1[8], q2[8], q3[F16 ? 1 : 8];
+  frag6 ql6[2], qh6[2], qt6[2];                 // CORR: the 6-bit images of the lane's 32 q values per row block
   float rs_a = 1.f, rs_b = 1.f;                 // F16: 1 / (scale of the lane's q row * scale of T)
   if constexpr (F16) {
     float qv[2][32];
@@ -508,12 +761,15 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
       pow2_scale(m, sq, iq);
       (nb ? rs_b : rs_a) = iq * it;
 #pragma unroll
+      for (int j = 0; j < 32; ++j) qv[nb][j] *= sq;
+#pragma unroll
       for (int s = 0; s < 4; ++s) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j];
         split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
       }
+      if constexpr (CORR) f16c_pack32(qv[nb], ql6[nb], qh6[nb], qt6[nb]);   // element 8 s + j <-> k = 32 s + 8 kg + j
     }
   } else {
 #pragma unroll
@@ -551,12 +807,26 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   {                                                                                            \
     const long gi = (gi_) < last_step ? (gi_) : last_step;                                     \
     const long a_ = gi >> 2, s_ = gi & 3;                                                      \
-    const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                       \
-    const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                       \
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
-    glds_b128(h0 + P0, l_off, dst);                                                            \
-    glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                          \
-    if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                                \
+    if constexpr (CORR) {                                                                      \
+      const uint4* ab = Tq + a_ * (4 * F16C_CHUNK16);                                          \
+      glds_b128(ab + s_ * 256 + wc, l_off, dst);                                               \
+      glds_b128(ab + s_ * 256 + wc + 2 * F16C_CHUNK16, l_off, dst + 8192);                     \
+      const uint4* tc = ab + (s_ >> 1) * F16C_CHUNK16 + 1024 + (s_ & 1) * 288;                 \
+      glds_b128(tc, c_off, dst + CHM * 16);                                                    \
+      if (wave_u == 0) glds_b128(tc, c_off8, dst + CHM * 16 + 8192);                           \
+    } else {                                                                                   \
+      const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                     \
+      const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                     \
+      glds_b128(h0 + P0, l_off, dst);                                                          \
+      glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                        \
+      if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                              \
+    }                                                                                          \
+  }
+#define DU_WAIT(N_)                                                                            \
+  {                                                                                            \
+    if constexpr (CORR) { if (wave_u == 0) wait_vmcnt<(N_) + 1>(); else wait_vmcnt<(N_)>(); }  \
+    else wait_vmcnt<(N_)>();                                                                   \
   }
 #define DU_PLOAD(a_)                                                                           \
   {                                                                                            \
@@ -573,6 +843,15 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   asm volatile("" ::: "memory");
 
   bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+  frag6 ce;
+  const unsigned char* cring = reinterpret_cast<const unsigned char*>(smem) + CHM * 16 + hf * 4608;
+#define DC_READ(F_, slot_, term_)                                                              \
+  {                                                                                            \
+    const unsigned char* cp = cring + (slot_) * (CH16 * 16) + (term_) * 1536;                  \
+    const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
+    const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
+    F_.w[0] = u_.x; F_.w[1] = u_.y; F_.w[2] = u_.z; F_.w[3] = u_.w; F_.w[4] = w_.x; F_.w[5] = w_.y; \
+  }
 #define DU_READ(F1_, F2_, F3_, slot_, cb_)                                                     \
   {                                                                                            \
     const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
@@ -597,6 +876,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
   }
   DU_READ(fa1, fa2, fa3, 0, 0);
+  if constexpr (CORR) DC_READ(ce, 0, 0);
   f32x4 part[8];
   // dvp[half][a][row]: the 32 rows of a wave are 128 contiguous bytes per `a` (row-major [row][a] would be 4-byte
   // stores at a 512-byte stride: 12x write amplification, measured with WRITE_SIZE).  32-bit offsets: the launcher
@@ -609,14 +889,34 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     for (int s = 0; s < 4; ++s) {                // k-step (a, s) sits in ring slot s
       DU_TLOAD((long)a * 4 + s + 3);
       if (s == 0) DU_PLOAD(a + 2);             // AFTER the T loads: see the wait below
+      // CORR: k-step s also adds the three correction terms (K = 128 each) of column block cb = s, whose 6-bit images
+      // ride in this ring slot: one term per MFMA group, fragments a group ahead
 #pragma unroll
       for (int cbp = 0; cbp < 2; ++cbp) {
         DU_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CORR) {   // the term whose fragment was read one group ago, then that group's planes
+          if (cbp == 0) {
+            part[2 * s + 0] = f16c_mma_th(ce, qh6[0], part[2 * s + 0]);
+            part[2 * s + 1] = f16c_mma_th(ce, qh6[1], part[2 * s + 1]);
+            DC_READ(ce, s, 1);
+          } else {
+            part[2 * s + 0] = f16c_mma_ll(ce, ql6[0], part[2 * s + 0]);
+            part[2 * s + 1] = f16c_mma_ll(ce, ql6[1], part[2 * s + 1]);
+            DC_READ(ce, (s + 1) & 3, 0);
+          }
+        }
         DU_MFMA(fa1, fa2, fa3, s, 2 * cbp);
         if (cbp == 0) DU_READ(fa1, fa2, fa3, s, 2)
         else DU_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CORR) {
+          if (cbp == 0) {
+            part[2 * s + 0] = f16c_mma_ht(ce, qt6[0], part[2 * s + 0]);
+            part[2 * s + 1] = f16c_mma_ht(ce, qt6[1], part[2 * s + 1]);
+            DC_READ(ce, s, 2);
+          }
+        }
         DU_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
       }
       if (s == 3) {
@@ -643,22 +943,28 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
           dvp[dv_a + a * dv_ld] = sga * da;        // dv_ld >= the tile-padded row count: no bounds check needed
           dvp[dv_b + a * dv_ld] = sgb * db;
         }
+        if constexpr (CORR) {   // the flush is complete HERE (the wave-dependent wait below is control flow: see ring16c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[i]));
+        }
       }
       // chunk i + 2 (issued one iteration ago) must have landed; everything issued after it may stay in flight
       // (in-order vmcnt, stores included): the previous `a`'s two dv stores + this step's T loads + the p load (s = 0),
       // the p load + T loads (s = 1), T loads (s = 2), T loads + this `a`'s dv stores (s = 3).  With vmcnt(NP)
       // everywhere the s = 3 wait, whose two youngest operations are the stores, drained the T loads issued a
       // quarter of a microsecond earlier.
-      if (s == 0) wait_vmcnt<NP + 3>();
-      else if (s == 1) wait_vmcnt<NP + 1>();
-      else if (s == 2) wait_vmcnt<NP>();
-      else wait_vmcnt<NP + 2>();
+      if (s == 0) DU_WAIT(NPL + 3)
+      else if (s == 1) DU_WAIT(NPL + 1)
+      else if (s == 2) DU_WAIT(NPL)
+      else DU_WAIT(NPL + 2)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DU_TLOAD
+#undef DU_WAIT
+#undef DC_READ
 #undef DU_PLOAD
 #undef DU_READ
 #undef DU_MFMA1
@@ -758,6 +1064,52 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
     dst[(blk + 0) * 2048 + in] = x1;
     dst[(blk + 1) * 2048 + in] = x2;
     dst[(blk + 2) * 2048 + in] = x3;
+  }
+}
+
+// f16x3c (mfma_bf16.h): the prepared T of the contraction kernels' 24-bit form.  One chunk = (a, column half, pair of
+// 16-column blocks) = everything the forward kernel needs for 32 output columns of one `a`, 25 KB contiguous:
+//   [k-step s = b/32 (4)][plane: h, l (2)][cb2 (2)][lane 64 x 16 B]          two fp16 planes of 2^k sgn(a) T[a]  (16 KB)
+//   [cb2 (2)][term: 0 t6, 1 h6, 2 l6 (3)][lane 64 x 16 B | lane 64 x 8 B]    6-bit images for the correction terms (9 KB)
+// lane = 16 kg + c % 16 holds, per plane fragment, b = 32 s + 8 kg + j (j = 0..7) and, per 6-bit fragment, all 32 values
+// b = 32 s + 8 kg + j <-> element 8 s + j: the order in which the contraction kernels hold their row operand.
+// One thread per (a, column c, k-group kg).  max |T| (tmax) lies behind the last chunk.
+__global__ void prepare_T_f16c_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int NA, long sa, long sb,
+                                      long sc, int alternate, const float* __restrict__ tmax) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)NA * 512) return;
+  // thread order follows the fastest source stride where it can: c fastest when sc == 1
+  int a = (int)(i >> 9), c, kg;
+  if (sc == 1) { c = (int)(i & 127); kg = (int)((i >> 7) & 3); }
+  else { kg = (int)(i & 3); c = (int)((i >> 2) & 127); }
+  float st, it;
+  pow2_scale(tmax[0], st, it);
+  if (alternate && (a & 1)) st = -st;
+  float v[32];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[8 * s + j] = src[a * sa + (long)(32 * s + 8 * kg + j) * sb + c * sc] * st;
+  const int half = c >> 6, cbp = (c & 63) >> 5, cb2 = (c >> 4) & 1, lane = 16 * kg + (c & 15);
+  uint4* chunk = dst + (((long)a * 2 + half) * 2 + cbp) * F16C_CHUNK16;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = v[8 * s + j];
+    bf16x8 h, l;
+    split2_x8_f16(w, h, l);
+    chunk[((s * 2 + 0) * 2 + cb2) * 64 + lane] = __builtin_bit_cast(uint4, h);
+    chunk[((s * 2 + 1) * 2 + cb2) * 64 + lane] = __builtin_bit_cast(uint4, l);
+  }
+  frag6 l6, h6, t6;
+  f16c_pack32(v, l6, h6, t6);
+  unsigned* blk = reinterpret_cast<unsigned*>(chunk + 1024) + cb2 * 1152;
+#pragma unroll
+  for (int term = 0; term < 3; ++term) {
+    const frag6& f = term == 0 ? t6 : (term == 1 ? h6 : l6);
+    *reinterpret_cast<uint4*>(blk + term * 384 + lane * 4) = make_uint4(f.w[0], f.w[1], f.w[2], f.w[3]);
+    *reinterpret_cast<uint2*>(blk + term * 384 + 256 + lane * 2) = make_uint2(f.w[4], f.w[5]);
   }
 }
 
@@ -983,6 +1335,19 @@ int prepare_T_f16_launch(const float* src, void* dst, int NA, long sa, long sb, 
   return CGAT_OK;
 }
 
+// f16x3c form (layout at prepare_T_f16c_kernel): NA * F16C_A_FLOATS floats, max |T| behind them; contiguous source
+int prepare_T_f16c_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
+                          hipStream_t stream) {
+  const long total = (long)NA * 128 * 128;
+  if (total <= 0) return CGAT_OK;
+  float* tmax = (float*)dst + (size_t)NA * F16C_A_FLOATS;
+  CGAT_TRY(absmax_launch(src, total, tmax, stream));
+  hipLaunchKernelGGL(prepare_T_f16c_kernel, dim3(cdiv((long)NA * 512, 256)), dim3(256), 0, stream, src, (uint4*)dst, NA,
+                     sa, sb, sc, alternate, (const float*)tmax);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // ---- the same for several [NA,128,128] tensors at once (the predicted layers of a hypernetwork: 4 x (memset + absmax +
 // prepare) = 12 launches of ~8 us each with a dispatch gap between every pair -> 2 launches).  Maxima without atomics:
 // stage 1 writes one partial maximum per workgroup, every workgroup of stage 2 folds the 64 partials of its tensor.
@@ -1172,25 +1537,36 @@ static int rows_per_wg() { return bilinear_mode() == 0 ? 128 : 256; }
 
 bool bilinear_T_interleaved(int NB, int NC) { return NB == 128 && NC == 128 && !force_generic(); }
 
-// 0 = f32-input MFMA (exact fp32), 6 = 3-way bf16 split with 6 MFMA passes (fp32-equivalent), 3 = 3 passes,
-// 2 = 2-way fp16 split with 3 passes (22-bit operands, scaled per row / per tensor)
+// 0 = f32-input MFMA (exact fp32), 6 = 3-way bf16 split with 6 MFMA passes (24-bit operands), 3 = 3 passes,
+// 2 = 2-way fp16 split with 3 passes (22-bit operands, scaled per row / per tensor),
+// 4 = "f16x3c" (DEFAULT): 24-bit operands -- the fp16 passes of mode 2 plus the three 6-bit correction terms
+//     (mfma_bf16.h) in the kernels that have that form (the hypernetwork contractions); every other matrix-core kernel
+//     runs its six-pass bf16 form, exactly as in mode 6 (tests on `bilinear_mode() == 2` are false, `!= 0` / `!= 3` true)
 static int g_bilinear_mode = -1;
 int bilinear_mode() {
   if (g_bilinear_mode < 0) {
-    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 | bf16x3 | f16x3 (default)
-    g_bilinear_mode = 2;
+    const char* e = getenv("CGAT_BILINEAR_MODE");   // f32 | bf16x6 | bf16x3 | f16x3 | f16x3c (default)
+    g_bilinear_mode = 4;
     if (e && !strcmp(e, "f32")) g_bilinear_mode = 0;
     if (e && !strcmp(e, "bf16x3")) g_bilinear_mode = 3;
     if (e && !strcmp(e, "bf16x6")) g_bilinear_mode = 6;
+    if (e && !strcmp(e, "f16x3")) g_bilinear_mode = 2;
   }
   return g_bilinear_mode;
 }
-void bilinear_set_mode(int m) { g_bilinear_mode = (m == 6 || m == 3 || m == 2) ? m : 0; }
-// floats of workspace the prepared T occupies (the bf16 form stores three 2-byte planes, the fp16 form two and its scale)
+void bilinear_set_mode(int m) { g_bilinear_mode = (m == 6 || m == 3 || m == 2 || m == 4) ? m : 0; }
+// floats of workspace the prepared T occupies (the bf16 form stores three 2-byte planes, the fp16 form two and its scale,
+// the f16x3c form the fp16 form + 18 bits per element of 6-bit images)
 size_t bilinear_T_floats(int NA, int NB, int NC) {
   size_t n = (size_t)NA * NB * NC;
   if (!bilinear_T_interleaved(NB, NC) || bilinear_mode() == 0) return n;
+  if (bilinear_mode() == 4) return (size_t)NA * F16C_A_FLOATS + 4;
   return bilinear_mode() == 2 ? n + 4 : (n * 3 + 1) / 2;
+}
+
+size_t bilinear_T_floats_max(int NA, int NB, int NC) {   // the mode may change between a size query and the call
+  const size_t n = (size_t)NA * NB * NC, a = n * 3 / 2 + 4, b = (size_t)NA * F16C_A_FLOATS + 4;
+  return (bilinear_T_interleaved(NB, NC) && b > a) ? b : a;
 }
 
 size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
@@ -1232,10 +1608,14 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
                       (!init1 || ((ldi1 % 4) == 0 && (((uintptr_t)init1) & 15) == 0))) ? 1 : 0;
   {
     CGAT_PROF("bilinear_dual", stream);
-    const float* tmax = T + (size_t)128 * 128 * 128;   // f16x3 only
+    const float* tmax = T + (size_t)128 * 128 * 128;   // f16x3: max |T| behind the two planes
     if (bilinear_mode() == 6)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<6>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
+    else if (bilinear_mode() == 4)   // f16x3c: prepare_T_f16c_kernel's image, max |T| behind it
+      hipLaunchKernelGGL((bilinear_rows128_dual_kernel<4>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
+                         (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io,
+                         T + (size_t)128 * F16C_A_FLOATS);
     else if (bilinear_mode() == 2)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<2>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
@@ -1284,10 +1664,14 @@ int bilinear_rows_launch(const float* p, long ldp, const float* q, long ldq, con
         cgat_set_error("bilinear_rows: ldp %ld too large", ldp);
         return CGAT_ERR_ARG;
       }
-      const float* tmax = T + (size_t)NA * 128 * 128;   // f16x3 only: max |T| behind the two planes
+      const float* tmax = T + (size_t)NA * 128 * 128;   // f16x3: max |T| behind the two planes (f16x3c: behind its image)
       if (bilinear_mode() == 6)
         hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<6>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
                            (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax);
+      else if (bilinear_mode() == 4)
+        hipLaunchKernelGGL(bilinear_rows128_ring16c_kernel, dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq,
+                           (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io,
+                           T + (size_t)NA * F16C_A_FLOATS);
 #ifdef CGAT_DEV_ABLATIONS   // timing-only variants (wrong results): only in builds made for tools/ring_ablation.py
       else if (bilinear_mode() == 2 && getenv("CGAT_RING_ABL")) {
 #define RG_ABL(A_) hipLaunchKernelGGL((bilinear_rows128_ring16_kernel<2, A_>), dim3(tiles2 * sp), dim3(512), 0, stream, p, ldp, q, ldq, (const uint4*)T, init, ldi, dst, dld, nrows, NA, tiles2, sp, stride, vec_io, tmax)
@@ -2449,6 +2833,7 @@ int bilinear_prepare_T(const float* src, float* dst, int n0, int n1, int n2, int
   if (bilinear_T_interleaved(dims[perm1], dims[perm2]) && bilinear_mode() != 0) {
     long st[3] = {(long)n1 * n2, (long)n2, 1};   // source strides of dims 0, 1, 2
     if (bilinear_mode() == 2) return prepare_T_f16_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
+    if (bilinear_mode() == 4) return prepare_T_f16c_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
     return prepare_T_bf16_launch(src, dst, dims[perm0], st[perm0], st[perm1], st[perm2], 1, stream);
   }
   return permute3_launch(src, dst, n0, n1, n2, perm0, perm1, perm2,

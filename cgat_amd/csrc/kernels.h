@@ -72,6 +72,7 @@ bool bilinear_T_interleaved(int NB, int NC);
 int bilinear_mode();               // 0 f32 MFMA, 6 / 3: split-bf16 passes
 void bilinear_set_mode(int m);
 size_t bilinear_T_floats(int NA, int NB, int NC);  // workspace floats of the prepared T
+size_t bilinear_T_floats_max(int NA, int NB, int NC);   // ... in whichever arithmetic mode needs most (size queries)
 // several tensors in two launches (f16x3 mode at width 128; CGAT_ERR_UNSUPPORTED otherwise -> prepare one by one)
 #define TPREP_MAX 8
 struct TPrepBatch {

@@ -89,6 +89,63 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- "f16x3c": the f16x3 product completed to 24-bit operands (round 4) ----
+// With x (already scaled as above) split EXACTLY into x = h + l + t, h = fp16(x), l = fp16(x - h), t = x - h - l
+// (|l| <= 2^-11 |x|; t is 0 or +-ulp32(x), i.e. the 24th bit), a product is
+//      a b = [hh + hl + lh] + [ll + ht + th] + O(2^-34):
+// the first bracket is what the three fp16 passes compute exactly; the second has weight <= 2^-22, so three or four
+// significant bits of each factor evaluate it to 2^-26 -- it runs as three block-scaled v_mfma_scale_f32_16x16x128_f8f6f4
+// instructions on 6-bit pieces (K = 128 per instruction at the cycles of ONE 16x16x32 fp16 pass: +25 % matrix time
+// over f16x3 instead of +100 % for six bf16 passes), accumulating into the same fp32 accumulator (the E8M0 scale
+// operands undo the pieces' power-of-two scales).  Piece formats: l as fp6 e2m3 (|l| <= 4: four bits), h and t as bf6
+// e3m2 (three bits, nine binades; scales below).
+// Measured against fp64 (tools/f16x3c_probe.hip): at or below the error of the six-pass bf16 split and of the f32-input
+// MFMA on every operand distribution tried.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+struct frag6 { unsigned w[6]; };          // 32 six-bit values of one lane: one operand of the 16x16x128 instruction
+__device__ __forceinline__ i32x8 frag6_as8(const frag6& f) {   // the builtin takes 8 dwords; the 6-bit formats read 6
+  i32x8 r;
+  r[0] = f.w[0]; r[1] = f.w[1]; r[2] = f.w[2]; r[3] = f.w[3]; r[4] = f.w[4]; r[5] = f.w[5];
+  return r;
+}
+// piece scales: l6 = fp6(l) (|l| <= 4), h6 = bf6(h * 2^-12) (< 4), t6 = bf6(t * 2^12) (|t| <= 2^-10 -> <= 4): every product
+// of two pieces carries the scale 1, so the instruction needs no E8M0 scale operands (zero scale arguments select the
+// unscaled v_mfma_f32_16x16x128_f8f6f4: no scale VGPRs).  bf6 spans 0.0625 .. 28: t (a power of two) is exact for every
+// element within 2^-7 of its block's maximum, h keeps three bits within 2^-4 of it.
+// prepared-T image of the contraction kernels in this form (bilinear.hip, prepare_T_f16c_kernel)
+#define F16C_CHUNK16 1600                       // 16-byte pieces per chunk (a, column half, column-block pair): 25 KB
+#define F16C_A_FLOATS (4 * F16C_CHUNK16 * 4)    // floats per `a` (four chunks)
+// the three 6-bit images of 32 scaled values (the lane's K elements in ANY order: both operands of a product use this
+// same function on identically ordered values, so the instruction's interleaving of its two sources does not matter)
+__device__ __forceinline__ void f16c_pack32(const float (&x)[32], frag6& l6, frag6& h6, frag6& t6) {
+  f32x16v l0, l1, h0, h1, t0, t1;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float h = (float)(_Float16)x[j];
+    const float r = x[j] - h;
+    const float l = (float)(_Float16)r;
+    const float t = r - l;
+    if (j < 16) { l0[j] = l; h0[j] = h; t0[j] = t; } else { l1[j - 16] = l; h1[j - 16] = h; t1[j - 16] = t; }
+  }
+  const u32x6 a = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(l0, l1, 1.0f);          // the instruction divides by its scale
+  const u32x6 b = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(h0, h1, 4096.0f);
+  const u32x6 c = __builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(t0, t1, 0x1p-12f);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { l6.w[i] = a[i]; h6.w[i] = b[i]; t6.w[i] = c[i]; }
+}
+// acc += A_t B_h + A_h B_t + A_l B_l  (smallest first); A = the instruction's A operand (rows), B its B operand
+__device__ __forceinline__ f32x4 f16c_mma_th(const frag6& at, const frag6& bh, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag6_as8(at), frag6_as8(bh), c, 3, 3, 0, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 f16c_mma_ht(const frag6& ah, const frag6& bt, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag6_as8(ah), frag6_as8(bt), c, 3, 3, 0, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 f16c_mma_ll(const frag6& al, const frag6& bl, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag6_as8(al), frag6_as8(bl), c, 2, 2, 0, 0, 0, 0);
+}
+
 // ---- bf16 STORAGE of activations (the edge phase's Z / gZ in the "bf16" edge-storage mode, BASELINE configs[4]) ----
 // four fp32 -> four bf16 (round to nearest even, two v_cvt_pk_bf16_f32) as 8 bytes, and back (exact)
 __device__ __forceinline__ uint2 pack4_bf16(float4 v) {

@@ -997,18 +997,22 @@ def segment_sum(x, index_plan, index):
     return SegmentSumFn.apply(x.index_select(0, perm), index_plan.rowptr, index.index_select(0, perm))
 
 
-_MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "f16x3": 2}
+_MODES = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "f16x3": 2, "f16x3c": 4}
 # the mode a fresh process starts in (env CGAT_BILINEAR_MODE overrides the built-in default)
-DEFAULT_MODE = os.environ.get("CGAT_BILINEAR_MODE", "f16x3")
+DEFAULT_MODE = os.environ.get("CGAT_BILINEAR_MODE", "f16x3c")
 if DEFAULT_MODE not in _MODES:
-    DEFAULT_MODE = "f16x3"
+    DEFAULT_MODE = "f16x3c"
 
 
 def set_bilinear_mode(mode):
-    """Arithmetic of the width-128 matrix-core kernels: "f16x3" (default; every fp32 operand scaled by a power
-    of two and split into two fp16 pieces = 22 bits, three fp16-MFMA passes, fp32 accumulate -- measured at the
-    error of an fp32 product chain), "bf16x6" (three bf16 pieces, six passes, same accuracy), "f32" (f32-input
-    MFMA, exact fp32 fmaf chains) or "bf16x3" (three bf16 passes, ~4e-6 relative; fails the parity tests)."""
+    """Arithmetic of the width-128 matrix-core kernels.
+    "f16x3c" (default, round 4): 24-bit operands.  Every fp32 operand is scaled by a power of two and split EXACTLY into
+    three pieces x = h + l + t (two fp16 pieces and the 24th bit); a product is hh + hl + lh on three fp16-MFMA passes
+    (exact) plus ll + ht + th (weight <= 2^-22) on three 6-bit MFMA passes of K = 128 (csrc/mfma_bf16.h), fp32 accumulate:
+    1.25 x the matrix time of "f16x3" where "bf16x6" needs 2 x.  Kernels without that form run their "bf16x6" form.
+    "bf16x6": three bf16 pieces (24 bits), six bf16-MFMA passes.  "f16x3": two fp16 pieces = 22-bit operands, three passes
+    (the fastest; not the default because its operands are narrower than fp32's).  "f32": f32-input MFMA, exact fp32
+    fmaf chains.  "bf16x3": three bf16 passes, ~4e-6 relative; fails the parity tests (diagnostic)."""
     lib.cgat_set_bilinear_mode(_MODES[mode])
 
 

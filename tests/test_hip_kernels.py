@@ -135,7 +135,7 @@ def test_gemm_blocked_A(env, kmajor):
                                     # tiles, a width off the 16-byte grid)
                                     (64, 1000), (96, 333), (22, 130), (256, 130)])
 @pytest.mark.parametrize("with_init", [False, True])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3", "f16x3c"])
 def test_bilinear_rows(env, W, rows, with_init, mode):
     """All three arithmetic modes of the width-128 kernel; the 6-pass bf16 split and the f32-input MFMA are
     held to the same 2e-5, the 3-pass form to 2e-5 as well (measured ~3e-6)."""
@@ -165,7 +165,7 @@ def test_bilinear_rows(env, W, rows, with_init, mode):
 
 @pytest.mark.parametrize("rows", [1, 127, 128, 300, 1000, 83340])
 @pytest.mark.parametrize("with_init", [False, True])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3", "f16x3c"])
 def test_bilinear_dual(env, rows, with_init, mode):
     """The fused pair of hypernetwork gradients (one contraction, two outputs) against fp64 einsums; the f32 mode
     runs the same entry point as two contractions."""
@@ -200,7 +200,7 @@ def test_bilinear_dual(env, rows, with_init, mode):
 
 @pytest.mark.parametrize("W,rows", [(128, 64), (128, 1000), (128, 2500), (16, 45), (128, 33), (128, 20001),
                                     (64, 20001), (96, 1000), (22, 130), (256, 300)])
-@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f32", "bf16x3", "f16x3", "f16x3c"])
 def test_bilinear_wgrad(env, W, rows, mode):
     _, _lib, ops, dev = env
     ops.set_bilinear_mode(mode)
@@ -516,7 +516,7 @@ def test_segment_softmax(env, F, with_mult):
                                    # head at 64 crystals), forward over K and input gradient over N
                                    (64, 1024, 1024), (64, 1024, 200), (130, 640, 512), (64, 200, 1024)])
 @pytest.mark.parametrize("act", ["none", "leaky", "tanh"])
-@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32", "f16x3c"])
 def test_linear_routes(env, M, K, N, act, mode):
     """cgat_linear_forward/backward through ops.LinearFn: the split routes (K == 128, or 128 outputs), the one-pass
     weight+bias gradient kernel (K == N == 128, from a single row to the BASELINE row count) and the generic engine,
@@ -596,7 +596,7 @@ def test_linear_backward_dact_and_hidden_maximum(env, M, Hd, mode):
 
 
 @pytest.mark.parametrize("M,H,Hd", [(1000, 5, 256), (77, 3, 256), (3000, 2, 384), (500, 5, 128), (640, 9, 256)])
-@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "f32", "f16x3c"])
 def test_heads_linear_batched(env, M, H, Hd, mode):
     """cgat_heads_linear_forward / _backward_dact (all heads of a network's second layer in one call; grid.y = head in the
     f16x3 mode, head by head otherwise -- Hd = 128 and 9 heads take the loop in every mode) against H single-head

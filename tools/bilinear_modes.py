@@ -18,7 +18,7 @@ def call():
                                            W, rows, W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
 res = {}
 for rnd in range(5):
-    for mode in (0, 6, 3, 2):
+    for mode in (0, 6, 3, 2, 4):
         _lib.lib.cgat_set_bilinear_mode(mode)
         call(); torch.cuda.synchronize()
         if rnd == 0:
@@ -43,7 +43,7 @@ r1 = torch.einsum("na,nac->nc", p[sel].double().cpu(), M); r2 = torch.einsum("nc
 def dual():
     _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, q.data_ptr(), W, z.data_ptr(), W, T.data_ptr(), None, W, o1.data_ptr(), W,
                                            None, W, o2.data_ptr(), W, rows, ws2.data_ptr(), ws2.numel(), None), "dual")
-for mode in (6, 3, 2):
+for mode in (6, 3, 2, 4):
     _lib.lib.cgat_set_bilinear_mode(mode)
     dual(); torch.cuda.synchronize()
     e1_ = float((o1[sel].double().cpu() - r1).abs().max() / r1.abs().max()); e2_ = float((o2[sel].double().cpu() - r2).abs().max() / r2.abs().max())
@@ -59,7 +59,7 @@ scale = torch.logspace(-6, 4, rows).to(dev)[:, None]
 qs = q * scale
 Ts = T * 1e-3
 refs = torch.einsum("na,nb,abc->nc", p[sel].double().cpu(), qs[sel].double().cpu(), Ts.double().cpu())
-for mode in (6, 2):
+for mode in (6, 2, 4):
     _lib.lib.cgat_set_bilinear_mode(mode)
     _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, qs.data_ptr(), W, Ts.data_ptr(), None, W, out.data_ptr(),
                                            W, rows, W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
@@ -71,7 +71,7 @@ wout = torch.empty(W, W, W, device=dev)
 ws3 = torch.empty(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W), dtype=torch.uint8, device=dev)
 for tag, (pp, qq, rr) in {"unit": (p, q, z), "scaled": (p * 3e-4, q * 2e3, z * 1e-5)}.items():
     refw = torch.einsum("na,nb,nc->abc", pp[:20000].double(), qq[:20000].double(), rr[:20000].double()).cpu()
-    for mode in (6, 3, 2):
+    for mode in (6, 3, 2, 4):
         _lib.lib.cgat_set_bilinear_mode(mode)
         def wg(n=rows):
             _lib.check(_lib.lib.cgat_bilinear_wgrad(pp.data_ptr(), W, qq.data_ptr(), W, rr.data_ptr(), W, wout.data_ptr(), n, W, W, W,
