@@ -473,7 +473,7 @@ def bench_train(args, rank, world, device):
                "ms_per_step": 1e3 * elapsed / args.steps, "step_ms_gpu_events": step_ms,
                "launch_bound": {"library_kernel_launches_per_step": train_launches, "host_syncs_per_step": train_syncs},
                "higher_is_better": True, "scaling": args.scaling,
-               "vs_baseline": None, "dtype": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
+               "vs_baseline": None, "dtype": "f32 storage / " + P.get_bilinear_mode(),
                "data": "synthetic", "bilinear_mode": P.get_bilinear_mode(),
                "config": {"workload": f"train step: {per_rank} ragged crystals (2..40 atoms, 24 stored / {K_NBR} used nbrs) per "
                                       f"rank and step, CGAtNet(200,128,4,msg_heads=3,update_edges=True), RobustL1, FusedAdamW, "
@@ -680,6 +680,10 @@ def main():
     ap.add_argument("--edge-storage", choices=["f32", "bf16"], default="f32",
                     help="storage of the per-edge intermediates Z / gZ (bf16 = the 'bf16 activations' of configs[4]; "
                          "tolerance 1e-2 instead of 1e-4: never the default, reported in the line)")
+    ap.add_argument("--mode", choices=["f16x3c", "bf16x6", "f16x3", "f32"], default=None,
+                    help="arithmetic of the matrix-core kernels (cgat_amd.set_bilinear_mode); default: the library's default, "
+                         "f16x3c = 24-bit operands.  `value` is measured in this mode; the other modes are reported under "
+                         "`modes`, each from a fresh process")
     ap.add_argument("--workload", choices=["layer", "stack", "collate", "optim", "train", "stress", "edge_hyper", "lightning"], default="layer",
                     help="layer: BASELINE metric (one GATConvNodes layer).  stack: informational, the full "
                          "CGAtNet(200,128,4,msg_heads=3) fwd+bwd of config 3 on the same 1M-edge batch")
@@ -695,6 +699,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (cuda device); there is no CPU path to measure")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.mode is not None:
+        P.set_bilinear_mode(args.mode)
 
     if args.workload == "collate":
         return bench_collate(args, rank, world, device)
@@ -788,17 +794,28 @@ def main():
     mode = P.get_bilinear_mode()
     modes_ms, stack_ms = {mode: 1e3 * elapsed / args.steps}, None
     if world == 1 and not args.no_extra_legs and args.workload == "layer" and K_used == K_NBR:
-        for m in ("f16x3", "bf16x6", "f32"):
-            if m == mode:
-                continue
-            P.set_bilinear_mode(m)
-            modes_ms[m] = 1e3 * _time_steps(step, 1, 5 if m != "f32" else 3, world) / (5 if m != "f32" else 3)
-        P.set_bilinear_mode(mode)
         del step
         torch.cuda.empty_cache()
         sstep, _, _ = make_stack_workload(args.graphs, rank, world, device)
         stack_ms = 1e3 * _time_steps(sstep, 1, 3, world) / 3
         del sstep
+        torch.cuda.empty_cache()
+        # the same timed region in the other arithmetic modes: a FRESH child process per mode (no process-global switch
+        # behind this process' back), the same --steps / --warmup, no CPU leg, no further legs
+        import subprocess
+        for m in ("f16x3c", "bf16x6", "f16x3", "f32"):
+            if m == mode:
+                continue
+            k, w = (args.steps, args.warmup) if m != "f32" else (max(3, args.steps // 4), 2)
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", m, "--steps", str(k), "--warmup", str(w),
+                   "--graphs", str(args.graphs), "--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                modes_ms[m] = float(json.loads(line)["ms_per_step"])
+            except Exception as ex:                        # a failed leg must not take the headline down with it
+                modes_ms[m] = None
+                sys.stderr.write(f"bench.py: mode leg {m} failed: {ex}\n")
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -809,6 +826,7 @@ def main():
         kernels = {"bilinear_wgrad": "bilinear_wgrad128_f16p_kernel", "bilinear_dual": "bilinear_rows128_dual_kernel",
                    "bilinear_rows": "bilinear_rows128_ring16_kernel"}
         layers_per_launch = {"bilinear_wgrad": 4, "bilinear_dual": 1, "bilinear_rows": 1}   # f16x3: one batched dT launch
+        kpasses = {}                                       # matrix-core pass-equivalents per product, per kernel
         if mode == "f32":
             kernels = {"bilinear_wgrad": "bilinear_wgrad128_kernel", "bilinear_rows": "bilinear_rows128_kernel"}
             layers_per_launch["bilinear_wgrad"] = 1
@@ -821,6 +839,25 @@ def main():
                     "3 v_mfma_f32_*_f16 passes per product, fp32 accumulate (measured at the error of an fp32 "
                     f"product chain): executed MFMA flop = 3 x algorithmic, so the roof for ALGORITHMIC flop is the dense "
                     f"fp16 peak {MFMA_BF16_PEAK_TFLOPS:.0f} / 3; the f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
+        elif mode == "f16x3c":
+            # 24-bit operands: three fp16 passes + three 6-bit passes that run K = 128 in the cycles of one fp16 pass of
+            # K = 32 (4 x the rate): 3 + 3/4 = 3.75 pass-equivalents of matrix time per product in the kernels that have
+            # the form; the others run their six-pass bf16 form
+            kernels["bilinear_rows"] = "bilinear_rows128_ring16c_kernel"
+            F16C = getattr(P.ops, "F16C_KERNELS", ("bilinear_rows", "bilinear_dual"))
+            kpasses = {t: (3.75 if t in F16C else 6) for t in kernels}
+            if "bilinear_wgrad" not in F16C:
+                kernels["bilinear_wgrad"] = "bilinear_wgrad128_bf16_kernel"
+                layers_per_launch["bilinear_wgrad"] = 1
+            passes = 3.75
+            peak = MFMA_BF16_PEAK_TFLOPS / passes
+            note = ("24-bit operands: every fp32 operand scaled by a power of two and split EXACTLY into h + l + t (two fp16 "
+                    "pieces + the 24th bit); a product = hh + hl + lh as 3 v_mfma_f32_16x16x32_f16 passes (exact) + ll + ht + "
+                    "th (weight <= 2^-22) as 3 v_mfma_f32_16x16x128_f8f6f4 passes on 6-bit images (4 x the fp16 rate per "
+                    "flop), fp32 accumulate: executed matrix time = 3.75 fp16-pass-equivalents per product in the kernels "
+                    f"with this form (roof for ALGORITHMIC flop = {MFMA_BF16_PEAK_TFLOPS:.0f} / 3.75), 6 bf16 passes "
+                    f"({MFMA_BF16_PEAK_TFLOPS:.0f} / 6) in the others -- each kernel's `peak` says which; measured error vs "
+                    "fp64 at or below the six-pass bf16 split's and the f32-input MFMA's (tools/f16x3c_probe.hip)")
         else:
             kernels["bilinear_wgrad"] = "bilinear_wgrad128_bf16_kernel"
             layers_per_launch["bilinear_wgrad"] = 1
@@ -845,8 +882,10 @@ def main():
             avg_ms = ms_t / n_t
             fl = flops_per_layer * layers_per_launch[tag]
             ach = fl / (avg_ms * 1e-3) / 1e12
-            per_kernel[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1),
-                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            kpeak = MFMA_BF16_PEAK_TFLOPS / kpasses[tag] if tag in kpasses else peak
+            per_kernel[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(kpeak, 1),
+                               "unit": "TFLOP/s", "frac": round(ach / kpeak, 4),
+                               "matrix_passes_per_product": kpasses.get(tag, passes),
                                # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
                                # per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE); see profiles/
                                "traffic": traffic.get(kname, {}).get("hbm_bytes_per_launch"),
@@ -857,11 +896,12 @@ def main():
             if tag in concurrent and prof_x.get(tag, (0, 0))[0]:
                 x_ms = prof_x[tag][1] / prof_x[tag][0]
                 x_ach = per_kernel[tag]["flops_per_launch"] / (x_ms * 1e-3) / 1e12
+                peak_t = per_kernel[tag]["peak"]
                 per_kernel[tag]["concurrent"] = ("runs on the side stream on half of the CUs beside the HBM-bound attention "
                                                  "backward: the timed-region duration is shared; `exclusive` = the same "
                                                  "kernel alone on the chip, from a serial pass after the timed region")
                 per_kernel[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4), "achieved": round(x_ach, 2),
-                                                "frac": round(x_ach / peak, 4)}
+                                                "frac": round(x_ach / peak_t, 4)}
         if per_kernel:
             # the roofline object is for the kernel with the largest GPU time per step INSIDE the timed region, whatever
             # stream it ran on; its `frac` is the in-region one (side-stream kernels also carry their exclusive numbers)
@@ -913,21 +953,25 @@ def main():
                                              "frac": round(x_gbs / 8000.0, 4)}
         # the two per-edge products over the rebuilt gZ rows: 2 * E * W2 * 128 flop each, against the same matrix roof
         edge_mfma = {}
+        if mode == "f16x3c":
+            peak_e = MFMA_BF16_PEAK_TFLOPS / 6             # the per-edge products run their six-pass bf16 form in this mode
+        else:
+            peak_e = peak
         if mode != "f32":
             for tag, kname in (("edge_ge", "edge_ge_kernel"), ("edge_gw", "edge_gw_kernel")):
                 n_t, ms_t = prof[tag]
                 if n_t:
                     fl = 2.0 * E * W2cols * C_FEA / (n_t / args.steps)          # one launch per chunk of the step
                     ach = fl / (ms_t / n_t * 1e-3) / 1e12
-                    edge_mfma[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak, 1),
-                                      "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches_per_step": n_t / args.steps,
+                    edge_mfma[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(peak_e, 1),
+                                      "unit": "TFLOP/s", "frac": round(ach / peak_e, 4), "launches_per_step": n_t / args.steps,
                                       "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
                                       "flops_per_launch": fl}
                     if tag in concurrent and prof_x.get(tag, (0, 0))[0]:
                         x_ms = prof_x[tag][1] / prof_x[tag][0]
                         edge_mfma[tag]["exclusive"] = {"avg_launch_ms": round(x_ms, 4),
                                                        "achieved": round(fl / (x_ms * 1e-3) / 1e12, 2),
-                                                       "frac": round(fl / (x_ms * 1e-3) / 1e12 / peak, 4)}
+                                                       "frac": round(fl / (x_ms * 1e-3) / 1e12 / peak_e, 4)}
         shares = {}
         for tag in ALL_TAGS:
             n_t, ms_t = prof[tag]
@@ -948,7 +992,9 @@ def main():
                   else "edges/sec through one CGAT attention layer (fwd+bwd), 64M-edge large-neighbour batch in closed "
                        "chunks [BASELINE configs[4]]" if stress
                   else "batch-edges/sec through the full CGAT stack (4 layers, fwd+bwd), 1M-edge batch [informational]")
-        dtype = {"f16x3": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
+        dtype = {"f16x3c": "f32 storage / f16x3c (24-bit operands: exact h + l + t split, 3 fp16 + 3 six-bit matrix passes "
+                           "where built, six bf16 passes elsewhere; fp32 accumulate)",
+                 "f16x3": "f32 storage / f16x3 split (22-bit operands, fp32 accumulate)",
                  "bf16x6": "f32 storage / bf16x6 split (24-bit operands, fp32 accumulate)",
                  "bf16x3": "f32 storage / bf16x3 split (16-bit products; diagnostic mode)",
                  "f32": "f32 (f32-input MFMA)"}[mode]
@@ -983,10 +1029,12 @@ def main():
                 "hbm_bytes_compulsory": int(comp), "hbm_frac_compulsory": round(comp / (ms * 1e-3) / 8e12, 4),
                 "hbm_bytes_executed": int(execd), "hbm_frac": round(execd / (ms * 1e-3) / 8e12, 4),
                 "hbm_bytes_executed_by_kernel_family": by_family}
-            out["modes"] = {"what": "ms per step of the same layer step in each arithmetic mode (this process, after the "
-                                    "timed region; `value` is the mode named in bilinear_mode)",
-                            **{m: round(v, 3) for m, v in modes_ms.items()},
-                            "edges_per_s": {m: round(E / (v * 1e-3), 1) for m, v in modes_ms.items()}}
+            out["modes"] = {"what": "ms per step of the same timed region in each arithmetic mode: `value` is the mode named in "
+                                    "bilinear_mode (this process); every other mode is a fresh child process running "
+                                    "`bench.py --mode M` with the same --steps / --warmup (f32: a quarter of the steps). "
+                                    "f16x3c and bf16x6 carry 24-bit operands, f16x3 22-bit, f32 is the f32-input MFMA",
+                            **{m: (round(v, 3) if v is not None else None) for m, v in modes_ms.items()},
+                            "edges_per_s": {m: (round(E / (v * 1e-3), 1) if v else None) for m, v in modes_ms.items()}}
             if stack_ms is not None:
                 out["stack_fwd_bwd_ms"] = {"ms_per_step": round(stack_ms, 2), "batch_edges_per_s": round(E / (stack_ms * 1e-3), 1),
                                            "edge_layer_passes_per_s": round(4 * E / (stack_ms * 1e-3), 1),
