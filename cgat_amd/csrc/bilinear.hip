@@ -672,6 +672,271 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// f16x3c form of the fused backward contraction (round 4): out1 = init1 + sum_a p[:,a] M[:,a,:] and the partial sums of
+// dv[n,a] = sum_c zz[n,c] M[n,a,c] from ONE contraction M[n,a,c] = sum_b q[n,b] T[a,b,c] (bilinear_rows128_dual_kernel's
+// algebra), on bilinear_rows128_ring16c_kernel's machinery (same prepared image, chunks, ring, correction terms).
+//
+// Loop order: the 32-column chunk index ch = (half, block pair) is the OUTER loop, `a` the inner one.  The second
+// gradient needs zz[n, c] for the chunk's columns at every flush; with `a` outermost (the forward kernel's order) that
+// is either 64 registers for all 128 columns -- the dual kernel pays them by giving a wave only 64 columns, i.e. 128
+// rows per workgroup and twice the L2 -> LDS traffic per row, which is what bounds it -- or a reload per chunk (tried:
+// +41 % vector-memory traffic, 1.42 ms against 1.18 without the loads).  With ch outermost a wave holds the zz values and
+// the output accumulators of ONE chunk column range at a time (16 + 16 registers instead of 64 + 64), covers all 128
+// columns of its 32 rows in four phases, and a workgroup is 256 rows like the forward kernel's.  The prepared image is
+// read in (ch, a) order -- chunks are contiguous 25-KB pieces either way -- and every chunk of T is still streamed once
+// per workgroup.  dv comes out as four partial sums per (row, a), one per phase: dvp[ch][a][row] (dual_finish_kernel
+// adds them).  The ring slot of a chunk is its sequence number mod 4 (run-time: one address add per chunk).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void bilinear_rows128_dualc_kernel(
+    const float* __restrict__ p, long ldp, const float* __restrict__ q, long ldq, const float* __restrict__ zz, long ldz,
+    const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
+    float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io,
+    const float* __restrict__ tmax) {
+  constexpr int CH16 = F16C_CHUNK16;
+  constexpr int PST = 8 * 64;
+  __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int a_beg = (int)((long)NA * split / asplit), a_end = (int)((long)NA * (split + 1) / asplit);
+  // chunks of this workgroup: sequence number n = ch * (a_end - a_beg) + (a - a_beg)
+  const int row_w = tile * 256 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;           // the lane's two output rows
+  const long rowc_a = row_a < nrows ? row_a : nrows - 1, rowc_b = row_b < nrows ? row_b : nrows - 1;
+  const int row_st = row_w + (lane & 31);                            // the row whose p this lane stages
+  const long rowc_st = row_st < nrows ? row_st : nrows - 1;
+  if (asplit > 1) {
+    out += (long)split * slab_stride;
+    if (split > 0) init = nullptr;
+  }
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const unsigned wave_p = __builtin_amdgcn_readfirstlane(sbase + 4 * CH16 * 16 + wave * 256);
+  const bf16x8* ring0 = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const float* pst = reinterpret_cast<const float*>(smem + 4 * CH16) + wave * 64 + n16;
+  p += (long)tile * 256 * ldp;                                       // scalar tile base + 32-bit lane offsets
+  const unsigned prow_off = (unsigned)((rowc_st - (long)tile * 256) * ldp * 4);
+  const unsigned t_off = (unsigned)tid * 16;
+
+  // q[row, 32 s + 8 kg + j] of both row blocks, scaled per row: two fp16 planes qf[2 s + nb] + the three 6-bit images
+  bf16x8 q1[8], q2[8];
+  frag6 ql6[2], qh6[2], qt6[2];
+  float rs_a, rs_b;                             // 1 / (scale of the lane's q row * scale of T)
+  {
+    float qv[2][32];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>(q + (nb ? rowc_b : rowc_a) * ldq + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+    float st, it;
+    pow2_scale(tmax[0], st, it);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));          // the row's 128 values live in the four lanes n16 + 16 kg
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      (nb ? rs_b : rs_a) = iq * it;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) qv[nb][j] *= sq;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j];
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+      }
+      f16c_pack32(qv[nb], ql6[nb], qh6[nb], qt6[nb]);   // element 8 s + j <-> k = 32 s + 8 kg + j, as in the image
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // chunk (ch_, a_) with sequence number n_ -> ring slot n_ % 4; its p column -> staging slot n_ % 4 (each wave stages
+  // and reads its own rows).  Past the end the last chunk is loaded again (keeps the counted waits uniform).
+#define DC_TLOAD(n_, ch_, a_)                                                                  \
+  {                                                                                            \
+    const int ci_ = __builtin_amdgcn_readfirstlane((a_) * 4 + (ch_));   /* uniform: the DMA base must be scalar */ \
+    const uint4* tb = Tq + (long)ci_ * CH16;                                                   \
+    const unsigned dst = wave_t + (unsigned)__builtin_amdgcn_readfirstlane((n_) & 3) * (CH16 * 16); \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+    glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
+    if (wave_u == 0) glds_b128(tb + 1536, t_off, dst + 24576);                                 \
+  }
+#define DC_PLOAD(n_, a_)                                                                       \
+  glds_b32(p + __builtin_amdgcn_readfirstlane(a_), prow_off,                                   \
+           wave_p + (unsigned)__builtin_amdgcn_readfirstlane((n_) & 3) * (PST * 4));
+  // (ta, tch) = the chunk three sequence numbers ahead of the one being computed, advanced in (ch, a) order
+  int ta = a_beg, tch = 0;
+#define DC_ADVANCE() { if (ta + 1 < a_end) ++ta; else if (tch < 3) { ta = a_beg; ++tch; } }
+  // everything except the N_ youngest vector-memory operations of this wave (wave 0: + its extra piece) has landed
+#define DC_WAIT(N_) { if (wave_u == 0) wait_vmcnt<(N_) + 1>(); else wait_vmcnt<(N_)>(); }
+  DC_TLOAD(0, tch, ta); DC_PLOAD(0, ta); DC_ADVANCE();
+  DC_TLOAD(1, tch, ta); DC_PLOAD(1, ta); DC_ADVANCE();
+  DC_TLOAD(2, tch, ta); DC_PLOAD(2, ta); DC_ADVANCE();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fb1, fb2;
+  frag6 ce;
+  // group g = 2 s + cb2 of the chunk at ring_: the two planes of block cb2 at k-step s
+#define DC_READ(F1_, F2_, ring_, g_)                                                           \
+  {                                                                                            \
+    const bf16x8* fp = (ring_) + ((((g_) >> 1) * 2) * 2 + ((g_) & 1)) * 64;                    \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[2 * 64];                                                                          \
+  }
+  // 6-bit fragment j = 3 cb2 + term of the chunk at ring_
+#define DC_CREAD(ring_, j_)                                                                    \
+  {                                                                                            \
+    const unsigned char* cp = reinterpret_cast<const unsigned char*>((ring_) - lane) + 16384 + (j_) * 1536; \
+    const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
+    const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
+    ce.w[0] = u_.x; ce.w[1] = u_.y; ce.w[2] = u_.z; ce.w[3] = u_.w; ce.w[4] = w_.x; ce.w[5] = w_.y; \
+  }
+#define DC_MFMA(F1_, F2_, g_)                                                                  \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = part[2 * ((g_) & 1) + nb];                                                   \
+      P_ = mma16<true>(F2_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q2[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+    }                                                                                          \
+  }
+#define DC_CORR(j_)                                                                            \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = part[2 * ((j_) / 3) + nb];                                                   \
+      if ((j_) % 3 == 0) P_ = f16c_mma_th(ce, qh6[nb], P_);                                    \
+      else if ((j_) % 3 == 1) P_ = f16c_mma_ht(ce, qt6[nb], P_);                               \
+      else P_ = f16c_mma_ll(ce, ql6[nb], P_);                                                  \
+    }                                                                                          \
+  }
+  DC_READ(fa1, fa2, ring0, 0);
+  DC_CREAD(ring0, 0);
+  f32x4 part[4];
+  int n = 0;                                   // sequence number of the chunk being computed
+#pragma clang loop unroll(disable)
+  for (int ch = 0; ch < 4; ++ch) {             // columns 32 ch .. 32 ch + 31
+    // this phase's output accumulators and zz values: acc[2 cb2 + nb][t] <-> (row(nb), column 32 ch + 16 cb2 + 4 kg + t)
+    f32x4 acc[4], zq[4];
+#pragma unroll
+    for (int cb2 = 0; cb2 < 2; ++cb2)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int row = nb ? row_b : row_a;
+        const int col = 32 * ch + 16 * cb2 + 4 * kg;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (init && row < nrows) {
+          const float* ip = init + (long)row * ldi + col;
+          if (vec_io) v = *reinterpret_cast<const float4*>(ip);
+          else v = make_float4(ip[0], ip[1], ip[2], ip[3]);
+        }
+        acc[2 * cb2 + nb] = f32x4{v.x, v.y, v.z, v.w};
+        const float4 z4 = *reinterpret_cast<const float4*>(zz + (nb ? rowc_b : rowc_a) * ldz + col);
+        zq[2 * cb2 + nb] = f32x4{z4.x, z4.y, z4.z, z4.w};
+      }
+    float* dvc = dvp + (long)ch * NA * dv_ld;   // this phase's partial sums: dvp[ch][a][row]
+#pragma clang loop unroll(disable)
+    for (int a = a_beg; a < a_end; ++a, ++n) {
+      const bf16x8* ring = ring0 + (n & 3) * CH16;
+      const bf16x8* ringn = ring0 + ((n + 1) & 3) * CH16;
+      DC_TLOAD(n + 3, tch, ta);
+      DC_PLOAD(n + 3, ta);
+      DC_ADVANCE();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {         // groups 2 gp (set A) and 2 gp + 1 (set B)
+        DC_READ(fb1, fb2, ring, 2 * gp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * gp < 6) { DC_CORR(2 * gp); DC_CREAD(ring, 2 * gp + 1); }
+        DC_MFMA(fa1, fa2, 2 * gp);
+        if (gp < 3) DC_READ(fa1, fa2, ring, 2 * gp + 2)
+        else DC_READ(fa1, fa2, ringn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * gp + 1 < 6) {
+          DC_CORR(2 * gp + 1);
+          if (2 * gp + 2 < 6) DC_CREAD(ring, 2 * gp + 2)
+          else DC_CREAD(ringn, 0);
+        }
+        DC_MFMA(fb1, fb2, 2 * gp + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // the flush stays HERE (see bilinear_rows128_ring16c_kernel)
+      {
+        const float sg = (a & 1) ? -1.f : 1.f;   // part = (-1)^a M[n,a,:] (the prepared T alternates in sign)
+        const float sga = sg * rs_a, sgb = sg * rs_b;
+        const float pas_a = sga * pst[(n & 3) * PST], pas_b = sgb * pst[(n & 3) * PST + 16];
+        float da = 0.f, db = 0.f;
+#pragma unroll
+        for (int cb2 = 0; cb2 < 2; ++cb2)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[2 * cb2 + 0][t] = fmaf(pas_a, part[2 * cb2 + 0][t], acc[2 * cb2 + 0][t]);
+            acc[2 * cb2 + 1][t] = fmaf(pas_b, part[2 * cb2 + 1][t], acc[2 * cb2 + 1][t]);
+            da = fmaf(part[2 * cb2 + 0][t], zq[2 * cb2 + 0][t], da);
+            db = fmaf(part[2 * cb2 + 1][t], zq[2 * cb2 + 1][t], db);
+          }
+        asm volatile("" : "+v"(da));             // keep the two sums out of v_pk_* (note in edgez.hip)
+        asm volatile("" : "+v"(db));
+        da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
+        db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
+        // one store for both row blocks: lanes 0..15 carry rows 0..15 (da), lanes 16..31 rows 16..31 (db)
+        const float dv = (kg & 1) ? sgb * db : sga * da;
+        if (kg < 2) dvc[(long)a * dv_ld + row_w + (lane & 31)] = dv;   // dv_ld >= the tile-padded row count
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i]));   // the flush is complete here (ring16c)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // chunk n + 2 (issued one iteration ago) must have landed.  Younger than it: the previous iteration's p load and
+      // dv store, this iteration's three (four) T loads, p load and dv store.  (Anything issued between two phases --
+      // output stores, zz / init loads -- sits in between and only makes the wait stricter.)  The p value of chunk n + 1
+      // was requested two iterations ago, in front of chunk n + 2: it has landed too.
+      DC_WAIT(7)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // this phase's 32 output columns (the thread id is laundered: addresses computed here, not kept across the loop)
+    {
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int e_row = tile * 256 + (tl >> 6) * 32 + (tl & 15), e_kg = (tl >> 4) & 3;
+#pragma unroll
+      for (int cb2 = 0; cb2 < 2; ++cb2)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int row = e_row + 16 * nb;
+          if (row < nrows) {
+            float* op = out + (long)row * ldo + 32 * ch + 16 * cb2 + 4 * e_kg;
+            const f32x4 v = acc[2 * cb2 + nb];
+            if (vec_io) *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            else { op[0] = v[0]; op[1] = v[1]; op[2] = v[2]; op[3] = v[3]; }
+          }
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef DC_TLOAD
+#undef DC_PLOAD
+#undef DC_WAIT
+#undef DC_ADVANCE
+#undef DC_READ
+#undef DC_CREAD
+#undef DC_MFMA
+#undef DC_CORR
+}
+
+// ---------------------------------------------------------------------------------------
 // Two gradients from one contraction (hypernetwork backward, reference Hypernetworksmp.py:77-83 under autograd):
 //     out1[n,c] = init1[n,c] + sum_a p[n,a] * M[n,a,c]              M[n,a,c] = sum_b q[n,b] T[a,b,c]
 //     dv  [n,a] =              sum_c zz[n,c] * M[n,a,c]
@@ -689,14 +954,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     const uint4* __restrict__ Tq, const float* __restrict__ init, long ldi, float* __restrict__ out, long ldo,
     float* __restrict__ dvp, int dv_ld, int nrows, int NA, int tiles, int asplit, long slab_stride, int vec_io,
     const float* __restrict__ tmax) {
-  constexpr bool CORR = PASSES == 4;            // f16x3c: the fp16 form + the three 6-bit correction terms (mfma_bf16.h)
-  constexpr bool F16 = PASSES == 2 || CORR;     // two fp16 planes, three passes; tmax = max |T|
+  constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes; tmax = max |T|
   constexpr int NP = F16 ? 2 : 3;
   constexpr int HP = NP * 256;                  // 16-byte pieces of one (a, half, k-step) block of the prepared T
-  constexpr int CHM = 2 * HP;                   // planes per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
-  constexpr int CHC = CORR ? 576 : 0;           // + 9 KB: the 6-bit images of column block cb = s of both halves
-  constexpr int CH16 = CHM + CHC;
-  constexpr int NPL = CORR ? 3 : NP;            // LDS-DMA instructions per wave and k-step (wave 0: one more with CORR)
+  constexpr int CH16 = 2 * HP;                  // per ring slot: 24 KB (16 KB): [half][plane][cb][lane]
   constexpr int PST = 8 * 64;
   __shared__ uint4 smem[4 * CH16 + 4 * PST / 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -725,17 +986,8 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar copy: the LDS-DMA base pointers must be SGPRs
   const int P0 = 64 * wave_u, P1 = 64 * wave_u + 512, P2 = 64 * wave_u + 1024;
   const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + (unsigned)P0 * 16);
-  // CORR: the prepared T is prepare_T_f16c_kernel's image, chunk (a, half, block pair) = 1600 pieces: the plane block
-  // (half, plane, cb) of k-step s lies at chunk(a, half, cb / 2) + ((2 s + plane) 2 + cb % 2) 64, the 6-bit images of
-  // block cb = s at chunk(a, half, s / 2) + 1024 + (s % 2) 288.  Piece P = 64 w + lane of the slot's [half0 | half1]
-  // images (288 pieces each) comes from half 0 or, two chunks further, from half 1; wave w moves piece block w, wave 0
-  // also block 8
-  const int wc = ((wave_u & 3) >> 1) * F16C_CHUNK16 + ((wave_u >> 2) * 2 + (wave_u & 1)) * 64;
-  const unsigned c_off = (unsigned)(tid * 16 + (tid >= 288 ? (2 * F16C_CHUNK16 - 288) * 16 : 0));
-  const unsigned c_off8 = (unsigned)((512 + lane) * 16 + (2 * F16C_CHUNK16 - 288) * 16);
 
   bf16x8 q1[8], q2[8], q3[F16 ? 1 : 8];
-  frag6 ql6[2], qh6[2], qt6[2];                 // CORR: the 6-bit images of the lane's 32 q values per row block
   float rs_a = 1.f, rs_b = 1.f;                 // F16: 1 / (scale of the lane's q row * scale of T)
   if constexpr (F16) {
     float qv[2][32];
@@ -761,15 +1013,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
       pow2_scale(m, sq, iq);
       (nb ? rs_b : rs_a) = iq * it;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) qv[nb][j] *= sq;
-#pragma unroll
       for (int s = 0; s < 4; ++s) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j];
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j] * sq;
         split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
       }
-      if constexpr (CORR) f16c_pack32(qv[nb], ql6[nb], qh6[nb], qt6[nb]);   // element 8 s + j <-> k = 32 s + 8 kg + j
     }
   } else {
 #pragma unroll
@@ -807,26 +1056,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   {                                                                                            \
     const long gi = (gi_) < last_step ? (gi_) : last_step;                                     \
     const long a_ = gi >> 2, s_ = gi & 3;                                                      \
+    const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                       \
+    const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                       \
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
-    if constexpr (CORR) {                                                                      \
-      const uint4* ab = Tq + a_ * (4 * F16C_CHUNK16);                                          \
-      glds_b128(ab + s_ * 256 + wc, l_off, dst);                                               \
-      glds_b128(ab + s_ * 256 + wc + 2 * F16C_CHUNK16, l_off, dst + 8192);                     \
-      const uint4* tc = ab + (s_ >> 1) * F16C_CHUNK16 + 1024 + (s_ & 1) * 288;                 \
-      glds_b128(tc, c_off, dst + CHM * 16);                                                    \
-      if (wave_u == 0) glds_b128(tc, c_off8, dst + CHM * 16 + 8192);                           \
-    } else {                                                                                   \
-      const uint4* h0 = Tq + ((a_ * 2 + 0) * 4 + s_) * HP;                                     \
-      const uint4* h1 = Tq + ((a_ * 2 + 1) * 4 + s_) * HP;                                     \
-      glds_b128(h0 + P0, l_off, dst);                                                          \
-      glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                        \
-      if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                              \
-    }                                                                                          \
-  }
-#define DU_WAIT(N_)                                                                            \
-  {                                                                                            \
-    if constexpr (CORR) { if (wave_u == 0) wait_vmcnt<(N_) + 1>(); else wait_vmcnt<(N_)>(); }  \
-    else wait_vmcnt<(N_)>();                                                                   \
+    glds_b128(h0 + P0, l_off, dst);                                                            \
+    glds_b128(P1 < HP ? h0 + P1 : h1 + (P1 - HP), l_off, dst + 8192);                          \
+    if (NP == 3) glds_b128(h1 + (P2 - HP), l_off, dst + 16384);                                \
   }
 #define DU_PLOAD(a_)                                                                           \
   {                                                                                            \
@@ -843,15 +1078,6 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
   asm volatile("" ::: "memory");
 
   bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
-  frag6 ce;
-  const unsigned char* cring = reinterpret_cast<const unsigned char*>(smem) + CHM * 16 + hf * 4608;
-#define DC_READ(F_, slot_, term_)                                                              \
-  {                                                                                            \
-    const unsigned char* cp = cring + (slot_) * (CH16 * 16) + (term_) * 1536;                  \
-    const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
-    const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
-    F_.w[0] = u_.x; F_.w[1] = u_.y; F_.w[2] = u_.z; F_.w[3] = u_.w; F_.w[4] = w_.x; F_.w[5] = w_.y; \
-  }
 #define DU_READ(F1_, F2_, F3_, slot_, cb_)                                                     \
   {                                                                                            \
     const bf16x8* fp = ring + (slot_) * (CH16) + (cb_) * 64;                                   \
@@ -876,7 +1102,6 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     DU_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb_) + 1])                                 \
   }
   DU_READ(fa1, fa2, fa3, 0, 0);
-  if constexpr (CORR) DC_READ(ce, 0, 0);
   f32x4 part[8];
   // dvp[half][a][row]: the 32 rows of a wave are 128 contiguous bytes per `a` (row-major [row][a] would be 4-byte
   // stores at a 512-byte stride: 12x write amplification, measured with WRITE_SIZE).  32-bit offsets: the launcher
@@ -889,34 +1114,14 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     for (int s = 0; s < 4; ++s) {                // k-step (a, s) sits in ring slot s
       DU_TLOAD((long)a * 4 + s + 3);
       if (s == 0) DU_PLOAD(a + 2);             // AFTER the T loads: see the wait below
-      // CORR: k-step s also adds the three correction terms (K = 128 each) of column block cb = s, whose 6-bit images
-      // ride in this ring slot: one term per MFMA group, fragments a group ahead
 #pragma unroll
       for (int cbp = 0; cbp < 2; ++cbp) {
         DU_READ(fb1, fb2, fb3, s, 2 * cbp + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CORR) {   // the term whose fragment was read one group ago, then that group's planes
-          if (cbp == 0) {
-            part[2 * s + 0] = f16c_mma_th(ce, qh6[0], part[2 * s + 0]);
-            part[2 * s + 1] = f16c_mma_th(ce, qh6[1], part[2 * s + 1]);
-            DC_READ(ce, s, 1);
-          } else {
-            part[2 * s + 0] = f16c_mma_ll(ce, ql6[0], part[2 * s + 0]);
-            part[2 * s + 1] = f16c_mma_ll(ce, ql6[1], part[2 * s + 1]);
-            DC_READ(ce, (s + 1) & 3, 0);
-          }
-        }
         DU_MFMA(fa1, fa2, fa3, s, 2 * cbp);
         if (cbp == 0) DU_READ(fa1, fa2, fa3, s, 2)
         else DU_READ(fa1, fa2, fa3, (s + 1) & 3, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CORR) {
-          if (cbp == 0) {
-            part[2 * s + 0] = f16c_mma_ht(ce, qt6[0], part[2 * s + 0]);
-            part[2 * s + 1] = f16c_mma_ht(ce, qt6[1], part[2 * s + 1]);
-            DC_READ(ce, s, 2);
-          }
-        }
         DU_MFMA(fb1, fb2, fb3, s, 2 * cbp + 1);
       }
       if (s == 3) {
@@ -943,28 +1148,22 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
           dvp[dv_a + a * dv_ld] = sga * da;        // dv_ld >= the tile-padded row count: no bounds check needed
           dvp[dv_b + a * dv_ld] = sgb * db;
         }
-        if constexpr (CORR) {   // the flush is complete HERE (the wave-dependent wait below is control flow: see ring16c)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[i]));
-        }
       }
       // chunk i + 2 (issued one iteration ago) must have landed; everything issued after it may stay in flight
       // (in-order vmcnt, stores included): the previous `a`'s two dv stores + this step's T loads + the p load (s = 0),
       // the p load + T loads (s = 1), T loads (s = 2), T loads + this `a`'s dv stores (s = 3).  With vmcnt(NP)
       // everywhere the s = 3 wait, whose two youngest operations are the stores, drained the T loads issued a
       // quarter of a microsecond earlier.
-      if (s == 0) DU_WAIT(NPL + 3)
-      else if (s == 1) DU_WAIT(NPL + 1)
-      else if (s == 2) DU_WAIT(NPL)
-      else DU_WAIT(NPL + 2)
+      if (s == 0) wait_vmcnt<NP + 3>();
+      else if (s == 1) wait_vmcnt<NP + 1>();
+      else if (s == 2) wait_vmcnt<NP>();
+      else wait_vmcnt<NP + 2>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DU_TLOAD
-#undef DU_WAIT
-#undef DC_READ
 #undef DU_PLOAD
 #undef DU_READ
 #undef DU_MFMA1
@@ -983,19 +1182,22 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_dual_kernel(
     }
 }
 
-// out1 = sum of the a-split slabs (if any); out2[n,a] = init2[n,a] + dvp[0][a][n] + dvp[1][a][n].
+// out1 = sum of the a-split slabs (if any); out2[n,a] = init2[n,a] + sum_h dvp[h][a][n] (nhalf partial sums: 2 column
+// halves from the dual kernel, 4 column phases from the f16x3c one).
 // One workgroup per 32 rows: the [128 a][32 n] pieces of dvp are read coalesced and transposed through LDS.
 __global__ __launch_bounds__(256) void dual_finish_kernel(const float* __restrict__ slab, int splits, long slab_stride,
                                                           int nrows, float* __restrict__ out1, long ldo1,
                                                           const float* __restrict__ dvp, int dv_ld, int NA,
                                                           const float* __restrict__ init2, long ldi2,
-                                                          float* __restrict__ out2, long ldo2) {
+                                                          float* __restrict__ out2, long ldo2, int nhalf) {
   __shared__ float tile[128][33];
   const int n0 = blockIdx.x * 32, tid = threadIdx.x;
   for (int idx = tid; idx < 128 * 32; idx += 256) {   // idx = a * 32 + n
     const int a = idx >> 5, n = idx & 31;
     const long o = (long)a * dv_ld + n0 + n;
-    tile[a][n] = dvp[o] + dvp[(long)NA * dv_ld + o];
+    float t = dvp[o];
+    for (int h = 1; h < nhalf; ++h) t += dvp[(long)h * NA * dv_ld + o];   // partial sums in a fixed order
+    tile[a][n] = t;
   }
   __syncthreads();
   // A thread owns 16 outputs (n = k * 2 + tid / 128, c = tid % 128).  The slab loop is OUTERMOST so that the 16 loads
@@ -1580,10 +1782,14 @@ size_t bilinear_rows_ws_bytes(int nrows, int NA, int NB, int NC) {
 bool bilinear_dual_fast(int NA, int NB, int NC) {
   return bilinear_mode() != 0 && NA == 128 && NB == 128 && NC == 128 && !force_generic();
 }
-static int dual_dv_ld(int nrows) { return cdiv(nrows, 128) * 128; }   // rows padded to whole 128-row tiles
+static int dual_dv_ld(int nrows) { return cdiv(nrows, 256) * 256; }   // rows padded to whole tiles (128 or 256 rows)
+static int dual_asplit_max(int nrows) {   // the f16x3c form runs 256-row workgroups, the others 128-row ones
+  const int a = rows_asplit(nrows, 128), b = rows_asplit(nrows, 256);
+  return a > b ? a : b;
+}
 size_t bilinear_dual_ws_bytes(int nrows) {
-  const int sp = rows_asplit(nrows, 128);
-  return ws_round((size_t)2 * dual_dv_ld(nrows) * 128 + (sp > 1 ? (size_t)sp * nrows * 128 : 0), 4);
+  const int sp = dual_asplit_max(nrows);
+  return ws_round((size_t)4 * dual_dv_ld(nrows) * 128 + (sp > 1 ? (size_t)sp * nrows * 128 : 0), 4);   // <= 4 dv partials
 }
 // T: bilinear_prepare_T of the [NA,128,128] operand.  out1 = init1 + sum_a p[:,a] M[:,a,:], out2 = init2 + M . zz
 int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, const float* zz, long ldz, const float* T,
@@ -1591,17 +1797,18 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
                          float* out2, long ldo2, int nrows, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (nrows <= 0) return CGAT_OK;
   CGAT_CHECK_ARG((ldq % 4) == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)T) & 15) == 0 && ldp < (1l << 22) &&
-                     (long)dual_dv_ld(nrows) * 256 < (1l << 31),
+                     (long)dual_dv_ld(nrows) * 512 < (1l << 31),
                  "bilinear_dual: q and T must be 16-byte aligned with ldq %% 4 == 0, nrows < 2^23");
-  const int tiles = cdiv(nrows, 128);
-  const int sp = rows_asplit(nrows, 128);
+  const bool c256 = bilinear_mode() == 4;   // the f16x3c form: 256-row workgroups, dv complete per row
+  const int tiles = cdiv(nrows, c256 ? 256 : 128);
+  const int sp = rows_asplit(nrows, c256 ? 256 : 128);
   if (!ws || ws_bytes < bilinear_dual_ws_bytes(nrows)) {
     cgat_set_error("bilinear_dual: workspace too small (%zu < %zu)", ws_bytes, bilinear_dual_ws_bytes(nrows));
     return CGAT_ERR_WORKSPACE;
   }
   const int dv_ld = dual_dv_ld(nrows);
   float* dvp = (float*)ws;
-  float* slab = dvp + (size_t)2 * dv_ld * 128;
+  float* slab = dvp + (size_t)4 * dv_ld * 128;
   float* dst = sp > 1 ? slab : out1;
   const long dld = sp > 1 ? 128 : ldo1, stride = sp > 1 ? (long)nrows * 128 : 0;
   const int vec_io = ((dld % 4) == 0 && (((uintptr_t)dst) & 15) == 0 &&
@@ -1612,11 +1819,13 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
     if (bilinear_mode() == 6)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<6>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
-    else if (bilinear_mode() == 4)   // f16x3c: prepare_T_f16c_kernel's image, max |T| behind it
-      hipLaunchKernelGGL((bilinear_rows128_dual_kernel<4>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
+    else if (c256) {   // prepare_T_f16c_kernel's image, max |T| behind it
+      CGAT_CHECK_ARG((ldz % 4) == 0 && (((uintptr_t)zz) & 15) == 0 && ldz < (1l << 22),
+                     "bilinear_dual: zz must be 16-byte aligned with ldz %% 4 == 0");
+      hipLaunchKernelGGL(bilinear_rows128_dualc_kernel, dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io,
                          T + (size_t)128 * F16C_A_FLOATS);
-    else if (bilinear_mode() == 2)
+    } else if (bilinear_mode() == 2)
       hipLaunchKernelGGL((bilinear_rows128_dual_kernel<2>), dim3(tiles * sp), dim3(512), 0, stream, p, ldp, q, ldq, zz, ldz,
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
     else
@@ -1625,7 +1834,7 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
     CGAT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv(nrows, 32)), dim3(256), 0, stream, slab, sp, stride, nrows, out1, ldo1,
-                     dvp, dv_ld, 128, init2, ldi2, out2, ldo2);
+                     dvp, dv_ld, 128, init2, ldi2, out2, ldo2, c256 ? 4 : 2);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
