@@ -351,12 +351,12 @@ extern "C" int cgat_segment_attention_pool_backward(const float* a, int32_t aF, 
 
 // ---- dense-layer chain ----
 extern "C" size_t cgat_mlp_chain_workspace_bytes(int32_t n_layers) {
-  return (size_t)(n_layers > 0 ? n_layers : 0) * WPREP_IMAGE_FLOATS * sizeof(float) + 256;
+  return (size_t)(n_layers > 0 ? n_layers : 0) * WPREP_IMAGE_FLOATS_MAX * sizeof(float) + 256;
 }
 extern "C" int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_bytes, void* stream) {
   CGAT_CHECK_ARG(d && d->n_layers >= 1 && d->n_layers <= CHAIN_MAX && d->rows >= 0, "mlp_chain: bad descriptor");
-  if (bilinear_mode() != 2) {
-    cgat_set_error("mlp_chain: only the f16x3 arithmetic mode has the fused chain; run the layers one by one");
+  if (wprep_image_floats() == 0) {
+    cgat_set_error("mlp_chain: the f32 arithmetic mode has no fused chain; run the layers one by one");
     return CGAT_ERR_UNSUPPORTED;
   }
   if (!ws || ws_bytes < cgat_mlp_chain_workspace_bytes(d->n_layers)) {
@@ -373,7 +373,7 @@ extern "C" int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_byte
     const cgat_chain_layer& L = d->layer[l];
     wp.src[l] = L.W; wp.sb[l] = L.w_sk; wp.sc[l] = L.w_so;
     ChainLayer& o = c.layer[l];
-    o.W = (const uint4*)(images + (size_t)l * WPREP_IMAGE_FLOATS);
+    o.W = (const uint4*)(images + (size_t)l * wprep_image_floats());
     o.bias = L.bias; o.dact = L.dact; o.resid = L.resid; o.out = L.out;
     o.ld_dact = L.ld_dact; o.ld_resid = L.ld_resid; o.ld_out = L.ld_out;
     o.act = L.act; o.dact_type = L.dact_type; o.accumulate = L.accumulate;
@@ -382,7 +382,7 @@ extern "C" int cgat_mlp_chain(const cgat_chain_desc* d, void* ws, size_t ws_byte
   c.in_dact = d->in_dact; c.ld_in_dact = d->ld_in_dact; c.in_dact_type = d->in_dact_type;
   c.in_store = d->in_store; c.ld_in_store = d->ld_in_store;
   CGAT_CHECK_ARG(mlp_chain128_fast(c), "mlp_chain: rows must be 16-byte aligned with leading dimensions that are multiples of 4");
-  CGAT_TRY(prepare_W_f16_batch_launch(wp, images, s));
+  CGAT_TRY(prepare_W_batch_launch(wp, images, s));
   return mlp_chain128_launch(c, s);
 }
 

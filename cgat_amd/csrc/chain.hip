@@ -286,8 +286,256 @@ __global__ __launch_bounds__(256, 2) void mlp_chain128_kernel(ChainDesc d) {
 #undef CN_MFMA
 }
 
+// ---------------------------------------------------------------------------------------
+// The same chain in the 24-bit arithmetic modes ("f16x3c", "bf16x6"; round 4): every fp32 value split exactly into three
+// bf16 pieces, a product = six v_mfma_f32_16x16x32_bf16 passes (mfma_bf16.h), no scales.  The chain is bound by the
+// activations it moves and by its vector work (matrix-core utilisation 0.1 in the fp16 form), so the six passes cost
+// little; what they need is registers: 96 for a wave's rows instead of 64.  The partial accumulators therefore cover a
+// PAIR of 16-column blocks over the whole K instead of a 64-column half per k-step (8 + 8 registers... 16 + 16 instead
+// of 32 + 32), i.e. the weight image is cut differently:
+//   image of one 128 x 128 layer (prepare_W_x6_batch_kernel): chunk (half, cbp, kh) = 12 KB:
+//       [s2 (2)][plane (3)][cb2 (2)][lane 64 x 16 B],  lane = 16 kg + c % 16 holds W[c][b = 64 kh + 32 s2 + 8 kg + j]
+//   for the output column c = 64 half + 32 cbp + 16 cb2 + c % 16; eight chunks per layer in the order (half, cbp, kh).
+// Everything else -- ring, layout exchange between layers, epilogue, negated odd k-steps into a second accumulator set
+// (the bf16 matrix instruction's accumulator bias cancels) -- is mlp_chain128_kernel's.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prepare_W_x6_batch_kernel(WPrepBatch b, float* __restrict__ dst) {
+  const int it = blockIdx.x, tid = threadIdx.x;
+  const float* src = b.src[it];
+  const long sb = b.sb[it], sc = b.sc[it];
+  __bf16* img = reinterpret_cast<__bf16*>(dst + (size_t)it * WPREP_IMAGE_FLOATS_X6);
+#pragma unroll 4
+  for (int r = 0; r < 64; ++r) {
+    const int i = r * 256 + tid;                  // thread order follows the fastest source stride
+    int bb, c;
+    if (sc == 1) { bb = i >> 7; c = i & 127; }
+    else { c = i >> 7; bb = i & 127; }
+    __bf16 x1, x2, x3;
+    split3_bf16(src[bb * sb + c * sc], x1, x2, x3);
+    const int half = c >> 6, cbp = (c >> 5) & 1, cb2 = (c >> 4) & 1, i16 = c & 15;
+    const int kh = bb >> 6, s2 = (bb >> 5) & 1, kg = (bb >> 3) & 3, j = bb & 7;
+    const long chunk = ((long)(half * 2 + cbp) * 2 + kh) * 6144;          // 12 KB = 6144 bf16
+    const long in = ((long)cb2 * 64 + kg * 16 + i16) * 8 + j;
+    img[chunk + ((s2 * 3 + 0) * 2) * 512 + in] = x1;
+    img[chunk + ((s2 * 3 + 1) * 2) * 512 + in] = x2;
+    img[chunk + ((s2 * 3 + 2) * 2) * 512 + in] = x3;
+  }
+}
+int prepare_W_x6_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream) {
+  if (b.n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_W_x6_batch_kernel, dim3(b.n), dim3(256), 0, stream, b, dst);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_chain128_x6_kernel(ChainDesc d) {
+  constexpr int CH16 = 2 * 3 * 2 * 64;          // 16-byte pieces per chunk: two k-steps x three planes x two blocks x 64 lanes
+  constexpr int XP = 36;                        // pitch (floats) of the layout-exchange tile: 32 columns + 4
+  __shared__ uint4 smem[4 * CH16];
+  __shared__ __attribute__((aligned(16))) float xch[4 * 32 * XP];   // per wave: 32 rows x 32 columns (one k-step) at a time
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int rows = d.rows;
+  const int row_w = blockIdx.x * 128 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_a + 16;
+  const long rca = row_a < rows ? row_a : rows - 1, rcb = row_b < rows ? row_b : rows - 1;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned t_off = (unsigned)tid * 16;
+  const int n_chunks = d.n_layers * 8;
+
+  // ---- the lane's two rows: q[plane][2 s + nb] holds x[row(nb), 32 s + 8 kg + 0..7]; odd k-steps negated (CX_MFMA) ----
+  bf16x8 q1[8], q2[8], q3[8];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const long rr = nb ? rcb : rca;
+    const bool live = (nb ? row_b : row_a) < rows;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int col = 32 * s + 8 * kg;
+      const float4* xp = reinterpret_cast<const float4*>(d.x + rr * d.ldx + col);
+      float4 t0 = xp[0], t1 = xp[1];
+      if (d.in_dact) {                          // backward: rows = g * act'(saved activation)
+        const float4* yp = reinterpret_cast<const float4*>(d.in_dact + rr * d.ld_in_dact + col);
+        t0 = chain_deriv(t0, yp[0], d.in_dact_type);
+        t1 = chain_deriv(t1, yp[1], d.in_dact_type);
+      }
+      if (d.in_store && live) {
+        float4* sp = reinterpret_cast<float4*>(d.in_store + rr * d.ld_in_store + col);
+        sp[0] = t0; sp[1] = t1;
+      }
+      const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      split3_x8(v, q1[2 * s + nb], q2[2 * s + nb], q3[2 * s + nb]);
+      if (s & 1) { q1[2 * s + nb] = neg_x8(q1[2 * s + nb]); q2[2 * s + nb] = neg_x8(q2[2 * s + nb]); q3[2 * s + nb] = neg_x8(q3[2 * s + nb]); }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // chunk g = 8 l + 4 half + 2 cbp + kh of the whole chain -> ring slot g % 4; past the end the last chunk is re-loaded
+#define CX_TLOAD(g_)                                                                           \
+  {                                                                                            \
+    const int gg = (g_) < n_chunks ? (g_) : n_chunks - 1;                                      \
+    const uint4* tb = d.layer[gg >> 3].W + (long)(gg & 7) * CH16;                              \
+    const unsigned dst = wave_t + (unsigned)((g_) & 3) * (CH16 * 16);                          \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 256, t_off, dst + 4096);                                                    \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+  }
+  CX_TLOAD(0);
+  CX_TLOAD(1);
+  CX_TLOAD(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+  // group gq = 2 s2 + cb2 of the chunk in ring slot slot_: the three planes of block cb2 at k-step s2
+#define CX_READ(F1_, F2_, F3_, slot_, gq_)                                                     \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * (CH16) + ((((gq_) >> 1) * 3) * 2 + ((gq_) & 1)) * 64;  \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[2 * 64];                                                                          \
+    F3_ = fp[4 * 64];                                                                          \
+  }
+#define CX_MFMA1(F1_, F2_, F3_, qi_, P_)                                                       \
+  {                                                                                            \
+    P_ = mma16<false>(F3_, q1[qi_], P_);                                                       \
+    P_ = mma16<false>(F1_, q3[qi_], P_);                                                       \
+    P_ = mma16<false>(F2_, q2[qi_], P_);                                                       \
+    P_ = mma16<false>(F2_, q1[qi_], P_);                                                       \
+    P_ = mma16<false>(F1_, q2[qi_], P_);                                                       \
+    P_ = mma16<false>(F1_, q1[qi_], P_);                                                       \
+  }
+  // k-step s_ = 2 kh + s2; odd k-steps (negated rows) go to the second accumulator set, subtracted in the epilogue
+#define CX_MFMA(F1_, F2_, F3_, s_, cb2_)                                                       \
+  {                                                                                            \
+    if ((s_) & 1) {                                                                            \
+      CX_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, partn[2 * (cb2_) + 0])                             \
+      CX_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, partn[2 * (cb2_) + 1])                             \
+    } else {                                                                                   \
+      CX_MFMA1(F1_, F2_, F3_, 2 * (s_) + 0, part[2 * (cb2_) + 0])                              \
+      CX_MFMA1(F1_, F2_, F3_, 2 * (s_) + 1, part[2 * (cb2_) + 1])                              \
+    }                                                                                          \
+  }
+  CX_READ(fa1, fa2, fa3, 0, 0);
+  f32x4 part[4], partn[4];
+  f32x4 vals[2][8];                              // vals[nb][b] = this layer's out[row(nb), 16 b + 4 kg .. + 3]
+  for (int l = 0; l < d.n_layers; ++l) {
+    const ChainLayer L = d.layer[l];
+#pragma unroll
+    for (int hc = 0; hc < 4; ++hc) {             // hc = 2 half + cbp: output columns 32 hc .. 32 hc + 31
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { part[i] = f32x4{0.f, 0.f, 0.f, 0.f}; partn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {           // chunk (l, hc, kh) sits in ring slot (2 hc + kh) % 4
+        const int slot = (2 * hc + kh) & 3;
+        CX_TLOAD(l * 8 + hc * 2 + kh + 3);
+        // four groups (s2, cb2), fragments one group ahead (sets A / B alternate)
+        CX_READ(fb1, fb2, fb3, slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        CX_MFMA(fa1, fa2, fa3, 2 * kh + 0, 0);
+        CX_READ(fa1, fa2, fa3, slot, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        CX_MFMA(fb1, fb2, fb3, 2 * kh + 0, 1);
+        CX_READ(fb1, fb2, fb3, slot, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        CX_MFMA(fa1, fa2, fa3, 2 * kh + 1, 0);
+        CX_READ(fa1, fa2, fa3, (slot + 1) & 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        CX_MFMA(fb1, fb2, fb3, 2 * kh + 1, 1);
+        // chunk g + 2 (issued one chunk ago) must have landed; younger than it: this chunk's three loads.  The epilogue's
+        // ordinary loads and stores are older than the next chunk's loads, so the counted wait can only be stricter
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      // ---- epilogue of the 32 columns ----
+#pragma unroll
+      for (int cb2 = 0; cb2 < 2; ++cb2) {
+        const int b16 = 2 * hc + cb2;            // 16-column block of the layer's output
+        const int col = 16 * b16 + 4 * kg;
+        const f32x4 pa = part[2 * cb2 + 0] - partn[2 * cb2 + 0], pb = part[2 * cb2 + 1] - partn[2 * cb2 + 1];
+        float4 va = make_float4(pa[0], pa[1], pa[2], pa[3]), vb = make_float4(pb[0], pb[1], pb[2], pb[3]);
+        if (L.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(L.bias + col);
+          va.x += b4.x; va.y += b4.y; va.z += b4.z; va.w += b4.w;
+          vb.x += b4.x; vb.y += b4.y; vb.z += b4.z; vb.w += b4.w;
+        }
+        va = chain_act(va, L.act);
+        vb = chain_act(vb, L.act);
+        if (L.resid) {
+          const float4 ra = *reinterpret_cast<const float4*>(L.resid + rca * L.ld_resid + col);
+          const float4 rb = *reinterpret_cast<const float4*>(L.resid + rcb * L.ld_resid + col);
+          va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+          vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+        }
+        if (L.dact) {
+          va = chain_deriv(va, *reinterpret_cast<const float4*>(L.dact + rca * L.ld_dact + col), L.dact_type);
+          vb = chain_deriv(vb, *reinterpret_cast<const float4*>(L.dact + rcb * L.ld_dact + col), L.dact_type);
+        }
+        if (L.out) {
+          float* oa = L.out + rca * L.ld_out + col;
+          float* ob = L.out + rcb * L.ld_out + col;
+          if (L.accumulate) {
+            const float4 ua = *reinterpret_cast<const float4*>(oa), ub = *reinterpret_cast<const float4*>(ob);
+            if (row_a < rows) *reinterpret_cast<float4*>(oa) = make_float4(ua.x + va.x, ua.y + va.y, ua.z + va.z, ua.w + va.w);
+            if (row_b < rows) *reinterpret_cast<float4*>(ob) = make_float4(ub.x + vb.x, ub.y + vb.y, ub.z + vb.z, ub.w + vb.w);
+          } else {
+            if (row_a < rows) *reinterpret_cast<float4*>(oa) = va;
+            if (row_b < rows) *reinterpret_cast<float4*>(ob) = vb;
+          }
+        }
+        vals[0][b16] = f32x4{va.x, va.y, va.z, va.w};
+        vals[1][b16] = f32x4{vb.x, vb.y, vb.z, vb.w};
+      }
+    }
+    if (l + 1 < d.n_layers) {
+      // ---- this layer's outputs become the next layer's rows: C layout -> B layout inside the four lanes of a row,
+      // through a wave-private LDS tile, 32 columns at a time (see mlp_chain128_kernel; LDS serves a wave's accesses in
+      // order, so write -> read -> overwrite needs no barrier) ----
+      float* xw = xch + wave * (32 * XP);
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) {           // columns 32 sq .. 32 sq + 31 = k-step sq of the next layer
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int c16 = 0; c16 < 2; ++c16) {
+            const f32x4 t = vals[nb][2 * sq + c16];
+            *reinterpret_cast<float4*>(xw + (n16 + 16 * nb) * XP + 16 * c16 + 4 * kg) = make_float4(t[0], t[1], t[2], t[3]);
+          }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const float* rp = xw + (n16 + 16 * nb) * XP + 8 * kg;
+          const float4 lo = *reinterpret_cast<const float4*>(rp), hi4 = *reinterpret_cast<const float4*>(rp + 4);
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          const int qi = 2 * sq + nb;
+          split3_x8(v, q1[qi], q2[qi], q3[qi]);
+          if (sq & 1) { q1[qi] = neg_x8(q1[qi]); q2[qi] = neg_x8(q2[qi]); q3[qi] = neg_x8(q3[qi]); }   // odd k-step
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef CX_TLOAD
+#undef CX_READ
+#undef CX_MFMA1
+#undef CX_MFMA
+}
+
+// floats of one prepared weight image in the current arithmetic mode (0: no fused chain in this mode)
+size_t wprep_image_floats() {
+  const int m = bilinear_mode();
+  return m == 2 ? (size_t)WPREP_IMAGE_FLOATS : ((m == 4 || m == 6) ? (size_t)WPREP_IMAGE_FLOATS_X6 : 0);
+}
+int prepare_W_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream) {
+  if (bilinear_mode() == 2) return prepare_W_f16_batch_launch(b, dst, stream);
+  if (bilinear_mode() == 4 || bilinear_mode() == 6) return prepare_W_x6_batch_launch(b, dst, stream);
+  return CGAT_ERR_UNSUPPORTED;
+}
+
 bool mlp_chain128_fast(const ChainDesc& d) {
-  if (bilinear_mode() != 2 || d.n_layers < 1 || d.n_layers > CHAIN_MAX) return false;
+  if (wprep_image_floats() == 0 || d.n_layers < 1 || d.n_layers > CHAIN_MAX) return false;
   uintptr_t bits = (uintptr_t)d.x | (uintptr_t)d.in_dact | (uintptr_t)d.in_store;
   long lds = d.ldx | d.ld_in_dact | d.ld_in_store;
   for (int l = 0; l < d.n_layers; ++l) {
@@ -300,9 +548,10 @@ bool mlp_chain128_fast(const ChainDesc& d) {
 
 int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream) {
   if (d.rows <= 0) return CGAT_OK;
-  CGAT_CHECK_ARG(mlp_chain128_fast(d), "mlp_chain128: needs the f16x3 mode, 1..%d layers and 16-byte aligned rows", CHAIN_MAX);
+  CGAT_CHECK_ARG(mlp_chain128_fast(d), "mlp_chain128: needs a split arithmetic mode, 1..%d layers and 16-byte aligned rows", CHAIN_MAX);
   CGAT_PROF("mlp_chain", stream);
-  hipLaunchKernelGGL(mlp_chain128_kernel, dim3(cdiv(d.rows, 128)), dim3(256), 0, stream, d);
+  if (bilinear_mode() == 2) hipLaunchKernelGGL(mlp_chain128_kernel, dim3(cdiv(d.rows, 128)), dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL(mlp_chain128_x6_kernel, dim3(cdiv(d.rows, 128)), dim3(256), 0, stream, d);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -150,6 +150,9 @@ int linear128_heads_launch(int heads, const float* in, long ldi, long s_in, cons
 // batched form for 128 x 128 dense-layer weights W(o, k) = src[o * so + k * sk]: image i at dst + i * WPREP_IMAGE_FLOATS
 #define WPREP_MAX 48
 #define WPREP_IMAGE_FLOATS (16384 + 4)
+#define WPREP_IMAGE_FLOATS_X6 24576             // the six-pass bf16 chain's image: three 2-byte planes (chain.hip)
+#define WPREP_IMAGE_FLOATS_MAX 24576
+size_t wprep_image_floats();                    // ... of the current arithmetic mode (0: it has no fused chain)
 struct WPrepBatch {
   const float* src[WPREP_MAX];
   long sb[WPREP_MAX], sc[WPREP_MAX];   // strides of the k index and of the output index
@@ -192,6 +195,7 @@ struct ChainDesc {
   float* in_store;       // null, or where the (multiplied) input rows are stored
   long ld_in_store;
 };
+int prepare_W_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);   // the current mode's chain images
 bool mlp_chain128_fast(const ChainDesc& d);
 int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----

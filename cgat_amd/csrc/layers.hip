@@ -26,18 +26,20 @@ struct Ctx {
       : w(dry_ ? nullptr : ws, dry_ ? (size_t)-1 / 2 : bytes), dry(dry_), s(st), scratch_need(0), scratch(nullptr),
         scratch_bytes(0), wprep_images(nullptr) { wprep.n = 0; }
   // call before seal(): reserves the image space; add items, then wprep_run() once
-  void wprep_reserve(int max_items) { wprep_images = take<float>((size_t)max_items * WPREP_IMAGE_FLOATS); }
+  // (images of the current arithmetic mode: the fp16 chain's in "f16x3", the six-pass bf16 chain's in the 24-bit modes;
+  // the space is reserved for the larger of the two so that a size query does not depend on the mode)
+  void wprep_reserve(int max_items) { wprep_images = take<float>((size_t)max_items * WPREP_IMAGE_FLOATS_MAX); }
   void wprep_add(const float* W, long so, long sk) {
     if (wprep.n < WPREP_MAX) { wprep.src[wprep.n] = W; wprep.sb[wprep.n] = sk; wprep.sc[wprep.n] = so; ++wprep.n; }
   }
   int wprep_run() {
-    if (dry || bilinear_mode() != 2 || wprep.n == 0) { if (bilinear_mode() != 2) wprep.n = 0; return CGAT_OK; }
-    return prepare_W_f16_batch_launch(wprep, wprep_images, s);
+    if (dry || wprep_image_floats() == 0 || wprep.n == 0) { if (wprep_image_floats() == 0) wprep.n = 0; return CGAT_OK; }
+    return prepare_W_batch_launch(wprep, wprep_images, s);
   }
   const void* wprep_find(const float* W, long so, long sk) const {
-    if (dry || bilinear_mode() != 2) return nullptr;
+    if (dry || wprep_image_floats() == 0) return nullptr;
     for (int i = 0; i < wprep.n; ++i)
-      if (wprep.src[i] == W && wprep.sb[i] == sk && wprep.sc[i] == so) return wprep_images + (size_t)i * WPREP_IMAGE_FLOATS;
+      if (wprep.src[i] == W && wprep.sb[i] == sk && wprep.sc[i] == so) return wprep_images + (size_t)i * wprep_image_floats();
     return nullptr;
   }
   template <typename T>
@@ -1272,7 +1274,7 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
     // launch (chain.hip) when the weights of the pass have been prepared in a batch (f16x3 mode, width 128, <= 4 trunk
     // layers); the remaining linear term u += vin @ Bm^T follows.  Bm = head_b[:W*W] as [o,i], U = head_w[W*W:]
     bool chained = false;
-    if (batch_w && !c.dry && bilinear_mode() == 2 && p->n_fc + 1 <= CHAIN_MAX) {
+    if (batch_w && !c.dry && wprep_image_floats() != 0 && p->n_fc + 1 <= CHAIN_MAX) {
       ChainDesc cd;
       memset(&cd, 0, sizeof(cd));
       cd.n_layers = p->n_fc + 1; cd.rows = rows; cd.x = hin; cd.ldx = W;
@@ -1371,7 +1373,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   // the fused trunk chain (chain.hip) leaves every trunk layer's pre-activation gradient behind, so the weight
   // gradients of all dense layers of all predicted layers can wait for ONE batched launch at the end (rowsdw.hip):
   // they feed nothing else in the backward pass.  g_pre then needs a buffer per predicted layer.
-  const bool chain_ok = batch_w && bilinear_mode() == 2 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX;
+  const bool chain_ok = batch_w && wprep_image_floats() != 0 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX;
   const bool defer_dw = chain_ok && p->n_hyper * (p->n_fc + 2) <= DW_BATCH_MAX;
   const int nfc1 = p->n_fc > 0 ? p->n_fc : 1;
   const HnetSideLayout SL = hnet_side_layout(rows, p);

@@ -311,16 +311,23 @@ def _hnet_struct(cls, W, n_fc, n_hyper, flat, damping):
 
 # Side stream for the hypernetwork's weight-gradient contractions (cgat_hnet_backward_overlapped, used by NodeLayerFn):
 # they are off the critical path of the backward pass and matrix-core bound, the attention backward is HBM bound.
+# Decided by timeline per arithmetic mode (round 4): in the 22-bit "f16x3" mode the overlap is worth 0.5 ms of a 23.9 ms
+# step (the batched dT launch on half of the chip beside the HBM-bound attention backward); in the 24-bit modes the
+# weight-gradient contractions are two to four times as long as the kernels they would run beside and same-box A/Bs
+# measure nothing (33.13 / 33.12 ms with, 33.04 / 33.08 without the side stream): the default there is the serial order
+# (every kernel alone on the chip).  CGAT_OVERLAP_WGRAD=0/1 or set_overlap_wgrad() override.
 _side_streams = {}
-_overlap_wgrad = os.environ.get("CGAT_OVERLAP_WGRAD", "1") != "0"
+_overlap_wgrad = {"0": False, "1": True}.get(os.environ.get("CGAT_OVERLAP_WGRAD", ""), None)
 
 
 def set_overlap_wgrad(flag):
     global _overlap_wgrad
-    _overlap_wgrad = bool(flag)
+    _overlap_wgrad = None if flag is None else bool(flag)
 
 
 def overlap_enabled():
+    if _overlap_wgrad is None:
+        return get_bilinear_mode() == "f16x3"
     return _overlap_wgrad
 
 
@@ -826,7 +833,7 @@ class ChainMLPFn(torch.autograd.Function):
     def eligible(x, weights, resid=None):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 128 and x.shape[0] > 0):
             return False
-        if get_bilinear_mode() != "f16x3" or not (1 <= len(weights) <= 5):
+        if get_bilinear_mode() not in ("f16x3", "f16x3c", "bf16x6") or not (1 <= len(weights) <= 5):
             return False
         if resid is not None and (resid.shape != x.shape or resid.dtype != torch.float32):
             return False

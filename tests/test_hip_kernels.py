@@ -313,8 +313,8 @@ def test_segment_attention_pool(env, F, aF, with_mult, permuted):
 def _chain(env, rows, x, layers, in_dact=None, in_dact_type=0, in_store=None):
     """layers: list of dicts(W [128,128] (out,in) or its transpose flag, bias, act, dact, dact_type, resid, out, accumulate)"""
     _, _lib, ops, dev = env
-    if ops.get_bilinear_mode() != "f16x3":
-        pytest.skip("the fused chain exists in the f16x3 arithmetic mode only (the other modes run the layers one by one)")
+    if ops.get_bilinear_mode() not in ("f16x3", "f16x3c", "bf16x6"):
+        pytest.skip("the f32 arithmetic mode has no fused chain (it runs the layers one by one)")
     d = _lib.ChainDesc()
     d.n_layers, d.rows = len(layers), rows
     d.x, d.ldx = x.data_ptr(), x.stride(0)
