@@ -349,9 +349,18 @@ bool rows_dw128_fast(const float* G, long ldg, const float* X1, long ldx1, const
   return !off && (ldg % 4) == 0 && (ldx1 % 4) == 0 && (((uintptr_t)G) & 15) == 0 && (((uintptr_t)X1) & 15) == 0 &&
          (!X2 || ((ldx2 % 4) == 0 && (((uintptr_t)X2) & 15) == 0));
 }
+size_t rows_dw128_batch_ws_bytes(int n_items, int rows);
 size_t rows_dw128_ws_bytes(int rows, int nx) {
   const int splits = cdiv(rows, dw_rows_per_wg(rows));
-  return ws_round((size_t)splits * ((size_t)nx * 16384 + 128), 4);
+  size_t b = ws_round((size_t)splits * ((size_t)nx * 16384 + 128), 4);
+  // nx == 1 in the split arithmetic modes runs as a batch of one on the bf16 matrix cores (rows_dw128_launch), whose slab
+  // count can exceed this kernel's: reserve and check the larger of the two, so that a caller that sized its scratch
+  // with this function (Ctx::dw128) gets the fast route, not CGAT_ERR_WORKSPACE from the inner launch
+  if (nx == 1) {
+    const size_t c = rows_dw128_batch_ws_bytes(1, rows);
+    if (c > b) b = c;
+  }
+  return b;
 }
 // X2/out2 may be null (one right operand); bsum may be null
 int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, float* out1, long ldo1, const float* X2,

@@ -54,24 +54,30 @@ __device__ __forceinline__ float block256_max(float v, float* red) {
 }
 // the long segments among segments [256 b, 256 b + 256): ids into list[] (LDS), count returned; order irrelevant (each
 // is processed independently)
-__device__ __forceinline__ int collect_long256(const int* __restrict__ rowptr, int S, int* list, int* count) {
+__device__ __forceinline__ int collect_long256(const int* __restrict__ rowptr, int S, int* list, int* count, int b) {
   if (threadIdx.x == 0) *count = 0;
   __syncthreads();
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int s = b * 256 + threadIdx.x;
   if (s < S && rowptr[s + 1] - rowptr[s] > SEG_LONG) list[atomicAdd(count, 1)] = s;
   __syncthreads();
   return *count;
 }
 
-// one thread per (segment, feature)
-__global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mult,
+// one thread per (segment, feature).  The workgroups behind the first `main_blocks` handle the long segments
+// (seg_softmax_fwd_long below): ONE launch for both (a separate launch that finds nothing to do is what the normal case
+// paid before, and at the harness' 64-crystal batch the step is launch-bound)
+__device__ void seg_softmax_fwd_long(const float* __restrict__ a, const float* __restrict__ mult,
+                                     const int* __restrict__ rowptr, int S, int F, float eps, float* __restrict__ alpha,
+                                     float* __restrict__ ssum, int b);
+__global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mult,
                                        const int* __restrict__ rowptr, int S, int F, float eps,
-                                       float* __restrict__ alpha, float* __restrict__ ssum) {
+                                       float* __restrict__ alpha, float* __restrict__ ssum, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) return seg_softmax_fwd_long(a, mult, rowptr, S, F, eps, alpha, ssum, blockIdx.x - main_blocks);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)S * F) return;
   int s = (int)(i / F), f = (int)(i % F);
   int r0 = rowptr[s], r1 = rowptr[s + 1];
-  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_fwd_long_kernel
+  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_fwd_long
   float mx = -INFINITY;
   for (int r = r0; r < r1; ++r) mx = fmaxf(mx, a[(long)r * F + f]);
   float z = 0.f;
@@ -92,13 +98,13 @@ __global__ void seg_softmax_fwd_kernel(const float* __restrict__ a, const float*
   if (ssum) ssum[i] = tot;
 }
 
-__global__ __launch_bounds__(256) void seg_softmax_fwd_long_kernel(const float* __restrict__ a, const float* __restrict__ mult,
-                                                                   const int* __restrict__ rowptr, int S, int F, float eps,
-                                                                   float* __restrict__ alpha, float* __restrict__ ssum) {
+__device__ void seg_softmax_fwd_long(const float* __restrict__ a, const float* __restrict__ mult,
+                                     const int* __restrict__ rowptr, int S, int F, float eps, float* __restrict__ alpha,
+                                     float* __restrict__ ssum, int b) {
   __shared__ int list[256];
   __shared__ int count;
   __shared__ float red[4];
-  const int n = collect_long256(rowptr, S, list, &count);
+  const int n = collect_long256(rowptr, S, list, &count, b);
   for (int k = 0; k < n; ++k) {
     const int s = list[k], r0 = rowptr[s], r1 = rowptr[s + 1];
     for (int f = 0; f < F; ++f) {
@@ -130,15 +136,21 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_long_kernel(const float* 
 }
 
 // ga = alpha * (g - sum_seg alpha*g),  g = galpha + gssum[seg];   gmult = ga / mult  (F == 1 only)
-__global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
+__device__ void seg_softmax_bwd_long(const float* __restrict__ alpha, const float* __restrict__ galpha,
+                                     const float* __restrict__ gssum, const float* __restrict__ mult,
+                                     const int* __restrict__ rowptr, int S, int F, float* __restrict__ ga,
+                                     float* __restrict__ gmult, int b);
+__global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
                                        const float* __restrict__ gssum, const float* __restrict__ mult,
                                        const int* __restrict__ rowptr, int S, int F, float* __restrict__ ga,
-                                       float* __restrict__ gmult) {
+                                       float* __restrict__ gmult, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks)   // the long segments: trailing workgroups of the same launch (see the forward)
+    return seg_softmax_bwd_long(alpha, galpha, gssum, mult, rowptr, S, F, ga, gmult, blockIdx.x - main_blocks);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)S * F) return;
   int s = (int)(i / F), f = (int)(i % F);
   int r0 = rowptr[s], r1 = rowptr[s + 1];
-  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_bwd_long_kernel
+  if (r1 - r0 > SEG_LONG) return;                 // seg_softmax_bwd_long
   float gs = gssum ? gssum[i] : 0.f;
   float dot = 0.f;
   for (int r = r0; r < r1; ++r) dot += alpha[(long)r * F + f] * (galpha[(long)r * F + f] + gs);
@@ -150,14 +162,14 @@ __global__ void seg_softmax_bwd_kernel(const float* __restrict__ alpha, const fl
   }
 }
 
-__global__ __launch_bounds__(256) void seg_softmax_bwd_long_kernel(const float* __restrict__ alpha, const float* __restrict__ galpha,
-                                                                   const float* __restrict__ gssum, const float* __restrict__ mult,
-                                                                   const int* __restrict__ rowptr, int S, int F,
-                                                                   float* __restrict__ ga, float* __restrict__ gmult) {
+__device__ void seg_softmax_bwd_long(const float* __restrict__ alpha, const float* __restrict__ galpha,
+                                     const float* __restrict__ gssum, const float* __restrict__ mult,
+                                     const int* __restrict__ rowptr, int S, int F, float* __restrict__ ga,
+                                     float* __restrict__ gmult, int b) {
   __shared__ int list[256];
   __shared__ int count;
   __shared__ float red[4];
-  const int n = collect_long256(rowptr, S, list, &count);
+  const int n = collect_long256(rowptr, S, list, &count, b);
   for (int k = 0; k < n; ++k) {
     const int s = list[k], r0 = rowptr[s], r1 = rowptr[s + 1];
     for (int f = 0; f < F; ++f) {
@@ -180,11 +192,9 @@ int seg_softmax_fwd_launch(const float* a, const float* mult, const int* rowptr,
   long n = (long)S * F;
   if (n <= 0) return CGAT_OK;
   CGAT_PROF("seg_softmax", s);
-  hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
-                     ssum);
-  CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_softmax_fwd_long_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps, alpha,
-                     ssum);
+  const int main_blocks = (int)cdiv(n, 256);
+  hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(main_blocks + cdiv(S, 256)), dim3(256), 0, s, a, mult, rowptr, S, F, eps,
+                     alpha, ssum, main_blocks);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -194,11 +204,9 @@ int seg_softmax_bwd_launch(const float* alpha, const float* galpha, const float*
   long n = (long)S * F;
   if (n <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(!gmult || F == 1, "seg_softmax_bwd: gradient of the multiplier needs F == 1");
-  hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult, rowptr, S,
-                     F, ga, gmult);
-  CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_softmax_bwd_long_kernel, dim3(cdiv(S, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult, rowptr,
-                     S, F, ga, gmult);
+  const int main_blocks = (int)cdiv(n, 256);
+  hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(main_blocks + cdiv(S, 256)), dim3(256), 0, s, alpha, galpha, gssum, mult,
+                     rowptr, S, F, ga, gmult, main_blocks);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

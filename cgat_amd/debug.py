@@ -35,8 +35,9 @@ class record_masks:
         return self.masks
 
     def __exit__(self, *exc):
-        global _active
+        global _active, last_hidden
         _active = self.prev
+        last_hidden = None      # the [E, 2 H Hd] activation (GBs at 1 M edges) must not outlive the recorder
 
 
 def recording():
@@ -76,7 +77,9 @@ def note_attention(a_in_w, m_in_w, plan, attn_params, saved, W2):
 def note_sorted_hidden(weights, plan, hidden):
     """EdgeHiddenFn's output (post-activation, destination-sorted slots) -> per-network masks in original edge order.
     `weights`: the first-layer weights of the stacked networks, equal column shares of `hidden`."""
-    if _active is None:
+    global last_hidden
+    last_hidden = None          # consumed: drop the module-global reference (the caller's `hidden` argument keeps it for this call)
+    if _active is None or hidden is None:
         return
     perm = plan.dst_perm.long()
     m = torch.empty(hidden.shape, dtype=torch.bool, device=hidden.device)

@@ -70,8 +70,10 @@ class GradientAverager:
     * `static_graph=True` (as DDP's): once two consecutive steps have produced the same global bitmap the cold set is
       FROZEN -- `finish()` then issues no bitmap all-reduce and, above all, no host synchronisation (reading the bitmap
       drains the launch queue: +2.3 ms on the 24.4 ms layer step, measured over a one-rank RCCL communicator); the
-      all-reduces are only stream-ordered.  A cold parameter that receives a gradient after that raises, a hot one
-      that does not contributes zeros and keeps its (zero-mean) gradient instead of None.
+      all-reduces are only stream-ordered.  A cold parameter that receives a gradient on some rank after that raises on
+      EVERY rank at the following finish() (a 4-byte flag is all-reduced asynchronously each step and read without
+      blocking one step later: no rank is left waiting in a collective), a hot one that receives none contributes zeros
+      and keeps its (zero-mean) gradient instead of None.
     * `force=True` keeps all of this alive at world size 1 (a one-rank communicator): the mean is
       then the identity, and the hooks, the asynchronous collectives and their interplay with the
       layer's side stream can be exercised over RCCL on a single GPU (tests/test_rccl_one_rank.py).
@@ -83,11 +85,17 @@ class GradientAverager:
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force and not dist.is_initialized():
+            # an inactive averager would still install zero bucket views in zero_grad() and never turn the unused
+            # parameters' gradients back into None: optimisers would then decay parameters the plain path skips
+            raise RuntimeError("GradientAverager(force=True) needs an initialised process group (a one-rank group will do)")
         self.active = (self.world > 1 or bool(force)) and dist.is_initialized()
         self.bucket_bytes = int(bucket_bytes)
         self.static_graph, self._frozen = bool(static_graph), False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._cold = frozenset()
+        self._last_cold = None                         # the previous step's global cold set (None: no step observed yet)
+        self._viol = None                              # frozen mode: (flag tensor, pinned copy, event) of the last step
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "cold_reduced": 0, "cold_skipped": 0,
                       "bytes_reduced": 0, "rebuilds": 0}
         self._layout(preserve=False)
@@ -198,20 +206,40 @@ class GradientAverager:
         for i, p in enumerate(self.params):
             p.grad = self._view[id(p)] if used[i] else None
         cold = frozenset(i for i in range(len(self.params)) if not used[i])
+        same_as_last = self._last_cold is not None and cold == self._last_cold
+        self._last_cold = cold
         if cold != self._cold:                         # same decision on every rank: the bitmap is global
             self._cold = cold
             self._layout(preserve=True)
             self.stats["rebuilds"] += 1
-        elif self.static_graph:
-            self._frozen = True                        # two steps with the same global bitmap: no more bitmap / host sync
+        elif self.static_graph and same_as_last:
+            # TWO consecutive steps have produced this global bitmap (the first step never matches: the initial empty
+            # cold set is a default, not an observation): no more bitmap / host sync
+            self._frozen = True
         self._reset()
 
     def _finish_frozen(self):
-        """static_graph after the cold set froze: stream-ordered waits only, no collective on the bitmap, no host sync."""
-        for i in self._cold:
-            if self._used[i]:
-                raise RuntimeError("GradientAverager(static_graph=True): a parameter that was unused on every rank when "
-                                   "the graph froze received a gradient; construct the averager with static_graph=False")
+        """static_graph after the cold set froze: stream-ordered waits only, no collective on the bitmap, no host sync.
+
+        A cold parameter that receives a gradient on SOME rank violates the contract.  Raising on that rank alone would
+        leave the others waiting in their next collective, so the violation travels: every step all-reduces one flag
+        (4 bytes, asynchronous, stream-ordered) and copies the sum to pinned memory behind an event; the NEXT finish()
+        looks at it without blocking (event.query()) and every rank raises together -- one step late, but
+        consistently."""
+        self._check_violation()
+        local = any(self._used[i] for i in self._cold)
+        dev = self.flat[0].device if self.flat else torch.device("cpu")
+        flag = torch.full((1,), 1 if local else 0, dtype=torch.int64, device=dev)
+        work = dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work.wait()                                    # stream-ordered on GPU backends
+        if dev.type == "cuda":
+            host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._viol = (flag, host, ev)
+        else:
+            self._viol = (flag, flag, None)
         inv = 1.0 / self.world
         for bi in range(self.n_hot):
             self._works[bi].wait()
@@ -223,7 +251,24 @@ class GradientAverager:
             p.grad = None if i in self._cold else self._view[id(p)]
         self._reset()
 
+    def _check_violation(self, block=False):
+        """Frozen mode: raise (on every rank alike) if some rank saw a gradient on a cold parameter in an earlier step."""
+        if self._viol is None:
+            return
+        flag, host, ev = self._viol
+        if ev is not None:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return                                 # not there yet: look again at the next step
+        self._viol = None
+        if int(host[0]) > 0:
+            raise RuntimeError("GradientAverager(static_graph=True): a parameter that was unused on every rank when the "
+                               "graph froze received a gradient on some rank; construct the averager with "
+                               "static_graph=False")
+
     def close(self):
+        self._check_violation(block=True)
         for h in self._handles:
             h.remove()
         self._handles = []

@@ -38,6 +38,7 @@ class DataParallelTrainer:
         # static_graph: the set of never-used parameters is fixed by the architecture (Edge.MH_A / Edge.MH_M under
         # no_hyper=True), so the averager may freeze it after two steps and stop synchronising with the host
         # force_averager: the bucketed all-reduce also at world size 1 (a one-rank RCCL communicator; dist.GradientAverager)
+        # (created only when it will be active: force=True without a process group raises in GradientAverager)
         self.averager = (GradientAverager(self.params, bucket_bytes=bucket_bytes, force=force_averager, static_graph=static_graph)
                          if (world > 1 or force_averager) else None)
         self.criterion = RobustL1 if loss == "L1" else RobustL2

@@ -233,15 +233,22 @@ def _static_worker(rank, world, port, out):
         frozen.append((avg._frozen, sum(1 for d in calls if d == torch.int32) - n0))
     want_w = (torch.arange(12, dtype=torch.float32).reshape(2, 6).sum(0) * 1.5).expand(4, 6)   # mean of ranks 1x and 2x
     ok = bool(torch.allclose(lin.weight.grad, want_w)) and dead.grad is None
-    raised = False
+    # a cold parameter receives a gradient on rank 1 ONLY: the violation must surface on BOTH ranks (a rank raising
+    # alone would leave the other one waiting in its next collective), one finish() later
+    raised, early = False, False
     avg.zero_grad()
     try:
-        (lin(x).sum() + dead.sum()).backward()
+        (lin(x).sum() + (dead.sum() if rank == 1 else 0.0)).backward()
+        avg.finish()
+    except RuntimeError:
+        early = True
+    avg.zero_grad()
+    try:
+        lin(x).sum().backward()
         avg.finish()
     except RuntimeError as ex:
         raised = "static_graph" in str(ex)
-    if rank == 0:
-        out.put((frozen, ok, raised))
+    out.put((rank, frozen, ok, raised and not early))
     dist.all_reduce = real
     dist.barrier()
     dist.destroy_process_group()
@@ -257,11 +264,48 @@ def test_static_graph_freezes_the_cold_set():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    frozen, ok, raised = out.get()
-    # step 0 learns the bitmap, step 1 confirms it (both reduce the int32 bitmap), from step 2 on: frozen, no bitmap
-    assert [f for f, _ in frozen] == [False, True, True, True], frozen
-    assert [n for _, n in frozen] == [1, 1, 0, 0], frozen
-    assert ok and raised
+    got = sorted(out.get() for _ in range(2))
+    assert [g[0] for g in got] == [0, 1]
+    for _, frozen, ok, raised in got:
+        # step 0 learns the bitmap, step 1 confirms it (both reduce the int32 bitmap), from step 2 on: frozen, no bitmap
+        assert [f for f, _ in frozen] == [False, True, True, True], frozen
+        assert [n for _, n in frozen] == [1, 1, 0, 0], frozen
+        assert ok and raised                             # ... and BOTH ranks raise, at the finish() after the violation
+
+
+def _two_obs_worker(port, out):
+    """No parameter is cold in step 1: the initial (empty) cold set must not count as an observation."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      CGAT_DIST_FORCE="1")
+    from cgat_amd.dist import GradientAverager, init_from_env
+    init_from_env("gloo")
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(3))
+    avg = GradientAverager([a, b], static_graph=True, force=True)
+    states = []
+    avg.zero_grad(); (a.sum() + b.sum()).backward(); avg.finish(); states.append(avg._frozen)      # step 1: all used
+    avg.zero_grad(); a.sum().backward(); avg.finish(); states.append((avg._frozen, b.grad is None))  # step 2: b unused
+    out.put(states)
+    dist.destroy_process_group()
+
+
+def test_static_graph_needs_two_observed_steps():
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    pr = ctx.Process(target=_two_obs_worker, args=(_free_port(), out))
+    pr.start()
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    s1, (s2, b_none) = out.get()
+    assert s1 is False and s2 is False and b_none      # not frozen after one step; the unused parameter ends with None
+
+
+def test_force_without_process_group_raises():
+    from cgat_amd.dist import GradientAverager
+    if dist.is_initialized():
+        pytest.skip("a process group is initialised in this process")
+    with pytest.raises(RuntimeError):
+        GradientAverager([torch.nn.Parameter(torch.ones(2))], force=True)
 
 
 def test_shard_range_partitions():
