@@ -784,7 +784,13 @@ def main():
         ops.prof_enable(False)
         prof_x = {t: ops.prof_get(t) for t in concurrent}
         ops.set_overlap_wgrad(True)
+    per_rank = None
     if world > 1:
+        # every rank's own timed-region duration (gathered: the SCALE line is self-checking), `value` uses the maximum
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [1e3 * float(x.item()) / args.steps for x in every]
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -1042,6 +1048,14 @@ def main():
                                                    "on the same 1M-edge batch, default arithmetic mode (3 steps after 1 warm-up)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if dist.is_initialized():
+            out["ranks"] = {"what": "one process per GPU; ms_per_step of every rank's own timed region (value = edges of all "
+                                    "ranks / the maximum), the communicator the gradient all-reduce ran over",
+                            "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                            "collective_library": "RCCL (torch.distributed backend 'nccl' on ROCm)"
+                            if dist.get_backend() == "nccl" else dist.get_backend(),
+                            "ms_per_step_per_rank": [round(x, 3) for x in per_rank] if per_rank else [round(ms, 3)],
+                            "devices_visible_to_rank0": torch.cuda.device_count()}
         if ar_report is not None:
             out["allreduce"] = ar_report
         if launch_rep is not None:

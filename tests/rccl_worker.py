@@ -79,7 +79,7 @@ def main():
             res["layer"][f"overlap={int(overlap)} bucket={bucket >> 20}MB no_sync x2"] = {
                 "bit_equal": all(torch.equal(a, c) for a, c in zip(got2, plain2))}
             avg.close()
-    ops.set_overlap_wgrad(True)
+    ops.set_overlap_wgrad(None)                            # back to the mode's default
 
     # ---- B: two steps of the training step (BASELINE configs[3]) with the averager forced on == without it
     data, emb = synthetic_dataset_dict(60, (2, 40), 24, seed=3)
@@ -103,6 +103,79 @@ def main():
                       "losses_equal": all(a == c for a, c in losses), "stats": st,
                       "unused_stay_none": all((p.grad is None) == (q.grad is None)
                                               for p, q in zip(net.parameters(), net2.parameters()))}
+    # ---- C: a VISIBLE all-reduce.  Over one rank the real collective is an identity and cannot show a missing stream
+    # dependency.  Here dist.all_reduce is replaced by a stub with NCCL's ordering contract -- the collective runs on its
+    # own stream behind an event of the caller's stream, Work.wait() makes the caller's stream wait for it without
+    # blocking the host -- that first spins for ~1 ms and then DOUBLES a floating-point buffer (the int32 used-bitmap
+    # passes through).  Every gradient must come out as exactly 2 x the plain one: a consumer that reads a bucket before
+    # waiting, or a producer (the layer's side stream, a late accumulation) that writes into it after the collective
+    # started, changes bits.
+    comm = torch.cuda.Stream(device=dev)
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream(dev).wait_event(self.ev)
+            return True
+
+    real_all_reduce = dist.all_reduce
+
+    def visible_all_reduce(t, op=None, group=None, async_op=False):
+        ev0 = torch.cuda.Event()
+        ev0.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev0)
+            if t.is_floating_point():
+                torch.cuda._sleep(2_000_000)
+                t.mul_(2.0)
+            ev1 = torch.cuda.Event()
+            ev1.record(comm)
+        w = _Work(ev1)
+        if async_op:
+            return w
+        w.wait()
+        return None
+
+    dist.all_reduce = visible_all_reduce
+    res["visible"] = {}
+    try:
+        for overlap in (True, False):
+            ops.set_overlap_wgrad(overlap)
+            plain = layer_grads(None, "none")
+            plain2 = layer_grads(None, "none", micro=2)
+            for bucket in (64 << 20, 1 << 20):
+                avg = GradientAverager(params, bucket_bytes=bucket, force=True)
+                for mode in ("none", "views"):
+                    for rep in range(3):
+                        got = layer_grads(avg, mode)
+                    res["visible"][f"overlap={int(overlap)} bucket={bucket >> 20}MB grads={mode}"] = {
+                        "exactly_doubled": all(torch.equal(a, 2.0 * c) for a, c in zip(got, plain)),
+                        "launched_in_backward": avg.stats["launched_in_backward"]}
+                got2 = layer_grads(avg, "views", micro=2)
+                res["visible"][f"overlap={int(overlap)} bucket={bucket >> 20}MB no_sync x2"] = {
+                    "exactly_doubled": all(torch.equal(a, 2.0 * c) for a, c in zip(got2, plain2))}
+                avg.close()
+        # the trainer: p <- AdamW(p, 2 g) must equal a plain trainer fed the doubled loss (gradients 2 g, same bits)
+        torch.manual_seed(0)
+        net3 = P.CGAtNet(200, 64, 2, msg_heads=2, neighbor_number=12, update_edges=True).to(dev)
+        net4 = copy.deepcopy(net3)
+        tr_vis = P.DataParallelTrainer(net3, ds, lr=1e-3, weight_decay=1e-2, force_averager=True, bucket_bytes=256 << 10)
+        tr_ref = P.DataParallelTrainer(net4, ds, lr=1e-3, weight_decay=1e-2)
+        ref_loss = tr_ref._loss
+        tr_ref._loss = lambda ids: (lambda lb: (2.0 * lb[0], lb[1]))(ref_loss(ids))
+        rs = np.random.RandomState(2)
+        for _ in range(3):
+            ids = rs.permutation(60)[:24]
+            tr_vis.step(ids)
+            tr_ref.step(ids)
+        torch.cuda.synchronize()
+        res["visible"]["trainer"] = {"params_bit_equal": all(torch.equal(p.detach(), q.detach())
+                                                             for p, q in zip(net3.parameters(), net4.parameters()))}
+    finally:
+        dist.all_reduce = real_all_reduce
+        ops.set_overlap_wgrad(None)
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_RESULT " + json.dumps(res), flush=True)

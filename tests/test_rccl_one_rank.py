@@ -34,7 +34,12 @@ def test_data_parallel_path_over_one_rank_rccl():
     t = res["trainer"]
     assert t["params_bit_equal"] and t["losses_equal"] and t["unused_stay_none"], t
     assert t["stats"]["launched_in_backward"] > 0 and t["stats"]["cold_skipped"] > 0, t
+    # the visible all-reduce (a stub with NCCL's stream contract that doubles the buffer after a 1 ms spin): every
+    # gradient exactly 2 x the plain one, i.e. no bucket is read before its Work is waited for and none is written after
+    # its collective started
+    for key, v in res["visible"].items():
+        assert v.get("exactly_doubled", v.get("params_bit_equal")), (key, v)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r03_rccl_one_rank.json"), "w") as f:
+    with open(os.path.join(out, "r04_rccl_one_rank.json"), "w") as f:
         json.dump(res, f, indent=1)
