@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcgat_hip.so")
 
 MAX_FC = 8
 MAX_HYPER = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_TANH, ACT_LEAKY, ACT_RELU = 0, 1, 2, 3
 
@@ -127,9 +127,9 @@ PROTOTYPES = {
     "cgat_segment_softmax_backward": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp]),
     "cgat_segment_sum": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, C.c_int64, vp]),
     "cgat_segment_attention_pool_forward": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, C.c_float,
-                                                      vp, vp, vp, vp]),
+                                                      vp, vp, vp, vp, vp]),
     "cgat_segment_attention_pool_backward": (C.c_int, [vp, C.c_int32, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp, vp,
-                                                       vp, vp, vp, C.c_int64, vp, vp]),
+                                                       vp, vp, vp, vp, C.c_int64, vp, vp]),
     "cgat_mlp_chain_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgat_mlp_chain": (C.c_int, [C.POINTER(ChainDesc), vp, C.c_size_t, vp]),
     "cgat_dense_wgrad_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -337,16 +337,17 @@ extern "C" int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx
 
 extern "C" int cgat_segment_attention_pool_forward(const float* a, int32_t aF, const float* mult, const float* m,
                                                    int64_t ldm, const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F,
-                                                   float eps, float* out, float* mx, float* inv, void* stream) {
-  return seg_attnpool_fwd_launch(a, aF, mult, m, ldm, rowptr, ridx, S, F, eps, out, mx, inv, (hipStream_t)stream);
+                                                   float eps, float* out, float* mx, float* inv, float* out_lo,
+                                                   void* stream) {
+  return seg_attnpool_fwd_launch(a, aF, mult, m, ldm, rowptr, ridx, S, F, eps, out, mx, inv, (hipStream_t)stream, out_lo);
 }
 extern "C" int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float* mult, const float* m,
                                                     int64_t ldm, const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F,
                                                     const float* out, const float* mx, const float* inv,
-                                                    const float* g_out, float* g_a, float* g_m, int64_t ldgm,
-                                                    float* g_mult, void* stream) {
+                                                    const float* out_lo, const float* g_out, float* g_a, float* g_m,
+                                                    int64_t ldgm, float* g_mult, void* stream) {
   return seg_attnpool_bwd_launch(a, aF, mult, m, ldm, rowptr, ridx, S, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, out_lo);
 }
 
 // ---- dense-layer chain ----

@@ -294,10 +294,11 @@ int seg_wsum_launch(const float* x, long ldx, const int* ridx, const float* w, i
 // softmax-weighted segment sum (attention pooling) in one pass per direction, see segment.hip
 bool seg_attnpool_fast(int aF, int F, long ldm, const void* a, const void* m, const void* out);
 int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
-                            const int* ridx, int S, int F, float eps, float* out, float* mx, float* inv, hipStream_t s);
+                            const int* ridx, int S, int F, float eps, float* out, float* mx, float* inv, hipStream_t s,
+                            float* out_lo = nullptr);     // out_lo: low part of the fp64 sum, for backward (may be null)
 int seg_attnpool_bwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
                             const int* ridx, int S, int F, const float* out, const float* mx, const float* inv, const float* g_out, float* g_a,
-                            float* g_m, long ldgm, float* g_mult, hipStream_t s);
+                            float* g_m, long ldgm, float* g_mult, hipStream_t s, const float* out_lo = nullptr);
 // per-row, per-head dot:  out[r,h] = sum_j act(x[r, h*Hd+j]) * v[(vrow(r)) * ldv + h*Hd + j] + bias[h] (+ addv[vrow(r)*H + h])
 int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, const int* vrow, const float* bias,
                   const float* addv, int rows, int H, int Hd, float* out, hipStream_t s);

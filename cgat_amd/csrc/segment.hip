@@ -86,12 +86,12 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(const float* __res
     if (mult) e *= mult[r];
     z += e;
   }
-  float inv = 1.f / (z + eps);
-  float tot = 0.f;
+  const float den = z + eps;                      // alpha = e / (sum + eps): one correctly rounded division, as the
+  float tot = 0.f;                                // reference forms it (see seg_attnpool_fwd_kernel)
   for (int r = r0; r < r1; ++r) {
     float e = expf(a[(long)r * F + f] - mx);
     if (mult) e *= mult[r];
-    float al = e * inv;
+    float al = e / den;
     alpha[(long)r * F + f] = al;
     tot += al;
   }
@@ -118,12 +118,12 @@ __device__ void seg_softmax_fwd_long(const float* __restrict__ a, const float* _
         z += e;
       }
       z = block256_sum(z, red);
-      const float inv = 1.f / (z + eps);
+      const float den = z + eps;
       float tot = 0.f;
       for (int r = r0 + threadIdx.x; r < r1; r += 256) {
         float e = expf(a[(long)r * F + f] - mx);
         if (mult) e *= mult[r];
-        const float al = e * inv;
+        const float al = e / den;
         alpha[(long)r * F + f] = al;
         tot += al;
       }
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
                                                                 const int* __restrict__ rowptr,
                                                                 const int* __restrict__ ridx, int F, float eps,
                                                                 float* __restrict__ out, float* __restrict__ mx_out,
-                                                                float* __restrict__ inv_out) {
+                                                                float* __restrict__ inv_out, float* __restrict__ out_lo) {
   const int s = blockIdx.x;
   const int r0 = rowptr[s], r1 = rowptr[s + 1];
   for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
@@ -511,7 +511,29 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
       }
     }
     if (!PER_F) mx.y = mx.z = mx.w = mx.x;
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f), acc = z;
+    // Normalised coefficients exactly as the reference forms them -- alpha = (mult e) / (sum + eps), ONE correctly rounded
+    // division per coefficient (torch_geometric softmax: out / (out_sum + 1e-16); roost_message.py:311) -- not e times a
+    // rounded reciprocal: a segment of one row then has alpha == 1 and two equal rows 0.5 each, bit for bit, and the
+    // gradient of the logits, which vanishes or is antisymmetric there, comes out so (tools/roost_gate_probe.py: with
+    // e * (1 / sum) a single-row segment had alpha = 1 - 2^-24 and a logit gradient of 2e-8 instead of 0, which the gate
+    // network's weight gradient -- a sum that cancels over every segment -- amplified to 2e-4 of its value).
+    // The weighted sum is accumulated in fp64 and handed to backward as a float pair (out, out_lo): backward centres every
+    // row on it, g_a = sum_f alpha g (m - out), and a rounding error of `out` would be common to all rows of the segment.
+    // The segment's denominator sum + eps goes to `inv_out` (backward divides by it again: the same alpha).
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; ++r) {
+      const long rr = ridx ? (long)ridx[r] : (long)r;
+      const float w = mult ? mult[rr] : 1.f;
+      if (PER_F) {
+        const float4 v = *reinterpret_cast<const float4*>(a + rr * aF + ac);
+        z.x += expf(v.x - mx.x) * w; z.y += expf(v.y - mx.y) * w; z.z += expf(v.z - mx.z) * w; z.w += expf(v.w - mx.w) * w;
+      } else {
+        z.x += expf(a[rr * aF + ac] - mx.x) * w;
+      }
+    }
+    if (!PER_F) z.y = z.z = z.w = z.x;
+    const float4 den = make_float4(z.x + eps, z.y + eps, z.z + eps, z.w + eps);
+    double accd[4] = {0.0, 0.0, 0.0, 0.0};
     for (int r = r0; r < r1; r += AP_U) {
       float4 av[AP_U], mv[AP_U];
       float wv[AP_U];
@@ -527,17 +549,24 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
 #pragma unroll
       for (int u = 0; u < AP_U; ++u) {
         if (r + u < r1) {
-          float4 e;
-          e.x = expf(av[u].x - mx.x) * wv[u];
-          if (PER_F) { e.y = expf(av[u].y - mx.y) * wv[u]; e.z = expf(av[u].z - mx.z) * wv[u]; e.w = expf(av[u].w - mx.w) * wv[u]; }
-          else e.y = e.z = e.w = e.x;
-          z.x += e.x; z.y += e.y; z.z += e.z; z.w += e.w;
-          acc.x += e.x * mv[u].x; acc.y += e.y * mv[u].y; acc.z += e.z * mv[u].z; acc.w += e.w * mv[u].w;
+          float4 al;
+          al.x = (expf(av[u].x - mx.x) * wv[u]) / den.x;
+          if (PER_F) {
+            al.y = (expf(av[u].y - mx.y) * wv[u]) / den.y; al.z = (expf(av[u].z - mx.z) * wv[u]) / den.z;
+            al.w = (expf(av[u].w - mx.w) * wv[u]) / den.w;
+          } else al.y = al.z = al.w = al.x;
+          accd[0] += (double)al.x * (double)mv[u].x; accd[1] += (double)al.y * (double)mv[u].y;
+          accd[2] += (double)al.z * (double)mv[u].z; accd[3] += (double)al.w * (double)mv[u].w;
         }
       }
     }
-    const float4 inv = make_float4(1.f / (z.x + eps), 1.f / (z.y + eps), 1.f / (z.z + eps), 1.f / (z.w + eps));
-    *reinterpret_cast<float4*>(out + (long)s * F + f) = make_float4(acc.x * inv.x, acc.y * inv.y, acc.z * inv.z, acc.w * inv.w);
+    const float4 inv = den;   // (stored under the old name: the denominators)
+    const float4 oh = make_float4((float)accd[0], (float)accd[1], (float)accd[2], (float)accd[3]);
+    *reinterpret_cast<float4*>(out + (long)s * F + f) = oh;
+    if (out_lo)
+      *reinterpret_cast<float4*>(out_lo + (long)s * F + f) =
+          make_float4((float)(accd[0] - (double)oh.x), (float)(accd[1] - (double)oh.y), (float)(accd[2] - (double)oh.z),
+                      (float)(accd[3] - (double)oh.w));
     if (PER_F) {
       *reinterpret_cast<float4*>(mx_out + (long)s * aF + ac) = mx;
       *reinterpret_cast<float4*>(inv_out + (long)s * aF + ac) = inv;
@@ -561,7 +590,8 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
                                                                 const float* __restrict__ invs,
                                                                 const float* __restrict__ g_out,
                                                                 float* __restrict__ g_a, float* __restrict__ g_m,
-                                                                long ldgm, float* __restrict__ g_mult) {
+                                                                long ldgm, float* __restrict__ g_mult,
+                                                                const float* __restrict__ out_lo) {
   const int s = blockIdx.x;
   const int r0 = rowptr[s], r1 = rowptr[s + 1];
   // every thread of a wave runs the same number of iterations (F rounded up to whole groups by the launch), so the
@@ -579,6 +609,8 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
       mx.y = mx.z = mx.w = mx.x; inv.y = inv.z = inv.w = inv.x;
     }
     const float4 o4 = *reinterpret_cast<const float4*>(out + (long)s * F + f);
+    // low part of the forward's fp64 sum (see the forward kernel): m - out = (m - out_hi) - out_lo
+    const float4 ol = out_lo ? *reinterpret_cast<const float4*>(out_lo + (long)s * F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 go = *reinterpret_cast<const float4*>(g_out + (long)s * F + f);
     for (int rs = r0; rs < r1; ++rs) {
       const long r = ridx ? (long)ridx[rs] : (long)rs;
@@ -588,11 +620,12 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
       else { av.x = a[r * aF + ac]; av.y = av.z = av.w = av.x; }
       const float4 mv = *reinterpret_cast<const float4*>(m + r * ldm + f);
       float4 al;
-      al.x = expf(av.x - mx.x) * w * inv.x;
-      if (PER_F) { al.y = expf(av.y - mx.y) * w * inv.y; al.z = expf(av.z - mx.z) * w * inv.z; al.w = expf(av.w - mx.w) * w * inv.w; }
+      al.x = (expf(av.x - mx.x) * w) / inv.x;    // `inv` holds the segment's denominator sum + eps (see the forward)
+      if (PER_F) { al.y = (expf(av.y - mx.y) * w) / inv.y; al.z = (expf(av.z - mx.z) * w) / inv.z; al.w = (expf(av.w - mx.w) * w) / inv.w; }
       else al.y = al.z = al.w = al.x;
       const float4 gm = make_float4(al.x * go.x, al.y * go.y, al.z * go.z, al.w * go.w);
-      const float4 t = make_float4(gm.x * (mv.x - o4.x), gm.y * (mv.y - o4.y), gm.z * (mv.z - o4.z), gm.w * (mv.w - o4.w));
+      const float4 dm = make_float4((mv.x - o4.x) - ol.x, (mv.y - o4.y) - ol.y, (mv.z - o4.z) - ol.z, (mv.w - o4.w) - ol.w);
+      const float4 t = make_float4(gm.x * dm.x, gm.y * dm.y, gm.z * dm.z, gm.w * dm.w);
       if (live && g_m) *reinterpret_cast<float4*>(g_m + r * ldgm + f) = gm;
       if (PER_F) {
         if (live) *reinterpret_cast<float4*>(g_a + r * aF + ac) = t;
@@ -603,8 +636,8 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
         // (whose row contributes nothing to out) still gets its -- in general non-zero -- gradient
         float q = 0.f;
         if (g_mult) {                                    // kernel argument: uniform branch
-          const float e0 = expf(av.x - mx.x) * inv.x;
-          q = live ? e0 * ((go.x * (mv.x - o4.x) + go.y * (mv.y - o4.y)) + (go.z * (mv.z - o4.z) + go.w * (mv.w - o4.w))) : 0.f;
+          const float e0 = expf(av.x - mx.x) / inv.x;
+          q = live ? e0 * ((go.x * dm.x + go.y * dm.y) + (go.z * dm.z + go.w * dm.w)) : 0.f;
           for (int o = grp >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         }
         if (live && (threadIdx.x & (grp - 1)) == 0) {
@@ -632,35 +665,36 @@ static int attnpool_threads(int F) {
   return t > 1024 ? 1024 : t;
 }
 int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
-                            const int* ridx, int S, int F, float eps, float* out, float* mx, float* inv, hipStream_t s) {
+                            const int* ridx, int S, int F, float eps, float* out, float* mx, float* inv, hipStream_t s,
+                            float* out_lo) {
   if (S <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out), "segment_attention_pool: unsupported shape (F=%d, aF=%d)", F, aF);
   const int fw = F / aF;
   CGAT_PROF("seg_attnpool_fwd", s);
   if (fw == 1)
     hipLaunchKernelGGL(seg_attnpool_fwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, mult, m, ldm,
-                       rowptr, ridx, F, eps, out, mx, inv);
+                       rowptr, ridx, F, eps, out, mx, inv, out_lo);
   else
     hipLaunchKernelGGL(seg_attnpool_fwd_kernel<false>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, mult, m, ldm,
-                       rowptr, ridx, F, eps, out, mx, inv);
+                       rowptr, ridx, F, eps, out, mx, inv, out_lo);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
 int seg_attnpool_bwd_launch(const float* a, int aF, const float* mult, const float* m, long ldm, const int* rowptr,
                             const int* ridx, int S, int F, const float* out, const float* mx, const float* inv, const float* g_out, float* g_a,
-                            float* g_m, long ldgm, float* g_mult, hipStream_t s) {
+                            float* g_m, long ldgm, float* g_mult, hipStream_t s, const float* out_lo) {
   if (S <= 0) return CGAT_OK;
-  CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out) && ldgm % 4 == 0 && (!g_m || (((uintptr_t)g_m) & 15) == 0),
+  CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out) && ldgm % 4 == 0 && (((uintptr_t)out_lo) & 15) == 0 && (!g_m || (((uintptr_t)g_m) & 15) == 0),
                  "segment_attention_pool backward: unsupported shape (F=%d, aF=%d)", F, aF);
   CGAT_CHECK_ARG(!g_mult || aF == 1, "segment_attention_pool backward: gradient of the multiplier needs one logit column");
   const int fw = F / aF;
   CGAT_PROF("seg_attnpool_bwd", s);
   if (fw == 1)
     hipLaunchKernelGGL(seg_attnpool_bwd_kernel<true>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, 1, mult, m, ldm,
-                       rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult);
+                       rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult, out_lo);
   else
     hipLaunchKernelGGL(seg_attnpool_bwd_kernel<false>, dim3(S), dim3(attnpool_threads(F)), 0, s, a, aF, fw, fw / 4, mult, m,
-                       ldm, rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult);
+                       ldm, rowptr, ridx, F, out, mx, inv, g_out, g_a, g_m, ldgm, g_mult, out_lo);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

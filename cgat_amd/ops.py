@@ -921,17 +921,19 @@ class AttentionPoolFn(torch.autograd.Function):
         out = torch.empty(S, F, dtype=torch.float32, device=dev)
         mx = torch.empty(S, aF, dtype=torch.float32, device=dev)
         inv = torch.empty(S, aF, dtype=torch.float32, device=dev)
+        out_lo = torch.empty(S, F, dtype=torch.float32, device=dev)   # low part of the fp64 sum: backward centres on out + out_lo
         with torch.cuda.device(dev):
             check(lib.cgat_segment_attention_pool_forward(_ptr(a), aF, _ptr(mu), _ptr(m), F, _ptr(rowptr), _ptr(perm), S, F,
-                                                          eps, _ptr(out), _ptr(mx), _ptr(inv), _stream()),
+                                                          eps, _ptr(out), _ptr(mx), _ptr(inv), _ptr(out_lo), _stream()),
                   "cgat_segment_attention_pool_forward")
         ctx.has_mu, ctx.has_perm, ctx.mshape = mu is not None, perm is not None, None if mult is None else mult.shape
-        ctx.save_for_backward(a, m, out, mx, inv, rowptr, *([mu] if mu is not None else []), *([perm] if perm is not None else []))
+        ctx.save_for_backward(a, m, out, mx, inv, out_lo, rowptr, *([mu] if mu is not None else []),
+                              *([perm] if perm is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        a, m, out, mx, inv, rowptr, *rest = ctx.saved_tensors
+        a, m, out, mx, inv, out_lo, rowptr, *rest = ctx.saved_tensors
         mu = rest.pop(0) if ctx.has_mu else None
         perm = rest.pop(0) if ctx.has_perm else None
         g_out = _f32c(g_out)
@@ -943,8 +945,8 @@ class AttentionPoolFn(torch.autograd.Function):
         g_mu = torch.empty_like(mu) if (mu is not None and ctx.needs_input_grad[1]) else None
         with torch.cuda.device(a.device):
             check(lib.cgat_segment_attention_pool_backward(_ptr(a), aF, _ptr(mu), _ptr(m), F, _ptr(rowptr), _ptr(perm), S, F,
-                                                           _ptr(out), _ptr(mx), _ptr(inv), _ptr(g_out), _ptr(g_a), _ptr(g_m),
-                                                           F, _ptr(g_mu), _stream()),
+                                                           _ptr(out), _ptr(mx), _ptr(inv), _ptr(out_lo), _ptr(g_out), _ptr(g_a),
+                                                           _ptr(g_m), F, _ptr(g_mu), _stream()),
                   "cgat_segment_attention_pool_backward")
         return g_a, (None if g_mu is None else g_mu.reshape(ctx.mshape)), g_m, None, None, None
 

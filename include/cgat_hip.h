@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-#define CGAT_ABI_VERSION 2   /* 2: cgat_linear_forward / cgat_edge_hidden_forward / _backward carry tensor maxima (round 3) */
+#define CGAT_ABI_VERSION 3   /* 2: cgat_linear_forward / cgat_edge_hidden_forward / _backward carry tensor maxima (round 3)
+                              * 3: cgat_segment_attention_pool_* carry out_lo; arithmetic mode 4 = "f16x3c" (round 4) */
 #define CGAT_MAX_FC 8      /* Linear+Tanh layers per hypernetwork trunk */
 #define CGAT_MAX_HYPER 8   /* predicted layers per hypernetwork */
 
@@ -300,17 +301,19 @@ int cgat_segment_sum(const float* x, int64_t ldx, const int32_t* ridx, const int
  *   alpha[r,c] = mult[r] * exp(a[r,c] - max_seg a[.,c]) / (sum_seg mult * exp(..) + eps)      (mult may be NULL)
  * = torch_geometric softmax (+1e-16) -> multiply -> scatter_add of reference CGAT.py:323-329 (vector attention:
  * aF = F), CGAT.py:59-61 (MHAttention: aF = heads) and roost_message.py:305-317 (WeightedAttention: aF = 1,
- * mult = weights ** pow, eps = 1e-13).  mx / inv [S, aF] (segment maximum, 1 / (sum + eps)) are what backward needs
- * instead of alpha.  Row r of a segment is row ridx[r] of a / mult / m (and of the gradients) when ridx != NULL.  Needs F % 4 == 0 and aF == F (aF % 4 == 0) or F / aF in {4, 8, .., 256} (a power of two). */
+ * mult = weights ** pow, eps = 1e-13).  mx / inv [S, aF] (segment maximum, the denominator sum + eps: alpha is ONE division, as in the reference) are what backward needs
+ * instead of alpha; out_lo [S, F] (may be NULL) receives the low part of the sum, which is accumulated in fp64: backward
+ * centres every row on out + out_lo, so that the rounding of `out` does not enter g_a as an error common to all rows of
+ * a segment.  Row r of a segment is row ridx[r] of a / mult / m (and of the gradients) when ridx != NULL.  Needs F % 4 == 0 and aF == F (aF % 4 == 0) or F / aF in {4, 8, .., 256} (a power of two). */
 int cgat_segment_attention_pool_forward(const float* a, int32_t aF, const float* mult, const float* m, int64_t ldm,
                                         const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F, float eps, float* out, float* mx,
-                                        float* inv, void* stream);
-/* g_m[r,f] = alpha * g_out[s,f];  g_a[r,c] = sum_{f in c} alpha * g_out * (m - out);  g_mult[r] = g_a[r,0] / mult[r]
- * (aF == 1; g_m / g_mult may be NULL) */
+                                        float* inv, float* out_lo, void* stream);
+/* g_m[r,f] = alpha * g_out[s,f];  g_a[r,c] = sum_{f in c} alpha * g_out * (m - out - out_lo);  g_mult[r] = g_a[r,0] / mult[r]
+ * (aF == 1; g_m / g_mult / out_lo may be NULL) */
 int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float* mult, const float* m, int64_t ldm,
                                          const int32_t* rowptr, const int32_t* ridx, int32_t S, int32_t F, const float* out, const float* mx,
-                                         const float* inv, const float* g_out, float* g_a, float* g_m, int64_t ldgm,
-                                         float* g_mult, void* stream);
+                                         const float* inv, const float* out_lo, const float* g_out, float* g_a, float* g_m,
+                                         int64_t ldgm, float* g_mult, void* stream);
 
 /* A chain of up to 5 dense layers of width 128 in ONE launch (f16x3 arithmetic mode; CGAT_ERR_UNSUPPORTED otherwise):
  *   r_0 = x                      (times act'(in_dact) if in_dact != NULL; stored to in_store if != NULL)

@@ -59,6 +59,14 @@ from golden_util import NOISE_MULT
 # pooling) come out as rounding noise in any summation order; a tensor whose largest entry is below ZERO_FLOOR of the
 # largest gradient of the case is compared against that floor instead of against its own magnitude.
 ZERO_FLOOR = 1e-6
+# The floor `ZERO_FLOOR * case_scale` (case_scale = the largest gradient of the case) is only open to gradients that are
+# NUMERICALLY ZERO: their fp64 reference value lies below fp32's resolution of the case (6e-8 of its largest gradient) --
+# zero in exact arithmetic (MH_A.fc_out.bias by the softmax's shift invariance, Roost's gate bias) or the remainder of a
+# >= 1e7-fold cancellation (tools/crypool_probe.py: in the sin-filled fixture `net_mean` every gradient of the crystal
+# pooling's attention branch is such a remainder -- the logit gradient alpha (g - sum alpha g) is 4e-6 of its terms --
+# and two correct fp32 evaluations of it differ by more than its value).  Everything else has to meet 1e-4 |ref| (or, for
+# the sin-filled fixtures, the reference's own fp32 deviation from fp64).
+NUM_ZERO = 1e-7
 
 
 def _mode():
@@ -138,7 +146,8 @@ def _compare_with_oracle(mk_prod, mk_orac, inputs, call, tol=TOL, label=None):
         nf = float((b.detach().double() - b64.detach()).abs().max())
         err = float((a - b.detach().double()).abs().max())
         err64 = float((a - b64.detach()).abs().max())
-        allowed = max(tol * ref_max, 0.0 if name == "out" else ZERO_FLOOR * case_scale)
+        num_zero = name != "out" and ref_max <= NUM_ZERO * case_scale
+        allowed = max(tol * ref_max, ZERO_FLOOR * case_scale if num_zero else 0.0)
         worst = max(worst, err / max(ref_max, 1e-300))
         verdict = "ok" if err <= tol * ref_max else ("ok (zero-gradient floor)" if err <= allowed else "FAIL")
         lines.append(f"  {name:66s} {err / max(ref_max, 1e-300):.2e} {err / max(nf, 1e-300):8.2f} "
@@ -340,6 +349,13 @@ def _report(lines):
             f.write(text + "\n")
 
 
+# fixture -> (most tensors admitted by the noise term, by the zero floor) in the 24-bit arithmetic modes.  Measured in
+# round 4 (f16x3c): net_mean 3 + 46 of 274 (the 46: the whole composition branch and the crystal pooling's attention
+# network, whose true gradients are ~1e-15 of the case's largest in this fixture, and the four exactly-zero MH_A output
+# biases), nodes_first0 0 + 1 of 52, nodes_first1 3 + 1 of 50; the bounds leave room for borderline roundings only.
+_ADMIT_LIMITS = {"net_mean": (6, 48), "nodes_first0": (2, 2), "nodes_first1": (6, 2)}
+
+
 @pytest.mark.parametrize("cname", _BASE_NAMES)
 def test_golden_base_full_gradients_vs_oracle(cname):
     """The BASELINE-shaped fixtures store parameter gradients above PROBE_ABOVE elements as a 12-number probe (the
@@ -369,7 +385,7 @@ def test_golden_base_full_gradients_vs_oracle(cname):
     case_scale = max(float(g.abs().max()) for g in go64.values() if g is not None)
     lines = [f"[{cname}] mode {_mode()} (derivative patterns forced)",
              "  tensor | err/|ref| | err/nf | (hip-ref64)/nf | nf/|ref| | admitted by"]
-    failures = []
+    failures, admitted = [], {}
     for name, g64 in go64.items():
         if g64 is None:
             assert gp[name] is None or float(gp[name].abs().max()) == 0.0, name
@@ -379,15 +395,25 @@ def test_golden_base_full_gradients_vs_oracle(cname):
         nf = float((go[name].double() - g64).abs().max())
         err = float((a - go[name].double()).abs().max())
         err64 = float((a - g64).abs().max())
-        terms = {"1e-4*|ref|": TOL * ref_max, f"{NOISE_MULT:g}*oracle_fp32_noise": NOISE_MULT * nf,
-                 "1e-6*case_scale": 1e-6 * case_scale}
+        terms = {"1e-4*|ref|": TOL * ref_max, f"{NOISE_MULT:g}*oracle_fp32_noise": NOISE_MULT * nf}
+        if ref_max <= NUM_ZERO * case_scale:             # numerically zero (see NUM_ZERO): the zero-gradient floor
+            terms["1e-6*case_scale (|ref| <= 1e-7 case_scale)"] = ZERO_FLOOR * case_scale
         ok = [k for k, v in terms.items() if err <= v]
+        admitted[ok[0] if ok else "NONE"] = admitted.get(ok[0] if ok else "NONE", 0) + 1
         lines.append(f"  {name:70s} {err / max(ref_max, 1e-300):.2e} {err / max(nf, 1e-300):8.2f} "
                      f"{err64 / max(nf, 1e-300):8.2f} {nf / max(ref_max, 1e-300):.2e}  {ok[0] if ok else 'NONE'}")
         if not ok:
             failures.append(f"{name}: err {err:.3e} > " + ", ".join(f"{k}={v:.3e}" for k, v in terms.items()))
+    lines.append(f"  ADMITTED-BY {cname} {_mode()}: " + ", ".join(f"{k} = {v}" for k, v in sorted(admitted.items())))
     _report(lines)
     assert not failures, "\n".join(failures)
+    # the number of tensors that need the noise term or the zero floor must not grow silently: bounds per fixture,
+    # measured in round 4 (profiles/r04_parity_attribution.txt) with two tensors of slack for borderline roundings
+    lim = _ADMIT_LIMITS.get(cname) if _mode() in ("f16x3c", "bf16x6") else None
+    if lim is not None:
+        n_noise = sum(v for k, v in admitted.items() if "noise" in k)
+        n_floor = sum(v for k, v in admitted.items() if "case_scale" in k)
+        assert n_noise <= lim[0] and n_floor <= lim[1], (cname, admitted, lim)
 
 
 def test_config1_full_size_forward_vs_oracle():
