@@ -860,6 +860,7 @@ def main():
             # K = 32 (4 x the rate): 3 + 3/4 = 3.75 pass-equivalents of matrix time per product in the kernels that have
             # the form; the others run their six-pass bf16 form
             kernels["bilinear_rows"] = "bilinear_rows128_ring16c_kernel"
+            kernels["bilinear_dual"] = "bilinear_rows128_dualc_kernel"
             F16C = getattr(P.ops, "F16C_KERNELS", ("bilinear_rows", "bilinear_dual"))
             kpasses = {t: (3.75 if t in F16C else 6) for t in kernels}
             if "bilinear_wgrad" not in F16C:

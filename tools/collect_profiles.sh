@@ -5,7 +5,7 @@
 # tools/counter_summary.py and a copy into profiles/ happen on the authoring side (tools/publish_profiles.sh).
 # Every rocprofv3 command has the program directly after `--`.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/${1:-final}
+O=$R/gpurun_out/${1:-r04final}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

@@ -180,17 +180,31 @@ template <int NF16, int NC, int FMT>
 __global__ __launch_bounds__(512, 2) void k_rate(float* out, int iters) {
   f32x4 acc[8];
   for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 acc32[2];
+  for (int i = 0; i < 2; ++i) for (int t = 0; t < 16; ++t) acc32[i][t] = 0.f;
   f16x8 a, b;
   for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 0.001f + j); b[j] = (_Float16)(j - 3.f); }
   i32x8 ca, cb;
   for (int j = 0; j < 8; ++j) { ca[j] = 0x38383838 + threadIdx.x + j; cb[j] = 0x30303030 + j; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NF16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i & 7], 0, 0, 0);
+    for (int i = 0; i < NF16; ++i) {
+      if constexpr (FMT >= 3) acc32[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc32[i & 1], 0, 0, 0);
+      else acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i & 7], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       if constexpr (FMT == 0) acc[i & 7] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ca, cb, acc[i & 7], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      else {
+      else if constexpr (FMT == 2) {   // mixed: A fp8 (8 dwords), B fp6 (6 dwords)
+        i32x6 b6 = {cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]};
+        acc[i & 7] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ca, widen6(b6), acc[i & 7], 0, 2, 0, 0, 0, 0);
+      } else if constexpr (FMT == 3) {   // 32x32x64 fp6 (unscaled)
+        i32x6 a6 = {ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]}, b6 = {cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]};
+        acc32[i & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen6(a6), widen6(b6), acc32[i & 1], 2, 2, 0, 0, 0, 0);
+      } else if constexpr (FMT == 4) {   // 32x32x64 mixed A fp8 / B fp6
+        i32x6 b6 = {cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]};
+        acc32[i & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ca, widen6(b6), acc32[i & 1], 0, 2, 0, 0, 0, 0);
+      } else {
         i32x6 a6 = {ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]}, b6 = {cb[0], cb[1], cb[2], cb[3], cb[4], cb[5]};
         acc[i & 7] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(widen6(a6), widen6(b6), acc[i & 7], 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       }
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void k_rate(float* out, int iters) {
   }
   float s = 0.f;
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  s += acc32[0][0] + acc32[1][5];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int NF16, int NC, int FMT>
@@ -380,6 +395,11 @@ int main() {
     time_rate<12, 3, 1>("12 x f16 + 3 x fp6 16x16x128", dout);
     time_rate<0, 12, 0>("12 x fp8 16x16x128", dout);
     time_rate<0, 12, 1>("12 x fp6 16x16x128", dout);
+    time_rate<12, 3, 2>("12 x f16 + 3 x (A fp8, B fp6) 16x16x128", dout);
+    time_rate<0, 12, 2>("12 x (A fp8, B fp6) 16x16x128", dout);
+    time_rate<12, 0, 3>("12 x f16 32x32x16", dout);
+    time_rate<12, 3, 3>("12 x f16 32x32x16 + 3 x fp6 32x32x64", dout);
+    time_rate<12, 3, 4>("12 x f16 32x32x16 + 3 x (A fp8, B fp6) 32x32x64", dout);
   }
   return 0;
 }

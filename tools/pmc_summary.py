@@ -34,10 +34,13 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") 
     for r in rows:
         f.write("%s,%d,%.1f,%.1f,%d\n" % r)
 N, C = 83340, 128
-# default arithmetic f16x3: the prepared T / r operands are two fp16 planes = 4 bytes per element
+# f16x3: the prepared T / r operands are two fp16 planes = 4 bytes per element; f16x3c (the default since round 4): the
+# prepared T is 25 KB per 32 output columns and `a` = 6.25 bytes per element; the bf16 forms: three 2-byte planes
 alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           # p, q, init, out + the two planes of T
        "bilinear_rows128_dual_kernel": 7 * N * C * 4 + C ** 3 * 4,             # p, q, zz, init1, out1, init2, out2 + T
-       "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 4 + C ** 3 * 4,  # pT, qT, r planes + out
+       "bilinear_rows128_ring16c_kernel": 4 * N * C * 4 + C * 4 * 25600,       # p, q, init, out + the f16x3c image of T
+       "bilinear_rows128_dualc_kernel": 7 * N * C * 4 + C * 4 * 25600,
+       "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 6 + C ** 3 * 4,  # pT, qT, three bf16 planes of r + out
        # the batched f16x3 launch covers the four predicted layers: 4 x (pT, qT, two fp16 planes of r, out)
        "bilinear_wgrad128_f16p_kernel": 4 * (2 * N * C * 4 + N * C * 4 + C ** 3 * 4)}
 import subprocess

@@ -3,7 +3,7 @@
 # DESIGN.md §6 and bench.py cite.   bash tools/publish_profiles.sh gpurun_out/r3final r03
 set -e
 D=${1:?gpurun_out/<dir>}
-T=${2:-r03}
+T=${2:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/profiles
 cp $D/bench.json $P/${T}_final_bench.json
