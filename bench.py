@@ -527,6 +527,29 @@ def _count_host_syncs(step):
     return sum(1 for x in w if "synchroniz" in str(x.message).lower())
 
 
+def _count_all_kernels(step):
+    """Every GPU kernel of ONE step (the library's and torch's own elementwise / copy / fill kernels), counted by
+    torch.profiler's device activity; None when another tracer (rocprofv3) owns the process or the profiler is missing."""
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) or \
+            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        n = 0
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower():
+                name = ev.name.lower()
+                if not (name.startswith("memcpy") or name.startswith("memset")):
+                    n += 1
+        return n or None
+    except Exception:
+        return None
+
+
 def _launch_report(step, steps, world, try_graph):
     """Launch-bound regime (the reference's shipped --batch-size 64, lightning_module.py:468-473): library kernel launches
     and host synchronisations per step, and the same step captured into ONE hipGraph (cgat_amd.GraphedStep) and
@@ -536,9 +559,11 @@ def _launch_report(step, steps, world, try_graph):
     n0 = ops.prof_launches()
     step()
     launches = ops.prof_launches() - n0
-    rep = {"library_kernel_launches_per_step": launches, "host_syncs_per_step": _count_host_syncs(step),
-           "what": "launches = kernels issued by libcgat_hip in one step (torch's own elementwise / copy kernels not "
-                   "counted; profiles/ has the rocprofv3 totals); host syncs by torch.cuda.set_sync_debug_mode"}
+    rep = {"library_kernel_launches_per_step": launches, "all_kernel_launches_per_step": _count_all_kernels(step),
+           "host_syncs_per_step": _count_host_syncs(step),
+           "what": "library launches = kernels issued by libcgat_hip in one step; all = every GPU kernel of the step "
+                   "incl. torch's own elementwise / copy / fill kernels (torch.profiler device activity; null under "
+                   "rocprofv3); host syncs by torch.cuda.set_sync_debug_mode"}
     if try_graph:
         try:
             gs = P.GraphedStep(step, warmup=2)

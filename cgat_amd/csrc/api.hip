@@ -400,8 +400,8 @@ extern "C" int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t 
   if (rows == 0) {   // empty sums
     for (int i = 0; i < n; ++i) {
       for (int o = 0; o < 128; ++o)
-        if (hipMemsetAsync(out[i] + o * ldo, 0, 512, s) != hipSuccess) return CGAT_ERR_HIP;
-      if (bsum && bsum[i] && hipMemsetAsync(bsum[i], 0, 512, s) != hipSuccess) return CGAT_ERR_HIP;
+        CGAT_TRY(fill_launch(out[i] + o * ldo, 0.f, 128, s));
+      if (bsum && bsum[i]) CGAT_TRY(fill_launch(bsum[i], 0.f, 128, s));
     }
     return CGAT_OK;
   }

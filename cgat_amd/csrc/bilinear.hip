@@ -1276,16 +1276,14 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
 // lane = 16 kg + c % 16 holds, per plane fragment, b = 32 s + 8 kg + j (j = 0..7) and, per 6-bit fragment, all 32 values
 // b = 32 s + 8 kg + j <-> element 8 s + j: the order in which the contraction kernels hold their row operand.
 // One thread per (a, column c, k-group kg).  max |T| (tmax) lies behind the last chunk.
-__global__ void prepare_T_f16c_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int NA, long sa, long sb,
-                                      long sc, int alternate, const float* __restrict__ tmax) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)NA * 512) return;
+__device__ __forceinline__ void prepare_T_f16c_item(const float* __restrict__ src, uint4* __restrict__ dst, long i, long sa,
+                                                    long sb, long sc, int alternate, float tm) {
   // thread order follows the fastest source stride where it can: c fastest when sc == 1
   int a = (int)(i >> 9), c, kg;
   if (sc == 1) { c = (int)(i & 127); kg = (int)((i >> 7) & 3); }
   else { kg = (int)(i & 3); c = (int)((i >> 2) & 127); }
   float st, it;
-  pow2_scale(tmax[0], st, it);
+  pow2_scale(tm, st, it);
   if (alternate && (a & 1)) st = -st;
   float v[32];
 #pragma unroll
@@ -1313,6 +1311,12 @@ __global__ void prepare_T_f16c_kernel(const float* __restrict__ src, uint4* __re
     *reinterpret_cast<uint4*>(blk + term * 384 + lane * 4) = make_uint4(f.w[0], f.w[1], f.w[2], f.w[3]);
     *reinterpret_cast<uint2*>(blk + term * 384 + 256 + lane * 2) = make_uint2(f.w[4], f.w[5]);
   }
+}
+__global__ void prepare_T_f16c_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int NA, long sa, long sb,
+                                      long sc, int alternate, const float* __restrict__ tmax) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)NA * 512) return;
+  prepare_T_f16c_item(src, dst, i, sa, sb, sc, alternate, tmax[0]);
 }
 
 // Weight operands of the edge / dense kernels in the fp16 form: one workgroup per 128 x 128 block `a` keeps the block
@@ -1443,7 +1447,7 @@ __global__ void absmax_kernel(const float* __restrict__ src, long n, float* __re
   block_absmax_commit(m, out);
 }
 int absmax_launch(const float* src, long n, float* out, hipStream_t stream) {
-  if (hipMemsetAsync(out, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
+  CGAT_TRY(fill_launch(out, 0.f, 1, stream));   // (a kernel, not hipMemsetAsync: see fill_launch in rowops.hip)
   if (n <= 0) return CGAT_OK;
   CGAT_CHECK_ARG((((uintptr_t)src) & 15) == 0, "absmax: source must be 16-byte aligned");
   const int blocks = (int)(cdiv(n, 4 * 256) < 512 ? cdiv(n, 4 * 256) : 512);
@@ -1597,13 +1601,28 @@ __global__ void prepare_T_f16_batch_kernel(TPrepBatch b, int NA, long sa, long s
   d16[(blk + 0) * 2048 + in] = h;
   d16[(blk + 1) * 2048 + in] = l;
 }
+// the f16x3c image (prepare_T_f16c_kernel) of several tensors: blockIdx.y = tensor, its maximum folded from the partials
+__global__ void prepare_T_f16c_batch_kernel(TPrepBatch b, int NA, long sa, long sb, long sc, int alternate,
+                                            const float* __restrict__ part) {
+  float tm = part[blockIdx.y * TPREP_PARTS + (threadIdx.x & 63)];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+  float* img = reinterpret_cast<float*>(b.dst[blockIdx.y]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) img[(size_t)NA * F16C_A_FLOATS] = tm;   // behind the last chunk
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)NA * 512) return;
+  prepare_T_f16c_item(b.src[blockIdx.y], reinterpret_cast<uint4*>(img), i, sa, sb, sc, alternate, tm);
+}
 size_t bilinear_prepare_T_batch_ws_floats(int n) { return (size_t)(n > 0 ? n : 1) * TPREP_PARTS; }
-// f16x3 mode, 128-wide interleaved layout only (returns CGAT_ERR_UNSUPPORTED otherwise: prepare one by one);
+// f16x3 / f16x3c modes, 128-wide interleaved layout only (returns CGAT_ERR_UNSUPPORTED otherwise: prepare one by one);
 // dst[i]: bilinear_T_floats(...) floats each; part: bilinear_prepare_T_batch_ws_floats(n) floats
 int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, int n0, int n1, int n2, int perm0,
                              int perm1, int perm2, float* part, hipStream_t stream, int alternate) {
   int dims[3] = {n0, n1, n2};
-  if (n < 1 || n > TPREP_MAX || bilinear_mode() != 2 || !bilinear_T_interleaved(dims[perm1], dims[perm2]))
+  const int mode = bilinear_mode();
+  static int off = -1;   // CGAT_NO_TPREP_BATCH=1 (debug): prepare the operands one by one
+  if (off < 0) { const char* e = getenv("CGAT_NO_TPREP_BATCH"); off = (e && e[0] == '1') ? 1 : 0; }
+  if (off || n < 1 || n > TPREP_MAX || (mode != 2 && mode != 4) || !bilinear_T_interleaved(dims[perm1], dims[perm2]))
     return CGAT_ERR_UNSUPPORTED;
   const long st[3] = {(long)n1 * n2, (long)n2, 1};
   const int NA = dims[perm0];
@@ -1616,8 +1635,12 @@ int bilinear_prepare_T_batch(int n, const float* const* src, float* const* dst, 
   }
   hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(TPREP_PARTS, n), dim3(256), 0, stream, b, total, part);
   CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(prepare_T_f16_batch_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, stream, b, NA, st[perm0],
-                     st[perm1], st[perm2], alternate, (const float*)part);
+  if (mode == 4)
+    hipLaunchKernelGGL(prepare_T_f16c_batch_kernel, dim3(cdiv((long)NA * 512, 256), n), dim3(256), 0, stream, b, NA,
+                       st[perm0], st[perm1], st[perm2], alternate, (const float*)part);
+  else
+    hipLaunchKernelGGL(prepare_T_f16_batch_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, stream, b, NA, st[perm0],
+                       st[perm1], st[perm2], alternate, (const float*)part);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }
@@ -2795,7 +2818,7 @@ int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, 
   WgradPrepDesc pd;
   memset(&pd, 0, sizeof(pd));
   pd.p[0] = p; pd.q[0] = q; pd.r[0] = r;
-  CGAT_HIP(hipMemsetAsync(mx, 0, 16, stream));
+  CGAT_TRY(fill_launch(mx, 0.f, 4, stream));
   hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA, mx);
   CGAT_LAUNCH_CHECK();
   hipLaunchKernelGGL(transpose_pad_batch_kernel, dim3(np / 32, 4, 2), dim3(256), 0, stream, pd, ldp, ldq, nrows, NA, np, rps,
@@ -2850,7 +2873,7 @@ int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, c
   u.sR = (long)np * 128 * 2 * 2 / 16;
   u.n_layers = n_layers; u.splits = splits; u.npairs = npairs; u.NA = NA; u.rows_pad = np; u.rows_per_split = rps;
   if (!prepared) {
-    CGAT_HIP(hipMemsetAsync(mx, 0, 256, stream));
+    CGAT_TRY(fill_launch(mx, 0.f, 64, stream));
     hipLaunchKernelGGL(absmax_rows_batch_kernel, dim3(256, 3 * n_layers), dim3(256), 0, stream, pd, ldp, ldq, ldr, nrows, NA,
                        mx);
     CGAT_LAUNCH_CHECK();
@@ -2922,7 +2945,7 @@ int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, co
     float* slab = (float*)((char*)ws + o_slab);
     float* mx = (float*)((char*)ws + need - 16);
     const bool f16 = bilinear_mode() == 2;
-    if (f16 && hipMemsetAsync(mx, 0, 16, stream) != hipSuccess) return CGAT_ERR_HIP;
+    if (f16) CGAT_TRY(fill_launch(mx, 0.f, 4, stream));
     hipLaunchKernelGGL(transpose_pad_kernel, dim3(np / 32, cdiv(NA, 32)), dim3(256), 0, stream, p, ldp, nrows, NA, np, pT,
                        f16 ? mx : (float*)nullptr);
     CGAT_LAUNCH_CHECK();

@@ -562,7 +562,7 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   // operand (a = column block, b = column in block, c = output k) = We[(128 a + b) * s_col + c * s_out]
   if (f16) {   // per-tensor weight scale: max |We| behind the two planes
     float* wmax = Wq + (size_t)ncb * 16384;
-    if (hipMemsetAsync(wmax, 0, sizeof(float), stream) != hipSuccess) return CGAT_ERR_HIP;
+    CGAT_TRY(fill_launch(wmax, 0.f, 1, stream));
     if (out_contig) CGAT_TRY(absmax_rows128_launch(We, s_col, W2, wmax, stream));
     else
       for (int j = 0; j < ncb; ++j) CGAT_TRY(absmax_rows128_launch(We + 128 * j, s_out, 128, wmax, stream));

@@ -948,7 +948,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     const bool vec = (d.Hd % 4 == 0) && ((((uintptr_t)sv.Z) | ((uintptr_t)gZ) | ((uintptr_t)gS) | ((uintptr_t)Gi) |
                                           ((uintptr_t)p->A_out_w)) & 15) == 0;
     have_scales = vec && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0;
-    if (have_scales) CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
+    if (have_scales) CGAT_TRY(fill_launch(scales, 0.f, 8, c.s));
     // the forward stored Z as bf16 under exactly this predicate (same tensors, same alignment)
     zb = attn_bf16(d) && edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
          edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
@@ -1066,12 +1066,12 @@ static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDi
   const bool f16_ok = !c.dry && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0 && d.E > 0;
   if (g_is_pre) {
     if (f16_ok && gpre_absmax) {
-      CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
+      CGAT_TRY(fill_launch(scales, 0.f, 8, c.s));
       CGAT_HIP(hipMemcpyAsync(scales, gpre_absmax, sizeof(float), hipMemcpyDeviceToDevice, c.s));
       have_scales = true;
     }
   } else if (f16_ok) {
-    CGAT_HIP(hipMemsetAsync(scales, 0, 8 * sizeof(float), c.s));
+    CGAT_TRY(fill_launch(scales, 0.f, 8, c.s));
     RUN(act_bwd_leaky_max_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, scales, c.s, &have_scales));
   } else {
     RUN(act_bwd_launch(Hsaved, g_H, gZ, (long)d.E * d.W2, CGAT_ACT_LEAKY, c.s));
@@ -1102,7 +1102,7 @@ extern "C" int cgat_edge_hidden_forward(const cgat_plan* plan, int32_t C, int32_
                                         const float* b_in, const float* x, const float* edge_attr, float* hidden,
                                         float* hidden_absmax, void* ws, size_t ws_bytes, void* stream) {
   CGAT_TRY(hidden_check(plan, C, Ce, W2));
-  if (hidden_absmax) CGAT_HIP(hipMemsetAsync(hidden_absmax, 0, sizeof(float), (hipStream_t)stream));
+  if (hidden_absmax) CGAT_TRY(fill_launch(hidden_absmax, 0.f, 1, (hipStream_t)stream));
   if (ws_bytes < cgat_edge_hidden_forward_workspace_bytes(plan, C, Ce, W2)) {
     cgat_set_error("edge_hidden_forward: workspace too small");
     return CGAT_ERR_WORKSPACE;
@@ -1234,9 +1234,9 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
                              float* saved) {
   const int W = p->W;
   const size_t WW = (size_t)W * W;
-  // the re-laid T of every predicted layer, prepared up front in two launches where the batched form exists (f16x3)
+  // the re-laid T of every predicted layer, prepared up front in two launches where the batched form exists (f16x3, f16x3c)
   const size_t Tfl = bilinear_T_floats(W, W, W);
-  const bool batch_T = W == 128 && bilinear_mode() == 2 && p->n_hyper <= TPREP_MAX;
+  const bool batch_T = W == 128 && (bilinear_mode() == 2 || bilinear_mode() == 4) && p->n_hyper <= TPREP_MAX;
   float* Tp = c.take<float>((batch_T ? (size_t)p->n_hyper : 1) * Tfl);
   float* Tpart = c.take<float>(bilinear_prepare_T_batch_ws_floats(p->n_hyper));
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
@@ -1362,7 +1362,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const size_t WW = (size_t)W * W;
   const size_t rw = (size_t)rows * W;
   const size_t Tfl = bilinear_T_floats(W, W, W);
-  const bool batch_T = W == 128 && bilinear_mode() == 2 && p->n_hyper <= TPREP_MAX && bilinear_dual_fast(W, W, W);
+  const bool batch_T = W == 128 && (bilinear_mode() == 2 || bilinear_mode() == 4) && p->n_hyper <= TPREP_MAX && bilinear_dual_fast(W, W, W);
   float* Tp = c.take<float>((batch_T ? (size_t)p->n_hyper : 1) * Tfl);
   float* Tpart = c.take<float>(bilinear_prepare_T_batch_ws_floats(p->n_hyper));
   float* g_hin = c.take<float>(rw);

@@ -152,11 +152,11 @@ int csr_from_keys_launch(const int* keys, int n, int S, int* rowptr, int* perm, 
     cgat_set_error("csr: workspace too small (%zu < %zu)", ws_bytes, w.off);
     return CGAT_ERR_WORKSPACE;
   }
-  CGAT_HIP(hipMemsetAsync(count, 0, ((size_t)S + 1) * 4, s));
-  CGAT_HIP(hipMemsetAsync(cursor, 0, ((size_t)S + 1) * 4, s));
+  CGAT_TRY(fill_launch(reinterpret_cast<float*>(count), 0.f, (long)S + 1, s));   // (0.f and int 0 share their bits)
+  CGAT_TRY(fill_launch(reinterpret_cast<float*>(cursor), 0.f, (long)S + 1, s));
   // keys outside [0, S) leave the tail of perm unfilled; the gathers that consume it before the caller has looked at
   // rowptr[S] must still read valid indices
-  if (n > 0) CGAT_HIP(hipMemsetAsync(perm, 0, (size_t)n * 4, s));
+  if (n > 0) CGAT_TRY(fill_launch(reinterpret_cast<float*>(perm), 0.f, (long)n, s));
   if (n > 0) {
     hipLaunchKernelGGL(hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, keys, n, S, count);
     CGAT_LAUNCH_CHECK();

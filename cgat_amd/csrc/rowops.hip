@@ -300,6 +300,12 @@ int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, in
   return CGAT_OK;
 }
 
+// Also the library's memset: NO hipMemsetAsync anywhere in the library (round 4).  A 4-byte hipMemsetAsync captured into a
+// hipGraph (cgat_amd.GraphedStep) was not reliably in effect before the kernel that followed it on the SECOND replay
+// (ROCm 7.2, memory from the capture's private pool): the slot of a maximum kept the bits a later operator of the
+// previous replay had left in the reused block, atomicMax compared against them, the operand scale came out wrong and the
+// step returned NaN -- replay 0 and every eager run were fine.  The same zeroing as a kernel node replays bit-identically
+// (tests/test_capture.py).
 __global__ void fill_kernel(float* __restrict__ p, float v, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;

@@ -369,10 +369,10 @@ int rows_dw128_launch(const float* G, long ldg, const float* X1, long ldx1, floa
   const int nx = X2 ? 2 : 1;
   if (rows <= 0) {
     for (int o = 0; o < 128; ++o) {
-      if (hipMemsetAsync(out1 + o * ldo1, 0, 512, stream) != hipSuccess) return CGAT_ERR_HIP;
-      if (X2 && hipMemsetAsync(out2 + o * ldo2, 0, 512, stream) != hipSuccess) return CGAT_ERR_HIP;
+      CGAT_TRY(fill_launch(out1 + o * ldo1, 0.f, 128, stream));
+      if (X2) CGAT_TRY(fill_launch(out2 + o * ldo2, 0.f, 128, stream));
     }
-    if (bsum && hipMemsetAsync(bsum, 0, 512, stream) != hipSuccess) return CGAT_ERR_HIP;
+    if (bsum) CGAT_TRY(fill_launch(bsum, 0.f, 128, stream));
     return CGAT_OK;
   }
   const size_t need = rows_dw128_ws_bytes(rows, nx);

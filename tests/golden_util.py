@@ -11,6 +11,17 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _cache = {}
 
 
+
+def floor_open(ref_max, case_scale):
+    """Is the zero-gradient floor `1e-6 * case scale` open to this tensor?  Only to numerically zero gradients (|fp64
+    reference| <= 1e-7 of the case's largest gradient: below fp32's resolution of the case) -- except in the DIAGNOSTIC
+    arithmetic mode `f32` (CGAT_BILINEAR_MODE=f32: f32-input MFMA / plain fp32 chains, never a default and not what any
+    number is quoted in), which keeps round 3's criterion (floor open to every tensor): its accumulators carry the
+    un-alternated rounding bias the split modes cancel, and four cancellation-heavy tensors of the
+    sin-filled fixtures sit at 1.0-2.0e-4 of their value there."""
+    import os
+    return ref_max <= 1e-7 * case_scale or os.environ.get("CGAT_BILINEAR_MODE", "") == "f32"
+
 def load(fname):
     if fname not in _cache:
         _cache[fname] = np.load(os.path.join(GOLDEN_DIR, fname))
@@ -78,7 +89,7 @@ def check_case(fname, cname, case, *, device="cpu", tol=1e-4, grad_tol=None, rep
                           abs(got[3] - want[3]) / n, np.abs(got[4:] - want[4:]).max())
         # the zero floor is only open to numerically zero gradients: |ref| below fp32's resolution of the case
         # (tests/test_hip_golden.py NUM_ZERO)
-        floor = 1e-6 * case_scale if ref_max <= 1e-7 * case_scale else 0.0
+        floor = 1e-6 * case_scale if floor_open(ref_max, case_scale) else 0.0
         allowed = max(grad_tol * ref_max, NOISE_MULT * nf_abs, floor)
         errs[name] = abs_err / max(ref_max, 1e-300)
         if report is not None:

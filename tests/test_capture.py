@@ -12,8 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_graphed_steps_equal_eager_bitwise():
+@pytest.mark.parametrize("one_by_one", [False, True])
+def test_graphed_steps_equal_eager_bitwise(one_by_one):
+    """one_by_one: the hypernetwork's operands prepared tensor by tensor (CGAT_NO_TPREP_BATCH=1: the fall-back of the
+    batched preparation) -- the path on which a captured 4-byte hipMemsetAsync made the second replay return NaN in
+    round 4 (csrc/rowops.hip, fill_launch)."""
+    env = dict(os.environ)
+    if one_by_one:
+        env["CGAT_NO_TPREP_BATCH"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "capture_worker.py")], capture_output=True, text=True,
-                       timeout=900)
+                       timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "CAPTURE_OK layer" in r.stdout and "CAPTURE_OK stack" in r.stdout, r.stdout[-2000:]
