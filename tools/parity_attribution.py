@@ -2,13 +2,13 @@
 """Merges the per-mode parity reports written by `pytest -m gpu` (gpurun_out/parity_report_<mode>.txt, one run per
 arithmetic mode) into profiles/<tag>_parity_report_<mode>.txt (copies) and profiles/<tag>_parity_attribution.txt: every
 tensor of the BASELINE-shaped fixtures that is more than 1e-4 of |ref| away from the oracle's fp32 run in the default
-mode, with its error in the three modes, the oracle's own fp32-vs-fp64 deviation nf, and what the excess is attributed
-to.   python tools/parity_attribution.py gpurun_out r03"""
+mode (f16x3c), with its error in the four modes, the oracle's own fp32-vs-fp64 deviation nf, and what the excess is
+attributed to.   python tools/parity_attribution.py gpurun_out r04"""
 import collections, os, re, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODES = ("f16x3", "bf16x6", "f32")
+MODES = ("f16x3c", "bf16x6", "f16x3", "f32")   # the default mode first
 ROW = re.compile(r"\s+(\S+)\s+([\d.e+-]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.e+-]+)\s+(.*)")
 
 
@@ -29,13 +29,13 @@ def load(mode):
 
 rep = {m: load(m) for m in MODES}
 out = ["Tensors of the BASELINE-shaped fixtures (closed-form sin-pattern parameters, derivative patterns forced) whose error vs the",
-       "oracle's fp32 run exceeds 1e-4 |ref| in the default mode (f16x3), in all three arithmetic modes.",
+       "oracle's fp32 run exceeds 1e-4 |ref| in the default mode (f16x3c, 24-bit operands), in all four arithmetic modes.",
        "  err = ||hip - oracle32||_inf / ||oracle64||_inf;  nf = ||oracle32 - oracle64||_inf / ||oracle64||_inf (the reference's own fp32 noise)",
        "  x64 = ||hip - oracle64||_inf / nf: how many times the reference's own fp32 deviation the HIP result is from the fp64 truth",
        "", f"{'case / tensor':86s} {'nf':>9s} | " + " | ".join(f"{m:>8s} err   x64" for m in MODES) + " | attribution"]
 n_listed = 0
 stats = collections.Counter()
-for key, r in rep["f16x3"].items():
+for key, r in rep[MODES[0]].items():
     case, name = key
     if not (case in ("net_mean", "nodes_first0", "nodes_first1") or case.startswith("net_")):
         continue
@@ -46,10 +46,12 @@ for key, r in rep["f16x3"].items():
         q = rep[m].get(key)
         cols.append(f"{q['rel']:.2e} {q['err64_nf']:5.2f}" if q else f"{'-':>8s} {'-':>5s}")
     others = [rep[m][key]["rel"] for m in ("bf16x6", "f32") if key in rep[m]]
-    if r["nf_rel"] >= 2.5e-5 and r["err64_nf"] <= 4:
+    if "case_scale" in r["verdict"]:
+        why = "numerically zero gradient (|ref64| <= 1e-7 of the case's largest gradient): admitted by the zero floor"
+    elif r["nf_rel"] >= 2.5e-5 and r["err64_nf"] <= 4:
         why = "oracle fp32 itself >= 2.5e-5 from fp64; hip within 4 nf of fp64: summation-order noise of a cancelling sum"
     elif others and min(others) <= 1e-4:
-        why = "22-bit operand split (a 24-bit mode is within 1e-4)"
+        why = "arithmetic of the default mode (bf16x6 or f32 is within 1e-4)"
     else:
         why = "summation order (all modes alike)"
     stats[why] += 1
