@@ -81,6 +81,12 @@ def test_graphed_stack_step_equals_eager_bitwise():
     out = step()
     torch.cuda.synchronize()
     want = _snap([out] + [p.grad for p in params])
+    import hashlib
+    h = hashlib.sha1()
+    for t in want:
+        if t is not None:
+            h.update(t.cpu().numpy().tobytes())
+    print("STACK_SHA1", h.hexdigest(), flush=True)   # tests/test_capture.py: the same on both operand-preparation paths
     # nothing of the eager step's autograd graph may stay alive into the capture: its AccumulateGrad nodes belong to the
     # stream the eager step ran on, and a capture that meets them crashes inside the HIP graph runtime (torch warns:
     # "The AccumulateGrad node's stream does not match ...")

@@ -9,6 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SHA = {}
 
 
 @pytest.mark.gpu
@@ -24,3 +25,6 @@ def test_graphed_steps_equal_eager_bitwise(one_by_one):
                        timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "CAPTURE_OK layer" in r.stdout and "CAPTURE_OK stack" in r.stdout, r.stdout[-2000:]
+    _SHA[one_by_one] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("STACK_SHA1")][0]
+    if len(_SHA) == 2:   # the batched and the one-by-one preparation build the same operand images: bit-equal steps
+        assert _SHA[False] == _SHA[True], _SHA
