@@ -1067,7 +1067,7 @@ static int edge_hidden_backward_impl(Ctx& c, const cgat_plan* plan, const AttnDi
   if (g_is_pre) {
     if (f16_ok && gpre_absmax) {
       CGAT_TRY(fill_launch(scales, 0.f, 8, c.s));
-      CGAT_HIP(hipMemcpyAsync(scales, gpre_absmax, sizeof(float), hipMemcpyDeviceToDevice, c.s));
+      CGAT_TRY(copy2d_launch(gpre_absmax, 1, scales, 1, 1, 1, c.s));   // (a kernel node, like every fill: rowops.hip)
       have_scales = true;
     }
   } else if (f16_ok) {
