@@ -169,11 +169,9 @@ __device__ __forceinline__ void block_absmax_commit(float m, float* out) {
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
-    // the slot only grows while a kernel runs, so a read that is already >= m makes the atomic unnecessary.  The read is
-    // an AGENT-scope atomic load: a plain (even volatile) load may be served by this XCD's L2 with the value the slot
-    // held BEFORE the memset that preceded the launch -- in a replayed hipGraph the slot keeps its address and its
-    // previous maximum, the stale line made every workgroup skip its atomic, and the operand was scaled by whatever
-    // partial maximum got through (found by tests/test_capture.py in the f16x3c mode: replay != eager).
+    // the slot only grows while a kernel runs (it is zeroed by a kernel before the launch: rowops.hip, fill_launch), so a
+    // read that is already >= m makes the atomic unnecessary.  The read is an agent-scope atomic load, so that it is
+    // served where the other XCDs' atomics land and not by a line this XCD's L2 fetched earlier in the launch.
     if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMax(reinterpret_cast<unsigned*>(out), __builtin_bit_cast(unsigned, m));
   }
