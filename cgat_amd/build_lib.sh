@@ -4,16 +4,16 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libcgat_hip.so"
-SRCS=(api gemm gemmsplit bilinear edgez edgebwd rowsdw collate optim rowops segment plan layers chain)
+SRCS=(api gemm gemmsplit bilinear wgradc edgez edgebwd rowsdw collate optim rowops segment plan layers chain)
 OBJS=()
 PIDS=()
 mkdir -p "$HERE/csrc/build"
 for s in "${SRCS[@]}"; do
   src="$HERE/csrc/$s.hip"; obj="$HERE/csrc/build/$s.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/kernels.h" -nt "$obj" ] || [ "$HERE/csrc/common.h" -nt "$obj" ] || [ "$HERE/csrc/mfma_bf16.h" -nt "$obj" ] || [ "$HERE/../include/cgat_hip.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/kernels.h" -nt "$obj" ] || [ "$HERE/csrc/common.h" -nt "$obj" ] || [ "$HERE/csrc/mfma_bf16.h" -nt "$obj" ] || [ "$HERE/csrc/wgrad_batch.h" -nt "$obj" ] || [ "$HERE/../include/cgat_hip.h" -nt "$obj" ]; then
     extra=""
     # MFMA kernels with VALU epilogues: no SLP packing into v_pk_*_f32 (see the note in csrc/edgez.hip)
-    if [ "$s" = edgez ] || [ "$s" = edgebwd ] || [ "$s" = bilinear ] || [ "$s" = chain ] || [ "$s" = rowsdw ] || [ "$s" = gemmsplit ]; then extra="-fno-slp-vectorize"; fi
+    if [ "$s" = edgez ] || [ "$s" = edgebwd ] || [ "$s" = bilinear ] || [ "$s" = wgradc ] || [ "$s" = chain ] || [ "$s" = rowsdw ] || [ "$s" = gemmsplit ]; then extra="-fno-slp-vectorize"; fi
     rm -f "$obj"     # a failed compile must not leave a stale object behind for the link step
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$src" -o "$obj" ${CGAT_HIPCC_FLAGS} &
     PIDS+=($!)

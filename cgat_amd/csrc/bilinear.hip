@@ -21,6 +21,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "mfma_bf16.h"
+#include "wgrad_batch.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -2401,18 +2402,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_bf16_kernel(const fl
 //    B fragments are double-buffered one column block ahead, and a three-slot LDS ring lets the fragments of the next
 //    chunk be fetched BEFORE the chunk barrier, so no wave starts a chunk with an empty matrix pipe.
 // ---------------------------------------------------------------------------------------
-#define WGB_MAX 8
-struct WgradBatchDesc {
-  float* out[WGB_MAX];   // final [NA][128][128] outputs (splits == 1)
-  float* slab;           // [layer][split][NA][128][128] partial sums (splits > 1)
-  long sT, sR;           // per-layer strides: floats of pT / qT, uint4 of Rq
-  int n_layers, splits, npairs, NA, rows_pad, rows_per_split;
-};
-struct WgradPrepDesc {
-  const float* p[WGB_MAX];
-  const float* q[WGB_MAX];
-  const float* r[WGB_MAX];
-};
+// (WgradBatchDesc / WgradPrepDesc: wgrad_batch.h)
 
 // mx[4 * layer + which] = max |tensor|, which 0 / 1 / 2 = p / q / r  (mx zeroed before)
 __global__ void absmax_rows_batch_kernel(WgradPrepDesc d, long ldp, long ldq, long ldr, int rows, int NA,
@@ -2778,14 +2768,16 @@ static size_t wgrad_batch_ws(int n_layers, int nrows, int NA, int splits, size_t
   return off;
 }
 bool bilinear_wgrad_batch_fast(int n_layers, int NA, int NB, int NC, long ldq, long ldr) {
-  return bilinear_mode() == 2 && n_layers >= 1 && n_layers <= WGB_MAX && NA >= 1 && NA <= 128 && NB == 128 && NC == 128 &&
+  return (bilinear_mode() == 2 || bilinear_mode() == 4) && n_layers >= 1 && n_layers <= WGB_MAX && NA >= 1 && NA <= 128 && NB == 128 && NC == 128 &&
          (ldr % 4) == 0 && !force_generic();
 }
 size_t bilinear_wgrad_batch_ws_bytes(int n_layers, int nrows, int NA, int NB, int NC) {
   const size_t single = bilinear_wgrad_ws_bytes(nrows, NA, NB, NC);
   if (NB != 128 || NC != 128 || NA > 128 || NA < 1 || n_layers > WGB_MAX || n_layers < 1 || nrows <= 0) return single;
   size_t a, b, c, d, e;
-  const size_t batch = wgrad_batch_ws(n_layers, nrows, NA, wgrad_batch_pick(n_layers, nrows, NA, nullptr), &a, &b, &c, &d, &e);
+  size_t batch = wgrad_batch_ws(n_layers, nrows, NA, wgrad_batch_pick(n_layers, nrows, NA, nullptr), &a, &b, &c, &d, &e);
+  const size_t batch_c = wgradc_ws_bytes(n_layers, nrows, NA);     // f16x3c form (wgradc.hip)
+  if (batch_c > batch) batch = batch_c;
   return batch > single ? batch : single;
 }
 // out[l][a,b,c] = sum_n p[l][n,a] q[l][n,b] r[l][n,c] for l < n_layers in ONE launch (f16x3 mode; other modes: one
@@ -2801,6 +2793,8 @@ int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, 
   if (slot < 0 || slot >= n_layers || ((((uintptr_t)q) | ((uintptr_t)r)) & 15) != 0 || nrows <= 0 || nrows > 8000000 ||
       !bilinear_wgrad_batch_fast(n_layers, NA, NB, NC, ldq, ldr))
     return CGAT_ERR_UNSUPPORTED;
+  if (bilinear_mode() == 4)
+    return wgradc_prep(slot, 1, n_layers, &p, ldp, &q, ldq, &r, ldr, nrows, NA, ws, ws_bytes, stream);
   const int np = cdiv(nrows, 32) * 32;
   int rps = 0;
   const int splits = wgrad_batch_pick(n_layers, nrows, NA, &rps);
@@ -2848,6 +2842,8 @@ int bilinear_wgrad_batch_launch(int n_layers, const float* const* p, long ldp, c
                                      max_wgs > 0 && max_wgs < 256 ? max_wgs / cdiv(NA, 2) : 0));
     return CGAT_OK;
   }
+  if (bilinear_mode() == 4)
+    return wgradc_launch(n_layers, p, ldp, q, ldq, r, ldr, out, nrows, NA, ws, ws_bytes, stream, max_wgs, prepared);
   if (max_wgs <= 0 || max_wgs > 256) max_wgs = 256;
   const int npairs = cdiv(NA, 2);
   const int np = cdiv(nrows, 32) * 32;
@@ -2911,10 +2907,12 @@ size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
     size_t bf = wgrad_bf16_ws(nrows, NA, &a, &b, &c, &d);
     size_t f32 = ws_round((size_t)wgrad_splits(nrows, NA) * NA * NB * NC, 4);
     if (f32 > bf) bf = f32;
-    if (NA >= 1 && NA <= 128 && nrows > 0) {   // the f16x3 form: batched kernel with one layer
+    if (NA >= 1 && NA <= 128 && nrows > 0) {   // the f16x3 / f16x3c forms: batched kernels with one layer
       size_t e;
       const size_t one = wgrad_batch_ws(1, nrows, NA, wgrad_batch_pick(1, nrows, NA, nullptr), &a, &b, &c, &d, &e);
       if (one > bf) bf = one;
+      const size_t one_c = wgradc_ws_bytes(1, nrows, NA);
+      if (one_c > bf) bf = one_c;
     }
     return bf;
   }
@@ -2926,8 +2924,9 @@ size_t bilinear_wgrad_ws_bytes(int nrows, int NA, int NB, int NC) {
 int bilinear_wgrad_launch(const float* p, long ldp, const float* q, long ldq, const float* r, long ldr, float* out,
                           int nrows, int NA, int NB, int NC, void* ws, size_t ws_bytes, hipStream_t stream,
                           int force_splits) {
-  if (wgrad_fast(q, ldq, r, ldr, NB, NC) && bilinear_mode() == 2 && nrows > 0 && nrows <= 8000000 && NA <= 128) {
-    // f16x3: the batched, software-pipelined kernel with one layer (row splits fill the chip)
+  if (wgrad_fast(q, ldq, r, ldr, NB, NC) && (bilinear_mode() == 2 || bilinear_mode() == 4) && nrows > 0 &&
+      nrows <= 8000000 && NA <= 128) {
+    // f16x3 / f16x3c: the batched kernels with one layer (row splits fill the chip)
     return bilinear_wgrad_batch_launch(1, &p, ldp, &q, ldq, &r, ldr, &out, nrows, NA, NB, NC, ws, ws_bytes, stream,
                                        force_splits > 0 ? force_splits * cdiv(NA, 2) : 0);
   }
