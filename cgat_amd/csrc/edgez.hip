@@ -26,7 +26,9 @@
 #include "kernels.h"
 #include "mfma_bf16.h"
 
-template <int PASSES, bool ADDS>
+// ZB (the per-edge launch only): Z is stored as bf16 (the "bf16" edge-storage mode, BASELINE configs[4]; ldz counts
+// elements either way).  The logits are formed from the unrounded values.
+template <int PASSES, bool ADDS, bool ZB = false>
 __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict__ e, long lde,
                                                         const int* __restrict__ perm, const uint4* __restrict__ Wq,
                                                         int ncb, const float* __restrict__ Pi,
@@ -281,8 +283,13 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
           }
         }
         // DEEP: unconditional (the allowances count eight stores; clamped rows rewrite identical values)
-        if (DEEP || row_a < E) *reinterpret_cast<float4*>(za + col) = va;
-        if (DEEP || row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
+        if constexpr (ZB) {
+          if (row_a < E) store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)rca * ldz + col, va);
+          if (row_b < E) store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)rcb * ldz + col, vb);
+        } else {
+          if (DEEP || row_a < E) *reinterpret_cast<float4*>(za + col) = va;
+          if (DEEP || row_b < E) *reinterpret_cast<float4*>(zb + col) = vb;
+        }
         if (omax) {   // (kernel argument: uniform) max |stored value|: the per-tensor fp16 scale of the kernels that read it
           omx = fmaxf(fmaxf(omx, fmaxf(fabsf(va.x), fabsf(va.y))), fmaxf(fabsf(va.z), fabsf(va.w)));
           omx = fmaxf(fmaxf(omx, fmaxf(fabsf(vb.x), fabsf(vb.y))), fmaxf(fabsf(vb.z), fabsf(vb.w)));
@@ -642,9 +649,12 @@ size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int act,
-                  float* omax) {
+                  float* omax, int z_bf16) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
+  CGAT_CHECK_ARG(!z_bf16 || (Pj != nullptr && bilinear_mode() != 2 && bilinear_mode() != 3 && bilinear_mode() != 0 &&
+                             act == CGAT_ACT_NONE && !omax),
+                 "edge_z: bf16 storage is the per-edge launch of the six-pass form only");
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
   if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, stream));
   else CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
@@ -656,6 +666,10 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
                      HeadBatch{})
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
+  else if (bilinear_mode() != 3 && z_bf16)
+    hipLaunchKernelGGL((edge_z_kernel<6, true, true>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb,
+                       Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr,
+                       0l, HeadBatch{});
   else if (bilinear_mode() != 3) { if (adds) EZ_GO(6, true); else EZ_GO(6, false); }
   else { if (adds) EZ_GO(3, true); else EZ_GO(3, false); }
 #undef EZ_GO

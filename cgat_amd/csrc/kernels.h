@@ -128,7 +128,7 @@ int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, lo
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
-                  int act = CGAT_ACT_NONE, float* omax = nullptr);
+                  int act = CGAT_ACT_NONE, float* omax = nullptr, int z_bf16 = 0);   // z_bf16: as edge_zx_launch
 int absmax_launch(const float* src, long n, float* out, hipStream_t stream);   // zeroes out[0] first
 int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream);  // folds into out[0]
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void edge_seg_bwd_kernel(const float* __restri
 //   seg_bwd_msg_kernel   step 1: one wave per (segment, head): g_alpha, the message half's sign bits, its share of Gi
 //   seg_bwd_soft_kernel  step 2: softmax backward per (segment, head)
 //   seg_bwd_att_kernel   step 3: the attention half: sign bits, Gi share, partial sums for grad fc_out_A
+template <bool ZB = false>   // ZB: Z is read as bf16 (the "bf16" edge-storage mode; offsets count elements either way)
 __global__ __launch_bounds__(256, 8) void seg_bwd_msg_kernel(const float* __restrict__ Z, const float* __restrict__ alpha,
                                                              const float* __restrict__ gS, const float* __restrict__ gs,
                                                              const int* __restrict__ rowptr, int N, int H,
@@ -471,7 +472,8 @@ __global__ __launch_bounds__(256, 8) void seg_bwd_msg_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int t = tb + u < r1 ? tb + u : r1 - 1;
-        zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + wcol);
+        zv[u] = ZB ? load4_bf16(reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + wcol)
+                   : *reinterpret_cast<const float4*>(Z + (long)t * W2 + wcol);
         al[u] = alpha[(long)t * H + h];
       }
 #pragma unroll
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(256, 8) void seg_bwd_soft_kernel(const float* __res
   }
 }
 
+template <bool ZB = false>
 __global__ __launch_bounds__(256, 8) void seg_bwd_att_kernel(const float* __restrict__ Z, const float* __restrict__ ga,
                                                              const int* __restrict__ rowptr,
                                                              const float* __restrict__ wA_out, int N, int H,
@@ -569,7 +572,8 @@ __global__ __launch_bounds__(256, 8) void seg_bwd_att_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int t = tb + u < r1 ? tb + u : r1 - 1;
-          zv[u] = *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
+          zv[u] = ZB ? load4_bf16(reinterpret_cast<const __bf16*>(Z) + (long)t * W2 + col)
+                     : *reinterpret_cast<const float4*>(Z + (long)t * W2 + col);
           cf[u] = ga[(long)t * H + h];
         }
 #pragma unroll
@@ -648,8 +652,10 @@ static int edge_storage() {
 }
 extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = (mode == 1 || mode == 2) ? mode : 0; }
 extern "C" int32_t cgat_get_edge_storage(void) { return edge_storage(); }
+// (f16x3: the K = 256 per-edge forward and the one-kernel segment backward; the 24-bit modes: the six-pass per-edge forward,
+// the weighted sum and the three-kernel segment backward; the f32 mode has no bf16 storage: cgat_set_edge_storage fails)
 static bool attn_bf16(const AttnDims& d) {
-  return edge_storage() == 1 && bilinear_mode() == 2 && d.C == 128 && d.Ce == 128 && d.Hd % 128 == 0 && d.W2 % 256 == 0 &&
+  return edge_storage() == 1 && bilinear_mode() != 0 && bilinear_mode() != 3 && d.C == 128 && d.Ce == 128 && d.Hd % 128 == 0 && d.W2 % 256 == 0 &&
          d.N > 0 && d.E > 0;
 }
 
@@ -706,13 +712,20 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   // and the attention logits a[t,h] = fc_out_A(leaky(zA)): one fused split-bf16 kernel at the benchmark widths,
   // the generic GEMM + row-dot otherwise (and in the f32 arithmetic mode)
   const bool fused_z = !c.dry && edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Pi, Pj, sv.Z, p->A_out_w);
-  const bool zb = zx && attn_bf16(d);     // Z stored as bf16 (edge-storage mode "bf16")
+  // Z stored as bf16 (edge-storage mode "bf16"): by edge_zx in the f16x3 mode, by the six-pass per-edge kernel otherwise
+  const bool zb = attn_bf16(d) && (zx || (fused_z && bilinear_mode() != 2));
+  if (!c.dry && edge_storage() == 1 && !zb && d.N > 0 && d.E > 0) {
+    cgat_set_error("nodes_attention_forward: edge storage \"bf16\" is set but this layer (C %d, Ce %d, H %d, Hd %d, arithmetic "
+                   "mode %d) has no bf16 form -- refusing to run it in fp32 storage under that label", d.C, d.Ce, d.H, d.Hd,
+                   bilinear_mode());
+    return CGAT_ERR_UNSUPPORTED;
+  }
   if (zx) {
     RUN(edge_zx_launch(e, d.Ce, plan->dst_perm, x, d.C, Wcat + d.C, Wcat + d.C + d.Ce, d.D, Wq, d.W2, Pi, plan->dst_sorted,
                        plan->src_sorted, d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, zb ? 1 : 0));
   } else if (fused_z) {
     RUN(edge_z_launch(e, d.Ce, plan->dst_perm, Wcat + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted,
-                      d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s));
+                      d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, CGAT_ACT_NONE, nullptr, zb ? 1 : 0));
   } else {
     GemmParams g = gemm_params(d.E, d.W2, d.Ce, e, d.Ce, Wcat + d.C, d.D, sv.Z, d.W2);
     g.a_rgather = plan->dst_perm;
@@ -950,8 +963,16 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     have_scales = vec && bilinear_mode() == 2 && d.Ce == 128 && (((uintptr_t)e) & 15) == 0;
     if (have_scales) CGAT_TRY(fill_launch(scales, 0.f, 8, c.s));
     // the forward stored Z as bf16 under exactly this predicate (same tensors, same alignment)
-    zb = attn_bf16(d) && edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
-         edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
+    const bool zb_x = attn_bf16(d) && bilinear_mode() == 2 &&
+                      edge_zx_fast(d.C, d.Ce, d.W2, d.H, d.Hd, d.W2, d.W2, e, x, Gi, sv.Z, p->A_out_w) &&
+                      edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Gi, Gj, Gi, gbcat);
+    const bool zb_6 = attn_bf16(d) && bilinear_mode() != 2 &&
+                      edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Gi, Gj, sv.Z, p->A_out_w);
+    zb = zb_x || zb_6;
+    if (edge_storage() == 1 && !zb) {
+      cgat_set_error("nodes_attention_backward: edge storage \"bf16\" is set but this layer has no bf16 form");
+      return CGAT_ERR_UNSUPPORTED;
+    }
     if (rc_shape)
       CGAT_CHECK_ARG(vec && (((uintptr_t)e) & 15) == 0,
                      "nodes_attention_backward: saved, edge_attr and MH_A.fc_out.weight must be 16-byte aligned at these widths");
@@ -959,19 +980,29 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     float* gzmax = have_scales ? scales : (float*)nullptr;
     // [2] max |Gi|, [3] max |Gj|, [4] max |x|: with them the node-side products run in the fp16 form too (rebuilt path)
     float* gimax = (have_scales && rc_shape) ? scales + 2 : (float*)nullptr;
-    if (zb) {
+    if (zb_6) {
+      CGAT_CHECK_ARG(vec && mask && d.Hd == 256, "nodes_attention_backward: the bf16 edge storage needs the vector form");
+      const long tasks = (long)d.N * d.H;
+      hipLaunchKernelGGL(seg_bwd_msg_kernel<true>, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, c.s, sv.Z, sv.alpha, gS, gs,
+                         plan->dst_rowptr, d.N, d.H, tt, Gi, gzmax, mask, gimax);
+      CGAT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_bwd_soft_kernel, dim3(chunks), dim3(256), 0, c.s, sv.alpha, tt, plan->dst_rowptr, d.N, d.H, ga);
+      CGAT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(seg_bwd_att_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, ga, plan->dst_rowptr, p->A_out_w,
+                         d.N, d.H, Gi, partial, gzmax, mask, gimax);
+    } else if (zb) {
       CGAT_CHECK_ARG(rc_shape && have_scales, "nodes_attention_backward: the bf16 edge storage needs the vector form");
       hipLaunchKernelGGL((edge_seg_bwd_kernel<true, true>), dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,
                          plan->dst_rowptr, p->A_out_w, d.N, d.H, d.Hd, tt, ga, Gi, partial, gzmax, mask, gimax);
     } else if (vec && mask && d.Hd == 256 && seg_bwd_split()) {
       // three small kernels (<= 64 VGPRs: they co-reside with the side stream's dT workgroups); bit-identical results
       const long tasks = (long)d.N * d.H;
-      hipLaunchKernelGGL(seg_bwd_msg_kernel, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, c.s, sv.Z, sv.alpha, gS, gs,
+      hipLaunchKernelGGL(seg_bwd_msg_kernel<false>, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, c.s, sv.Z, sv.alpha, gS, gs,
                          plan->dst_rowptr, d.N, d.H, tt, Gi, gzmax, mask, gimax);
       CGAT_LAUNCH_CHECK();
       hipLaunchKernelGGL(seg_bwd_soft_kernel, dim3(chunks), dim3(256), 0, c.s, sv.alpha, tt, plan->dst_rowptr, d.N, d.H, ga);
       CGAT_LAUNCH_CHECK();
-      hipLaunchKernelGGL(seg_bwd_att_kernel, dim3(chunks), dim3(256), shm, c.s, sv.Z, ga, plan->dst_rowptr, p->A_out_w, d.N,
+      hipLaunchKernelGGL(seg_bwd_att_kernel<false>, dim3(chunks), dim3(256), shm, c.s, sv.Z, ga, plan->dst_rowptr, p->A_out_w, d.N,
                          d.H, Gi, partial, gzmax, mask, gimax);
     } else if (vec)
       hipLaunchKernelGGL(edge_seg_bwd_kernel<true>, dim3(chunks), dim3(256), shm, c.s, sv.Z, gZ, gzb, sv.alpha, gS, gs,

@@ -1033,7 +1033,9 @@ def get_bilinear_mode():
 def set_edge_storage(mode):
     """Storage of the per-edge intermediates Z / gZ of the fused scalar-attention path: "f32" (default) or "bf16"
     (BASELINE configs[4]'s "bf16 activations": half the HBM bytes of the edge phase, tolerance 1e-2; logits, softmax
-    statistics and all products unchanged).  Takes effect at C = Ce = 128 in the f16x3 arithmetic mode."""
+    statistics and all products unchanged).  Exists at C = Ce = 128 in every split arithmetic mode (f16x3c, bf16x6, f16x3);
+    a scalar-attention layer without a bf16 form (other widths, the f32 mode) raises instead of silently running in fp32
+    storage."""
     lib.cgat_set_edge_storage({"f32": 0, "bf16": 1, "f32+gz": 2}[mode])
 
 

@@ -367,7 +367,10 @@ int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const 
  *   0 = fp32 Z (default);
  *   1 = bf16 Z ("bf16 activations" of BASELINE configs[4]): halves the bytes of the Z-sized passes; attention logits,
  *       softmax statistics, sums and every matrix product stay as they are (fp32 accumulation); tolerance of that mode
- *       1e-2 max-norm relative.  Effective at C = Ce = 128 in the f16x3 arithmetic mode, ignored elsewhere;
+ *       1e-2 max-norm relative.  Exists for the scalar-attention node layer at C = Ce = 128, Hd a multiple of 128, in every
+ *       split arithmetic mode (f16x3c, bf16x6, f16x3); cgat_nodes_attention_forward / _backward return
+ *       CGAT_ERR_UNSUPPORTED for a layer without that form (other widths, the f32 mode) instead of running it in fp32
+ *       storage under the bf16 label (round 4's library ignored the switch there);
  *   2 = fp32 Z with gZ stored in backward (round 1's path, 6 KB more workspace per edge): the A/B reference of the tests.
  * A backward call must run under the mode its forward ran under.  Env CGAT_EDGE_STORAGE = bf16 | f32+gz sets the start
  * value. */

@@ -216,9 +216,43 @@ def test_config5_bf16_edge_storage_vs_oracle():
         err = float((a.double().cpu() - r).abs().max())
         worst = max(worst, err / max(float(r.abs().max()), 1e-3 * scale))
     assert worst <= 1e-2, worst
-    if P.get_bilinear_mode() == "f16x3":                # (the other arithmetic modes ignore the storage switch)
-        assert rel(y16, y32.double().cpu()) > 1e-6      # the mode is on
+    assert rel(y16, y32.double().cpu()) > 1e-6          # the mode is on, in EVERY split arithmetic mode (round 5)
     assert rel(y32, yo.detach()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_edge_storage_is_never_silently_ignored():
+    """Round 4's library ignored the storage switch outside the f16x3 mode and ran fp32 storage under the bf16 label.  Now
+    the bf16 form exists in every split mode, and a scalar-attention layer WITHOUT a bf16 form -- any layer in the f32
+    arithmetic mode, or one at other widths -- raises instead (CGAT_ERR_UNSUPPORTED from cgat_nodes_attention_forward)."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    b, _ = P.synthetic_batch(4, 10, 6, seed=5)
+    g = torch.Generator().manual_seed(6)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    ei = b.edge_index.to(dev)
+
+    def layer_out(C):
+        torch.manual_seed(3)
+        layer = P.GATConvNodes(C, C, C, 3, concat=True).to(dev)
+        x, e, x0 = (torch.randn(n, C, generator=g).to(dev) for n in (N, E, N))
+        return layer(x, ei, e, x0)
+    mode0 = P.get_bilinear_mode()
+    P.set_edge_storage("bf16")
+    try:
+        for mode in ("f16x3c", "bf16x6", "f16x3"):
+            P.set_bilinear_mode(mode)
+            assert torch.isfinite(layer_out(128)).all()
+        P.set_bilinear_mode("f32")
+        with pytest.raises(RuntimeError, match="bf16"):
+            layer_out(128)
+        P.set_bilinear_mode(mode0)
+        with pytest.raises(RuntimeError, match="bf16"):
+            layer_out(64)                               # no bf16 form at this width
+    finally:
+        P.set_edge_storage("f32")
+        P.set_bilinear_mode(mode0)
+    assert torch.isfinite(layer_out(64)).all()
 
 
 @pytest.mark.gpu
@@ -251,6 +285,8 @@ def test_bf16_edge_storage_at_1m_edges_matches_fp32_storage():
     for k, (u, v) in enumerate(zip(a, c)):
         den = float(u.abs().max()) if k == 0 else max(float(u.abs().max()), 1e-2 * scale)
         assert float((u - v).abs().max()) <= 2e-2 * den, (k, float((u - v).abs().max()), den)
+    # ... and the two runs are NOT the same computation (in round 4's default mode this test compared a run with itself)
+    assert float((a[0] - c[0]).abs().max()) > 1e-6 * float(a[0].abs().max())
 
 
 @pytest.mark.gpu
