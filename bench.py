@@ -810,6 +810,7 @@ def main():
         if (ops.overlap_enabled() and not args.no_exclusive_pass) else ()
     prof_x = {}
     if concurrent:
+        raw_overlap = ops.get_overlap_wgrad()
         ops.set_overlap_wgrad(False)
         ops.prof_reset()
         ops.prof_enable(True)
@@ -818,7 +819,7 @@ def main():
         _fence(world)
         ops.prof_enable(False)
         prof_x = {t: ops.prof_get(t) for t in concurrent}
-        ops.set_overlap_wgrad(True)
+        ops.set_overlap_wgrad(raw_overlap)
     per_rank = None
     if world > 1:
         # every rank's own timed-region duration (gathered: the SCALE line is self-checking), `value` uses the maximum

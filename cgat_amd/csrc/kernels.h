@@ -69,7 +69,7 @@ size_t gemm_ws_bytes(const GemmParams& p);
 // out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T3[a,b,c], with T = bilinear_prepare_T(T3 source):
 // a permuted copy whose columns are interleaved for the MFMA kernel when NB == NC == 128.
 bool bilinear_T_interleaved(int NB, int NC);
-int bilinear_mode();               // 0 f32 MFMA, 6 / 3: split-bf16 passes
+int bilinear_mode();               // 0 f32 MFMA, 6 / 3: split-bf16 passes, 2: f16x3 (two fp16 planes), 4: f16x3c (h + l + t)
 void bilinear_set_mode(int m);
 size_t bilinear_T_floats(int NA, int NB, int NC);  // workspace floats of the prepared T
 size_t bilinear_T_floats_max(int NA, int NB, int NC);   // ... in whichever arithmetic mode needs most (size queries)

@@ -1285,7 +1285,7 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
   if (batch_w) {   // every dense-layer weight of the pass, prepared in one launch (forward orientation [out][in])
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], W, 1);
-      c.wprep_add(p->layer[l].head_b, W, 1);
+      if (bilinear_mode() == 2) c.wprep_add(p->layer[l].head_b, W, 1);   // read by linear128_launch in that mode only
       c.wprep_add(p->layer[l].head_w + WW * W, W, 1);
     }
     CGAT_TRY(c.wprep_run());
@@ -1425,7 +1425,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   if (batch_w) {   // the same weights in the transposed orientation (g_in = g_out W)
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], 1, W);
-      c.wprep_add(p->layer[l].head_b, 1, W);
+      if (bilinear_mode() == 2) c.wprep_add(p->layer[l].head_b, 1, W);
       c.wprep_add(p->layer[l].head_w + WW * W, 1, W);
     }
     CGAT_TRY(c.wprep_run());

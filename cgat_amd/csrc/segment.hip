@@ -669,6 +669,7 @@ int seg_attnpool_fwd_launch(const float* a, int aF, const float* mult, const flo
                             float* out_lo) {
   if (S <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(attnpool_ok(aF, F, ldm, a, m, out), "segment_attention_pool: unsupported shape (F=%d, aF=%d)", F, aF);
+  CGAT_CHECK_ARG((((uintptr_t)out_lo) & 15) == 0, "segment_attention_pool: out_lo must be 16-byte aligned");
   const int fw = F / aF;
   CGAT_PROF("seg_attnpool_fwd", s);
   if (fw == 1)

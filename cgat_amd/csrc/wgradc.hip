@@ -34,9 +34,10 @@ typedef __bf16 bf16x32 __attribute__((ext_vector_type(32)));
 #define WGC_PL_B 32768                      // fp16 planes of a chunk: [k-step 4][plane h,l][column block 4][lane 64][16 B]
 #define WGC_IM_B 18432                      // 6-bit images: [image l6,h6,t6][column block 4][lane 64 x 16 B | lane 64 x 8 B]
 #define WGC_RS_B (WGC_PL_B + WGC_IM_B)      // the r stream of a chunk: 50 pieces of 1 KB
-#define WGC_SLOT_B (WGC_RS_B + 512)         // + the two staged p rows
+#define WGC_P_B 2048                        // the two staged p rows, one 1-KB LDS-DMA piece each (256 B used)
+#define WGC_SLOT_B (WGC_P_B + WGC_RS_B)     // ring slot: [p rows][r stream]
 #define WGC_SLOTS 3
-#define WGC_NDMA 13                         // LDS-DMA instructions per issuing wave and chunk (4 x 13 = 50 + 2)
+#define WGC_NDMA0 7                         // LDS-DMA pieces per chunk a grp-0 wave issues (of 13 per wb; grp 1: the rest)
 #ifndef WGC_PRIO
 #define WGC_PRIO 2
 #endif
@@ -241,30 +242,40 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
       inv_all = ipq * ir;
     }
     if (nchunks > 0) {
-      // chunk ci -> ring slot ci % 3.  Issued by the four grp-0 waves only, 13 pieces each (piece k = wb + 4 m: 0..49 the
-      // r stream, 50 / 51 the p rows of a0 / a0 + 1), while they wait for their q loads anyway: a grp-1 wave starts its
-      // matrix phase the moment the barrier opens.  The chunk index is clamped: the last iteration re-loads the last
-      // chunk into a slot nobody reads, which keeps the vmcnt arithmetic uniform.
-#define WGC_DMA(ci_)                                                                         \
+      // chunk ci -> ring slot ci % 3, 52 pieces: 0..49 the r stream, 50 / 51 the p rows of a0 / a0 + 1; wave wb of the
+      // issuing group takes the 13 pieces k = wb + 4 m.  In the loop the grp-1 waves issue them ONE PER TWO GROUPS inside
+      // their matrix phase (WGC_STEP): issued as a burst by the grp-0 waves before their split, the 13 pieces cost those
+      // waves ~800 cycles of their critical path, and the burst of 52 KB landing in LDS beside the fragment reads of the
+      // partner's matrix phase and the p reads of the split stretched BOTH (any two of the three cost nothing, all three
+      // +0.45 ms per launch: tools/wgrad_ablate.sh, round 5).  The chunk index is clamped: the last iterations re-load
+      // the last chunk into a slot nobody reads.
+#define WGC_DMA_PIECE(m_, sl_, rb_, cc_, vo16_, vo4_)   /* branch-free: every piece is one 1-KB global_load_lds_dwordx4 */ \
   if (!(WGC_ABL & 8)) {                                                                      \
+    /* the bases are laundered so that each piece's address arithmetic happens HERE: hoisted to the top of the phase   \
+       (13 pieces x 64-bit source + LDS address) it spilled 38 SGPRs into vector registers and 159 of those to scratch */ \
+    const unsigned char* rbl_ = (rb_);                                                       \
+    unsigned sll_ = (sl_);                                                                   \
+    asm volatile("" : "+s"(rbl_), "+s"(sll_));                                               \
+    const int k_ = wb + 4 * (m_);                                                            \
+    if ((m_) < 12) {                                                                         \
+      glds_b128(rbl_ + k_ * 1024, vo16_, (unsigned)__builtin_amdgcn_readfirstlane((int)(sll_ + WGC_P_B + k_ * 1024))); \
+    } else {   /* k_ = 48, 49: r stream; 50, 51: the p row of a0 + k_ - 50 (256 B, fetched four times over) */     \
+      const bool isr_ = wb < 2;                                                              \
+      const unsigned char* src_ = isr_ ? rbl_ + k_ * 1024                                    \
+                                       : reinterpret_cast<const unsigned char*>(pT) + ((long)(wb - 2) * rows_pad + nbeg + (long)(cc_) * WGC_ROWS) * 4; \
+      const unsigned dst_ = isr_ ? sll_ + WGC_P_B + k_ * 1024 : sll_ + (wb - 2) * 1024;      \
+      glds_b128(src_, isr_ ? (vo16_) : ((vo16_) & 255u), (unsigned)__builtin_amdgcn_readfirstlane((int)dst_)); \
+    }                                                                                        \
+  }
+#define WGC_DMA(ci_, M0_, M1_)   /* pieces m in [M0_, M1_) of this wave */                   \
+  {                                                                                          \
     const int cc_ = (ci_) < nchunks ? (ci_) : nchunks - 1;                                   \
     const unsigned sl_ = sbase + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B;                 \
     int ln_ = lane;                                                                          \
     asm volatile("" : "+v"(ln_));   /* per-lane offsets are re-derived at every use: nothing lane-dependent stays live */ \
     const unsigned voff16 = (unsigned)ln_ * 16, voff4 = (unsigned)ln_ * 4;                   \
     const unsigned char* rb_ = Rs + (long)cc_ * WGC_RS_B;                                    \
-    _Pragma("unroll") for (int m_ = 0; m_ < 12; ++m_) {                                      \
-      const int k_ = wb + 4 * m_;                                                            \
-      glds_b128(rb_ + k_ * 1024, voff16, (unsigned)__builtin_amdgcn_readfirstlane((int)(sl_ + k_ * 1024))); \
-    }                                                                                        \
-    if (wb < 2) {                                                                            \
-      const int k_ = 48 + wb;                                                                \
-      glds_b128(rb_ + k_ * 1024, voff16, (unsigned)__builtin_amdgcn_readfirstlane((int)(sl_ + k_ * 1024)));                                   \
-    } else {                                                                                 \
-      const int g_ = wb - 2;                                                                 \
-      glds_b32(pT + ((long)g_ * rows_pad + nbeg + (long)cc_ * WGC_ROWS) * 4, voff4,                \
-               (unsigned)__builtin_amdgcn_readfirstlane((int)(sl_ + WGC_RS_B + g_ * 256))); \
-    }                                                                                        \
+    _Pragma("unroll") for (int m_ = (M0_); m_ < (M1_); ++m_) WGC_DMA_PIECE(m_, sl_, rb_, cc_, voff16, voff4) \
   }
       unsigned H[16], L[16];           // fp16 planes of the wave's products: the A fragments of the four k-steps
       unsigned A6l[6], A6h[6], A6t[6]; // their 6-bit images
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
     AFTER_LOADS_                                                                                                  \
     asm volatile("" : "+v"(qv_[0]), "+v"(qv_[1]), "+v"(qv_[2]), "+v"(qv_[3]), "+v"(qv_[4]), "+v"(qv_[5]),         \
                       "+v"(qv_[6]), "+v"(qv_[7]));   /* the values exist behind the counted wait, not before */   \
-    const unsigned char* ps_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + WGC_RS_B + grp * 256 + (lq_ >> 5) * 32; \
+    const unsigned char* ps_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + grp * 1024 + (lq_ >> 5) * 32;         \
     unsigned T_[16];                                                                                              \
     _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                            \
       if (WGC_ABL & 2) { T_[2 * j_] = 0; T_[2 * j_ + 1] = 0; continue; }                                          \
@@ -376,12 +387,14 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
     WGC_EXECG(g_, XA_, YA_, 0)                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if constexpr ((g_) + 3 < 28) WGC_LOADG((g_) + 3 < 28 ? (g_) + 3 : 0, XC_, YC_)                                 \
+    if constexpr (host_ && ((g_) & 1) && (g_) < 26) WGC_DMA_PIECE((g_) >> 1, dsl_, drb_, dcc_, dvo16_, dvo4_)      \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     WGC_EXECG(g_, XA_, YA_, 1)                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
   }
-#define WGC_MFMA(ci_)                                                                                             \
+#define WGC_MFMA(ci_, HOST_, DCI_)   /* HOST_ 1: the LDS-DMA of chunk DCI_ is issued along the way */              \
   {                                                                                                               \
+    constexpr bool host_ = HOST_;                                                                                 \
     if (((ci_) & 7) == 0 && (ci_) > 0) {                                                                          \
       const float sg_ = ((((ci_) >> 3) - 1) & 1) ? -1.f : 1.f;                                                    \
       _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_)                                                         \
@@ -392,8 +405,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
     }                                                                                                             \
     int lm_ = lane;                                                                                               \
     asm volatile("" : "+v"(lm_));                                                                                 \
-    const unsigned char* sl_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + lm_ * 16;                      \
-    const unsigned char* sl8_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + lm_ * 8;                      \
+    const unsigned char* sl_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + WGC_P_B + lm_ * 16;            \
+    const unsigned char* sl8_ = smem + (unsigned)((ci_) % WGC_SLOTS) * WGC_SLOT_B + WGC_P_B + lm_ * 8;            \
+    const int dcc_ = (DCI_) < nchunks ? (DCI_) : nchunks - 1;                                                     \
+    const unsigned dsl_ = sbase + (unsigned)((DCI_) % WGC_SLOTS) * WGC_SLOT_B;                                    \
+    const unsigned char* drb_ = Rs + (long)dcc_ * WGC_RS_B;                                                       \
+    const unsigned dvo16_ = (unsigned)lm_ * 16, dvo4_ = (unsigned)lm_ * 4;                                        \
     uint4 X0_ = {}, Y0_ = {}, X1_ = {}, Y1_ = {}, X2_ = {}, Y2_ = {}, X3_ = {}, Y3_ = {};                         \
     __builtin_amdgcn_s_setprio(WGC_PRIO);   /* the wave in its matrix phase goes first at the SIMD's issue port */ \
     WGC_LOADG(0, X0_, Y0_)                                                                                        \
@@ -412,7 +429,9 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
     __builtin_amdgcn_s_setprio(0);                                                                                \
   }
 
-      if (grp == 0) WGC_DMA(0);
+      // chunks 0 and 1 as bursts (an `else` branch for the first iteration inside the loop made the compiler peel it and
+      // spill 150 registers)
+      if (grp == 0) WGC_DMA(0, 0, 13) else WGC_DMA(1, 0, 13)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -428,14 +447,14 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
             // the wave's 8-KB block (result unused; the register stays reserved until the wait that ends the iteration):
             // q is consumed where it lands, so without this every workgroup of an XCD -- they share a stream and run in
             // lockstep -- would sit out the same HBM miss in every chunk
-            WGC_SPLIT(c, WGC_DMA(c + 1);
+            WGC_SPLIT(c, WGC_DMA(c + 1, 0, WGC_NDMA0)
                       {
                         const char* nb_ = qF + (long)(c + 1 < nchunks ? c + 1 : c) * 32768;
                         asm volatile("global_load_dword %0, %1, %2" : "=v"(pf) : "v"((unsigned)lq_ * 128u), "s"(nb_) : "memory");
                       }
-                      wait_vmcnt<(WGC_ABL & 8) ? 1 : WGC_NDMA + 1>(); WGC_TS(1))
+                      wait_vmcnt<(WGC_ABL & 8) ? 1 : WGC_NDMA0 + 1>(); WGC_TS(1))
             WGC_TS(2)
-            WGC_MFMA(c)
+            WGC_MFMA(c, 0, 0)
             WGC_TS(3)
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -449,9 +468,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
 #pragma clang loop unroll(disable)
         for (int c = 0; c <= nchunks; ++c) {
           WGC_TS(0)
-          if (c > 0) WGC_MFMA(c - 1)
+          if (c > 0) WGC_MFMA(c - 1, 0, 0)
           WGC_TS(1)
-          if (c < nchunks) WGC_SPLIT(c, wait_vmcnt<0>(); WGC_TS(2))
+          if (c < nchunks) WGC_SPLIT(c, WGC_DMA(c + 1, WGC_NDMA0, 13)   /* (iteration 0 repeats part of the prologue's chunk 1: harmless) */
+                                     wait_vmcnt<(WGC_ABL & 8) ? 0 : 13 - WGC_NDMA0>(); WGC_TS(2))
           WGC_TS(3)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           WGC_TS(4)
@@ -461,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
         }
       }
 #undef WGC_DMA
+#undef WGC_DMA_PIECE
 #undef WGC_SPLIT
 #undef WGC_MFMA
 #undef WGC_STEP

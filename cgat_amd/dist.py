@@ -6,6 +6,7 @@ gradient mean after backward, what Lightning's strategy='ddp' does in the refere
 RCCL over xGMI on MI355X, "gloo" in the CPU tests), launched from autograd hooks as soon as a
 bucket's gradients exist so that it overlaps the rest of backward.
 """
+import collections
 import contextlib
 import os
 
@@ -95,7 +96,11 @@ class GradientAverager:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._cold = frozenset()
         self._last_cold = None                         # the previous step's global cold set (None: no step observed yet)
-        self._viol = None                              # frozen mode: (flag tensor, pinned copy, event) of the last step
+        # frozen mode: one entry (step, flag tensor, pinned copy, event) per step, oldest first; an entry is read -- blocking on
+        # its event -- exactly VIOL_LAG steps after it was made, so every rank reads step k's (global) flag in the same finish()
+        self._viol_q = collections.deque()
+        self._viol_step = 0
+        self._viol_sticky = None                       # device tensor: the last global flag (a violation stays visible)
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "cold_reduced": 0, "cold_skipped": 0,
                       "bytes_reduced": 0, "rebuilds": 0}
         self._layout(preserve=False)
@@ -218,28 +223,37 @@ class GradientAverager:
             self._frozen = True
         self._reset()
 
+    VIOL_LAG = 2   # steps between a flag's all-reduce and the finish() that reads it (its event is long complete by then)
+
     def _finish_frozen(self):
         """static_graph after the cold set froze: stream-ordered waits only, no collective on the bitmap, no host sync.
 
         A cold parameter that receives a gradient on SOME rank violates the contract.  Raising on that rank alone would
         leave the others waiting in their next collective, so the violation travels: every step all-reduces one flag
-        (4 bytes, asynchronous, stream-ordered) and copies the sum to pinned memory behind an event; the NEXT finish()
-        looks at it without blocking (event.query()) and every rank raises together -- one step late, but
-        consistently."""
+        (8 bytes, asynchronous, stream-ordered; the flag also carries the previous step's global result, so a violation
+        stays visible) and copies the sum to pinned memory behind an event.  The entries form a FIFO -- none is ever
+        overwritten -- and the entry of step k is read in the finish() of step k + VIOL_LAG ON EVERY RANK (blocking on an
+        event that is two steps old, i.e. for free): the value is global, the step is fixed, so all ranks raise in the
+        same call and none is left waiting in a collective.  (Round 4 looked at a single slot with event.query(): a
+        not-yet-ready flag was overwritten by the next step's, and readiness differed between ranks.)"""
         self._check_violation()
         local = any(self._used[i] for i in self._cold)
         dev = self.flat[0].device if self.flat else torch.device("cpu")
         flag = torch.full((1,), 1 if local else 0, dtype=torch.int64, device=dev)
+        if self._viol_sticky is not None:
+            flag = torch.maximum(flag, (self._viol_sticky > 0).to(torch.int64))
         work = dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         work.wait()                                    # stream-ordered on GPU backends
+        self._viol_sticky = flag
         if dev.type == "cuda":
             host = torch.empty(1, dtype=torch.int64, pin_memory=True)
             host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._viol = (flag, host, ev)
+            self._viol_q.append((self._viol_step, flag, host, ev))
         else:
-            self._viol = (flag, flag, None)
+            self._viol_q.append((self._viol_step, flag, flag, None))
+        self._viol_step += 1
         inv = 1.0 / self.world
         for bi in range(self.n_hot):
             self._works[bi].wait()
@@ -251,24 +265,23 @@ class GradientAverager:
             p.grad = None if i in self._cold else self._view[id(p)]
         self._reset()
 
-    def _check_violation(self, block=False):
-        """Frozen mode: raise (on every rank alike) if some rank saw a gradient on a cold parameter in an earlier step."""
-        if self._viol is None:
-            return
-        flag, host, ev = self._viol
-        if ev is not None:
-            if block:
+    def _check_violation(self, drain=False):
+        """Frozen mode: raise (on every rank in the same call) if some rank saw a gradient on a cold parameter VIOL_LAG
+        steps ago (drain: in any step still queued)."""
+        bad = False
+        while self._viol_q and (drain or self._viol_q[0][0] <= self._viol_step - self.VIOL_LAG):
+            _, _, host, ev = self._viol_q.popleft()
+            if ev is not None:
                 ev.synchronize()
-            elif not ev.query():
-                return                                 # not there yet: look again at the next step
-        self._viol = None
-        if int(host[0]) > 0:
+            bad = bad or int(host[0]) > 0
+        if bad:
+            self._viol_q.clear()
             raise RuntimeError("GradientAverager(static_graph=True): a parameter that was unused on every rank when the "
                                "graph froze received a gradient on some rank; construct the averager with "
                                "static_graph=False")
 
     def close(self):
-        self._check_violation(block=True)
+        self._check_violation(drain=True)
         for h in self._handles:
             h.remove()
         self._handles = []

@@ -325,6 +325,11 @@ def set_overlap_wgrad(flag):
     _overlap_wgrad = None if flag is None else bool(flag)
 
 
+def get_overlap_wgrad():
+    """The raw setting (None = decided per arithmetic mode): what a caller that changes it temporarily must restore."""
+    return _overlap_wgrad
+
+
 def overlap_enabled():
     if _overlap_wgrad is None:
         return get_bilinear_mode() == "f16x3"
@@ -921,7 +926,9 @@ class AttentionPoolFn(torch.autograd.Function):
         out = torch.empty(S, F, dtype=torch.float32, device=dev)
         mx = torch.empty(S, aF, dtype=torch.float32, device=dev)
         inv = torch.empty(S, aF, dtype=torch.float32, device=dev)
-        out_lo = torch.empty(S, F, dtype=torch.float32, device=dev)   # low part of the fp64 sum: backward centres on out + out_lo
+        # low part of the fp64 sum: backward centres on out + out_lo (not needed, hence not computed, without a backward)
+        need_lo = any(ctx.needs_input_grad[:3])
+        out_lo = torch.empty(S, F, dtype=torch.float32, device=dev) if need_lo else None
         with torch.cuda.device(dev):
             check(lib.cgat_segment_attention_pool_forward(_ptr(a), aF, _ptr(mu), _ptr(m), F, _ptr(rowptr), _ptr(perm), S, F,
                                                           eps, _ptr(out), _ptr(mx), _ptr(inv), _ptr(out_lo), _stream()),

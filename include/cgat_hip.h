@@ -315,7 +315,8 @@ int cgat_segment_attention_pool_backward(const float* a, int32_t aF, const float
                                          const float* inv, const float* out_lo, const float* g_out, float* g_a, float* g_m,
                                          int64_t ldgm, float* g_mult, void* stream);
 
-/* A chain of up to 5 dense layers of width 128 in ONE launch (f16x3 arithmetic mode; CGAT_ERR_UNSUPPORTED otherwise):
+/* A chain of up to 5 dense layers of width 128 in ONE launch (the split arithmetic modes f16x3, f16x3c, bf16x6;
+ * CGAT_ERR_UNSUPPORTED in the f32 mode; the workspace holds one prepared weight image of 24576 floats per layer):
  *   r_0 = x                      (times act'(in_dact) if in_dact != NULL; stored to in_store if != NULL)
  *   r_(l+1) = act_l(r_l W_l^T + bias_l) (+ resid_l) (* dact_type_l'(dact_l)),   W_l(o,k) = W[o*w_so + k*w_sk]
  * every r_(l+1) is written to out_l when out_l != NULL (+= when accumulate).  Forward of the hypernetwork trunks

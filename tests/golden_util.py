@@ -15,12 +15,12 @@ _cache = {}
 def floor_open(ref_max, case_scale):
     """Is the zero-gradient floor `1e-6 * case scale` open to this tensor?  Only to numerically zero gradients (|fp64
     reference| <= 1e-7 of the case's largest gradient: below fp32's resolution of the case) -- except in the DIAGNOSTIC
-    arithmetic mode `f32` (CGAT_BILINEAR_MODE=f32: f32-input MFMA / plain fp32 chains, never a default and not what any
+    arithmetic mode `f32` (set_bilinear_mode("f32") / CGAT_BILINEAR_MODE=f32: f32-input MFMA / plain fp32 chains, never a default and not what any
     number is quoted in), which keeps round 3's criterion (floor open to every tensor): its accumulators carry the
     un-alternated rounding bias the split modes cancel, and four cancellation-heavy tensors of the
     sin-filled fixtures sit at 1.0-2.0e-4 of their value there."""
-    import os
-    return ref_max <= 1e-7 * case_scale or os.environ.get("CGAT_BILINEAR_MODE", "") == "f32"
+    from cgat_amd import ops                            # the arithmetic mode the library is actually in (ADVICE r4), not the
+    return ref_max <= 1e-7 * case_scale or ops.get_bilinear_mode() == "f32"   # environment variable it started from
 
 def load(fname):
     if fname not in _cache:

@@ -234,21 +234,19 @@ def _static_worker(rank, world, port, out):
     want_w = (torch.arange(12, dtype=torch.float32).reshape(2, 6).sum(0) * 1.5).expand(4, 6)   # mean of ranks 1x and 2x
     ok = bool(torch.allclose(lin.weight.grad, want_w)) and dead.grad is None
     # a cold parameter receives a gradient on rank 1 ONLY: the violation must surface on BOTH ranks (a rank raising
-    # alone would leave the other one waiting in its next collective), one finish() later
-    raised, early = False, False
-    avg.zero_grad()
-    try:
-        (lin(x).sum() + (dead.sum() if rank == 1 else 0.0)).backward()
-        avg.finish()
-    except RuntimeError:
-        early = True
-    avg.zero_grad()
-    try:
-        lin(x).sum().backward()
-        avg.finish()
-    except RuntimeError as ex:
-        raised = "static_graph" in str(ex)
-    out.put((rank, frozen, ok, raised and not early))
+    # alone would leave the other one waiting in its next collective) and in the SAME finish() on both: the one
+    # VIOL_LAG = 2 steps after the violation (every flag is queued and read at a fixed distance, none is overwritten)
+    raised_at = []
+    for it in range(4):
+        avg.zero_grad()
+        try:
+            (lin(x).sum() + (dead.sum() if (rank == 1 and it == 0) else 0.0)).backward()
+            avg.finish()
+        except RuntimeError as ex:
+            if "static_graph" in str(ex):
+                raised_at.append(it)
+            break
+    out.put((rank, frozen, ok, raised_at == [GradientAverager.VIOL_LAG]))
     dist.all_reduce = real
     dist.barrier()
     dist.destroy_process_group()

@@ -493,7 +493,7 @@ def test_determinism_bitwise(overlap):
     weight-gradient contractions on the side stream (default) and in serial order."""
     import cgat_amd as P
     from cgat_amd import ops
-    was = ops.overlap_enabled()
+    was = ops.get_overlap_wgrad()                       # the raw tri-state, so that the per-mode default survives (ADVICE r4)
     ops.set_overlap_wgrad(overlap)
     try:
         _determinism_body(P)
@@ -558,7 +558,7 @@ def test_side_stream_equals_serial():
     N, E = b.num_nodes, b.edge_index.shape[1]
     x, e, x0 = (torch.randn(s, 128, generator=g).to(dev) for s in (N, E, N))
     ei = b.edge_index.to(dev)
-    was = ops.overlap_enabled()
+    was = ops.get_overlap_wgrad()                       # the raw tri-state, so that the per-mode default survives
     res = {}
     try:
         for mode in (True, False):
