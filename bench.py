@@ -867,11 +867,14 @@ def main():
         flops_per_layer = 2.0 * N * C_FEA ** 3
         kernels = {"bilinear_wgrad": "bilinear_wgrad128_f16p_kernel", "bilinear_dual": "bilinear_rows128_dual_kernel",
                    "bilinear_rows": "bilinear_rows128_ring16_kernel"}
-        layers_per_launch = {"bilinear_wgrad": 4, "bilinear_dual": 1, "bilinear_rows": 1}   # f16x3: one batched dT launch
+        # contractions of each kind per STEP (4 predicted layers; in closed chunks the forward runs twice: once in the
+        # forward pass, once as the backward's per-chunk recomputation).  Flop per LAUNCH = flop per step / launches per
+        # step, whatever the rows of a launch are (a chunk's share, one layer or the four batched ones): round 4 multiplied
+        # a per-chunk launch by the whole batch's rows and printed a fraction of 4.3
+        contractions_per_step = {"bilinear_wgrad": 4, "bilinear_dual": 4, "bilinear_rows": 8 if stress else 4}
         kpasses = {}                                       # matrix-core pass-equivalents per product, per kernel
         if mode == "f32":
             kernels = {"bilinear_wgrad": "bilinear_wgrad128_kernel", "bilinear_rows": "bilinear_rows128_kernel"}
-            layers_per_launch["bilinear_wgrad"] = 1
             peak, passes = MFMA_F32_PEAK_TFLOPS, 1
             note = "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32"
         elif mode == "f16x3":
@@ -887,11 +890,11 @@ def main():
             # the form; the others run their six-pass bf16 form
             kernels["bilinear_rows"] = "bilinear_rows128_ring16c_kernel"
             kernels["bilinear_dual"] = "bilinear_rows128_dualc_kernel"
+            kernels["bilinear_wgrad"] = "bilinear_wgrad128_f16c_kernel"      # round 5: one launch for the four layers
             F16C = getattr(P.ops, "F16C_KERNELS", ("bilinear_rows", "bilinear_dual"))
             kpasses = {t: (3.75 if t in F16C else 6) for t in kernels}
             if "bilinear_wgrad" not in F16C:
                 kernels["bilinear_wgrad"] = "bilinear_wgrad128_bf16_kernel"
-                layers_per_launch["bilinear_wgrad"] = 1
             passes = 3.75
             peak = MFMA_BF16_PEAK_TFLOPS / passes
             note = ("24-bit operands: every fp32 operand scaled by a power of two and split EXACTLY into h + l + t (two fp16 "
@@ -903,7 +906,6 @@ def main():
                     "fp64 at or below the six-pass bf16 split's and the f32-input MFMA's (tools/f16x3c_probe.hip)")
         else:
             kernels["bilinear_wgrad"] = "bilinear_wgrad128_bf16_kernel"
-            layers_per_launch["bilinear_wgrad"] = 1
             passes = 6 if mode == "bf16x6" else 3
             peak = MFMA_BF16_PEAK_TFLOPS / passes
             note = (f"fp32 operands split into 3 bf16 pieces, {passes} v_mfma_f32_*_bf16 passes per product, fp32 "
@@ -923,7 +925,7 @@ def main():
             if not n_t:
                 continue
             avg_ms = ms_t / n_t
-            fl = flops_per_layer * layers_per_launch[tag]
+            fl = flops_per_layer * contractions_per_step[tag] / (n_t / args.steps)
             ach = fl / (avg_ms * 1e-3) / 1e12
             kpeak = MFMA_BF16_PEAK_TFLOPS / kpasses[tag] if tag in kpasses else peak
             per_kernel[tag] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": round(kpeak, 1),
@@ -967,7 +969,7 @@ def main():
         # f16x3: the per-edge forward kernel computes the x_j projection itself (edge_zx_kernel): Z written, e and
         # x[src] rows read, Pi rows once; other modes: Z written, Pj gathered (W2b per edge), e read, Pi rows once
         W2f = 2 * HEADS * 256 * 4                          # per-node rows (Pi, Gi, gS) are fp32 in either storage mode
-        ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2f if mode == "f16x3" else E * (2 * W2b + C_FEA * 4) + N * W2f
+        ez_bytes = E * (W2b + 2 * C_FEA * 4) + N * W2f if mode == "f16x3" else E * (W2b + W2f + C_FEA * 4) + N * W2f
         # Backward (split-arithmetic modes at these widths): gZ [E, W2] is never stored -- edge_seg_bwd leaves one bit per
         # element (W2 / 8 bytes per edge) and its consumers rebuild the rows from the per-node matrix gS (csrc/kernels.h
         # struct EdgeRC), so only edge_seg_bwd is still bound by a Z-sized pass; edge_ge / edge_gw are priced against the

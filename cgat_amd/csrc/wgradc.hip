@@ -191,9 +191,11 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
     if (lane == 0) reinterpret_cast<unsigned long long*>(smem + WGC_SLOTS * WGC_SLOT_B)[(wave * 4 + (c - 100)) * 8 + (k_)] = t_; \
   }
+#define WGC_TS7(dep_) { unsigned d_ = dep_[0]; asm volatile("" : "+v"(d_)); WGC_TS(7) }   /* after the value exists */
 #else
   __shared__ __attribute__((aligned(16))) unsigned char smem[WGC_SLOTS * WGC_SLOT_B];
 #define WGC_TS(k_)
+#define WGC_TS7(dep_)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,12 +329,14 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
       L[2 * j_] = __builtin_bit_cast(unsigned, l0_); L[2 * j_ + 1] = __builtin_bit_cast(unsigned, l1_);           \
       T_[2 * j_] = __builtin_bit_cast(unsigned, t0_); T_[2 * j_ + 1] = __builtin_bit_cast(unsigned, t1_);         \
     }                                                                                                             \
+    WGC_TS(6)                                                                                                     \
     f16x32 hv_, lv_;                                                                                              \
     bf16x32 tv_;                                                                                                  \
     __builtin_memcpy(&hv_, H, 64);                                                                                \
     __builtin_memcpy(&lv_, L, 64);                                                                                \
     __builtin_memcpy(&tv_, T_, 64);                                                                               \
     const u32x6 l6_ = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(lv_, 1.0f);                                      \
+    WGC_TS7(l6_)                                                                                                  \
     const u32x6 h6_ = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(hv_, 4096.0f);                                   \
     const u32x6 t6_ = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(tv_, 0x1p-12f);                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { A6l[i_] = l6_[i_]; A6h[i_] = h6_[i_]; A6t[i_] = t6_[i_]; } \

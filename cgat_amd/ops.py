@@ -1037,6 +1037,11 @@ def get_bilinear_mode():
     return {v: k for k, v in _MODES.items()}[m]
 
 
+# launch-timer tags of the contraction kernels that have the 3.75-pass h + l + t form in the f16x3c mode (bench.py prices a
+# kernel against 2500 / 3.75 TFLOP/s only if it is listed here, against 2500 / 6 otherwise)
+F16C_KERNELS = ("bilinear_rows", "bilinear_dual", "bilinear_wgrad")
+
+
 def set_edge_storage(mode):
     """Storage of the per-edge intermediates Z / gZ of the fused scalar-attention path: "f32" (default) or "bf16"
     (BASELINE configs[4]'s "bf16 activations": half the HBM bytes of the edge phase, tolerance 1e-2; logits, softmax
