@@ -308,6 +308,15 @@ class GradientAverager:
         self._stale[i] = False
 
     def _launch(self, bi):
+        if self.flat[bi].is_cuda:
+            # gradients of one bucket may have been written on more than one stream (cgat_amd.ops.branch_stream: the
+            # composition branch runs beside the graph layers at small batches; the f16x3 mode's side stream): the
+            # collective is ordered behind the CURRENT stream only, so the current stream waits for the others first
+            from .ops import aux_streams
+            cur = torch.cuda.current_stream(self.flat[bi].device)
+            for s in aux_streams():
+                if s != cur and s.device == self.flat[bi].device:
+                    cur.wait_stream(s)
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if bi < self.n_hot:
             self._next = bi + 1

@@ -20,6 +20,7 @@ from .mlp import ResidualNetwork, SimpleNetwork
 from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, EdgeHiddenHeadsFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, get_segment_plan, linear, small_embedding,
                   segment_softmax, segment_sum)
 from .ops import overlap_enabled as ops_overlap_enabled
+from .ops import branch_stream
 from .roost import Roost
 
 
@@ -412,6 +413,17 @@ class CGAtNet(nn.Module):
         G = getattr(batch, "num_graphs", None)
         if G is None:
             G = int(crystal_elem_idx[-1]) + 1                                   # one host sync per batch
+        # The composition branch (reference CGAT.py:593: computed AFTER the graph layers, which it does not depend on) is
+        # issued first, on a branch stream at small batches: it then runs beside the graph layers instead of after them
+        roost = tuple(roost)                                                    # the harness passes a generator
+        main = branch = None
+        if batch.x.is_cuda:
+            branch = branch_stream(batch.x.device, edge_index.shape[1])
+        if branch is not None:
+            main = torch.cuda.current_stream(batch.x.device)
+            branch.wait_stream(main)
+            with torch.cuda.stream(branch):
+                crys_comp = self.roost(*roost, num_crystals=G)
         edge_attr = small_embedding(batch.edge_attr, self.nbr_embedding.weight)  # [E] int64 -> [E,Ce]
         elem_fea = linear(batch.x, self.embedding.weight, None)                 # [N,200] -> [N,C]
         elem_fea_0 = elem_fea
@@ -426,9 +438,12 @@ class CGAtNet(nn.Module):
             else:
                 edge_attr = edge_attr + edge(elem_fea, edge_index, edge_attr, edge_attr_0)
             elem_fea = elem_fea + node_update
-        roost = tuple(roost)                                                    # the harness passes a generator
-        crys_fea = self.roost(*roost, num_crystals=G)
-        crys_fea = self.cry_pool(elem_fea, crys_fea, crystal_elem_idx, size=G)
+        if branch is not None:
+            main.wait_stream(branch)
+            crys_comp.record_stream(main)
+        else:
+            crys_comp = self.roost(*roost, num_crystals=G)
+        crys_fea = self.cry_pool(elem_fea, crys_comp, crystal_elem_idx, size=G)
         if self.mean_pooling:
             crys_fea = crys_fea.view(-1, self.msg_heads, self.elem_fea_len).mean(dim=1)
         if return_graph_embedding:

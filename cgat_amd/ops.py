@@ -346,6 +346,32 @@ def side_stream(device, create=True):
     return _side_streams.get(key)
 
 
+_branch_streams = {}
+_branch_max_edges = int(os.environ.get("CGAT_BRANCH_STREAM_MAX_EDGES", "262144"))   # 0: never
+
+
+def branch_stream(device, n_edges):
+    """The stream independent sub-networks run on beside the main stream at SMALL batches (CGAtNet: the composition
+    branch beside the graph layers) -- or None when the batch is large enough for every kernel to fill the chip by
+    itself.  At the harness' shipped batch (64 crystals) a kernel occupies 5-40 of the 256 CUs for as long as one
+    workgroup needs for its serial chain, so two independent chains side by side cost the longer one, not the sum
+    (SURVEY 8 f3).  Works eagerly and under hipGraph capture (fork / join by events); autograd runs each node's backward
+    on its forward's stream, so the backward overlaps the same way."""
+    if _branch_max_edges <= 0 or n_edges > _branch_max_edges:
+        return None
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _branch_streams:
+        _branch_streams[key] = torch.cuda.Stream(device=dev)
+    return _branch_streams[key]
+
+
+def aux_streams():
+    """Every stream this package may have issued gradient-producing work on besides the caller's (dist.py makes a
+    collective wait for them)."""
+    return list(_branch_streams.values()) + list(_side_streams.values())
+
+
 class HNetFn(torch.autograd.Function):
     """y = HyperFC(hyper_input)(v)  with hyper_input = h0 (H_Net_0) or d*h0 + (1-d)*v (H_Net);
     reference Hypernetworksmp.py:257-313.  `flat` = per predicted layer: n_fc trunk weights,
