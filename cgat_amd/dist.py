@@ -99,6 +99,7 @@ class GradientAverager:
         # frozen mode: one entry (step, flag tensor, pinned copy, event) per step, oldest first; an entry is read -- blocking on
         # its event -- exactly VIOL_LAG steps after it was made, so every rank reads step k's (global) flag in the same finish()
         self._viol_q = collections.deque()
+        self._home = None
         self._viol_step = 0
         self._viol_sticky = None                       # device tensor: the last global flag (a violation stays visible)
         self.stats = {"launched_in_backward": 0, "launched_in_finish": 0, "cold_reduced": 0, "cold_skipped": 0,
@@ -166,6 +167,8 @@ class GradientAverager:
         then accumulates straight into the bucket)."""
         for f in self.flat:
             f.zero_()
+        if self.flat and self.flat[0].is_cuda:
+            self._home = torch.cuda.current_stream(self.flat[0].device)    # (hooks may fire under another stream)
         for i, p in enumerate(self.params):
             p.grad = self._view[id(p)]
             self._stale[i] = False
@@ -314,7 +317,8 @@ class GradientAverager:
             # collective is ordered behind the CURRENT stream only, so the current stream waits for the others first
             from .ops import aux_streams
             cur = torch.cuda.current_stream(self.flat[bi].device)
-            for s in aux_streams():
+            others = aux_streams() + ([self._home] if self._home is not None else [])   # _home: the caller's stream
+            for s in others:
                 if s != cur and s.device == self.flat[bi].device:
                     cur.wait_stream(s)
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -350,7 +350,7 @@ _branch_streams = {}
 _branch_max_edges = int(os.environ.get("CGAT_BRANCH_STREAM_MAX_EDGES", "262144"))   # 0: never
 
 
-def branch_stream(device, n_edges):
+def branch_stream(device, n_edges, which=0):
     """The stream independent sub-networks run on beside the main stream at SMALL batches (CGAtNet: the composition
     branch beside the graph layers) -- or None when the batch is large enough for every kernel to fill the chip by
     itself.  At the harness' shipped batch (64 crystals) a kernel occupies 5-40 of the 256 CUs for as long as one
@@ -360,7 +360,7 @@ def branch_stream(device, n_edges):
     if _branch_max_edges <= 0 or n_edges > _branch_max_edges:
         return None
     dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), which)
     if key not in _branch_streams:
         _branch_streams[key] = torch.cuda.Stream(device=dev)
     return _branch_streams[key]
