@@ -984,10 +984,23 @@ def main():
             n_t, ms_t = prof[tag]
             if n_t:
                 gbs = nbytes / (ms_t / args.steps * 1e-3) / 1e9      # bytes of the step / the tag's time in the step
-                hbm[tag] = {"bound": "hbm", "kernel": {"edge_z": "edge_zx_kernel" if mode == "f16x3" else "edge_z_kernel",
-                                                        "edge_seg_bwd": "edge_seg_bwd_kernel"}[tag],
+                # counter bytes of one step for the tag (builder-collected rocprofv3 --pmc passes, profiles/): the largest
+                # launch of each kernel name = the per-edge launch at the headline batch; only valid for that batch
+                kn = {"edge_z": ("edge_zx_kernel",) if mode == "f16x3" else ("edge_z_kernel",),
+                      "edge_seg_bwd": ("edge_seg_bwd_kernel",) if mode == "f16x3" else
+                                      ("seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel")}[tag]
+                tb = traffic.get("hbm_bound_kernels", {}) if (args.workload == "layer" and args.graphs == GRAPHS and
+                                                                args.edge_storage == "f32") else {}
+                cbytes = sum(tb[k]["hbm_bytes_largest_launch"] for k in kn) if all(k in tb for k in kn) else None
+                hbm[tag] = {"bound": "hbm", "kernel": " + ".join(kn),
                             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(gbs / 8000.0, 4), "traffic": None, "launches_per_step": n_t / args.steps,
+                            "frac": round(gbs / 8000.0, 4),
+                            "what": "achieved / frac: ALGORITHMIC bytes over the tag's time; traffic: HBM bytes from the PMC "
+                                    "counters (2 x FETCH_SIZE + WRITE_SIZE); frac_from_counters: those over the same time -- "
+                                    "gathers of per-node rows that hit in L2 are algorithmic bytes, not HBM bytes",
+                            "traffic": cbytes, "traffic_source": traffic_src if cbytes else None,
+                            "frac_from_counters": round(cbytes / (ms_t / args.steps * 1e-3) / 8e12, 4) if cbytes else None,
+                            "launches_per_step": n_t / args.steps,
                             "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
                             "algorithmic_bytes_per_launch": int(nbytes / (n_t / args.steps))}
                 if tag in concurrent and prof_x.get(tag, (0, 0))[0]:

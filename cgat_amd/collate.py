@@ -125,7 +125,9 @@ class PackedDataset:
         N, Nc, Ec = int(meta[1, B]), int(meta[2, B]), int(meta[3, B])
         K, F, dev = self.host["max_nbr"], self.host["fea"], self.device
         E = N * K
-        m = torch.from_numpy(meta).to(dev, non_blocking=True)
+        # pinned staging: a pageable source makes the upload a synchronous copy -- the one host sync per training step that
+        # round 4's bench line still showed
+        m = torch.from_numpy(meta).pin_memory().to(dev, non_blocking=True)
         f32, i64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int64, device=dev)
         x, ei, ea = torch.empty(N, F, **f32), torch.empty(2, E, **i64), torch.empty(E, **i64)
         y, batch = torch.empty(B, **f32), torch.empty(N, **i64)

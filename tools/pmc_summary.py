@@ -9,6 +9,7 @@ side is doubled; WRITE_SIZE is exact for 16-byte streaming stores.  Both counter
 import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+CSV_ONLY = len(sys.argv) > 4 and sys.argv[4] == "csv-only"   # (other workloads: the per-kernel CSV, not the headline's JSON)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -33,6 +34,8 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") 
     f.write("kernel,dispatches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
     for r in rows:
         f.write("%s,%d,%.1f,%.1f,%d\n" % r)
+if CSV_ONLY:
+    sys.exit(0)
 N, C = 83340, 128
 # f16x3: the prepared T / r operands are two fp16 planes = 4 bytes per element; f16x3c (the default since round 4): the
 # prepared T is 25 KB per 32 output columns and `a` = 6.25 bytes per element; the bf16 forms: three 2-byte planes
@@ -42,7 +45,15 @@ alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           #
        "bilinear_rows128_dualc_kernel": 7 * N * C * 4 + C * 4 * 25600,
        "bilinear_wgrad128_bf16_kernel": 2 * N * C * 4 + N * C * 6 + C ** 3 * 4,  # pT, qT, three bf16 planes of r + out
        # the batched f16x3 launch covers the four predicted layers: 4 x (pT, qT, two fp16 planes of r, out)
-       "bilinear_wgrad128_f16p_kernel": 4 * (2 * N * C * 4 + N * C * 4 + C ** 3 * 4)}
+       "bilinear_wgrad128_f16p_kernel": 4 * (2 * N * C * 4 + N * C * 4 + C ** 3 * 4),
+       # the batched f16x3c launch (round 5), four predicted layers: pT, qF (fp32), the r stream of 50 KB per 64 rows
+       # (6.25 bytes per element), out
+       "bilinear_wgrad128_f16c_kernel": 4 * (2 * N * C * 4 + (N // 64 + 1) * 51200 + C ** 3 * 4)}
+# HBM-bound kernels of the edge phase (bench.py hbm_bound_kernels: the fraction of 8 TB/s from COUNTER bytes): reported as
+# measured, no algorithmic figure here (bench.py holds it)
+HBM_KERNELS = ("edge_z_kernel", "edge_zx_kernel", "seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel",
+               "edge_seg_bwd_kernel", "seg_wsum_vec_kernel", "seg_softmax_fwd_kernel", "edge_gj_kernel", "edge_ge_kernel",
+               "edge_gw_kernel", "mlp_chain128_x6_kernel", "rows_dw128_split_batch_kernel")
 import subprocess
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
@@ -56,5 +67,16 @@ for k, n, f_kb, w_kb, b in rows:
     if k in alg:
         out[k] = {"dispatches": n, "FETCH_SIZE_KB_per_launch": round(f_kb, 1), "WRITE_SIZE_KB_per_launch": round(w_kb, 1),
                   "hbm_bytes_per_launch": b, "algorithmic_bytes_per_launch": alg[k]}
+# per-edge kernels: the per-EDGE launches only (the same template also runs the small per-node products): the launch with the
+# most bytes of each name
+def _largest(agg, k):
+    return max(agg.get(k, [0.0]))
+hb = {}
+for k in HBM_KERNELS:
+    if k in fetch or k in write:
+        f_kb, w_kb = _largest(fetch, k), _largest(write, k)
+        hb[k] = {"FETCH_SIZE_KB_largest_launch": round(f_kb, 1), "WRITE_SIZE_KB_largest_launch": round(w_kb, 1),
+                 "hbm_bytes_largest_launch": int((2 * f_kb + w_kb) * 1024)}
+out["hbm_bound_kernels"] = hb
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
