@@ -1314,10 +1314,25 @@ __device__ __forceinline__ void prepare_T_f16c_item(const float* __restrict__ sr
   }
 }
 __global__ void prepare_T_f16c_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int NA, long sa, long sb,
-                                      long sc, int alternate, const float* __restrict__ tmax) {
+                                      long sc, int alternate, const float* __restrict__ tmax, int per_a = 0) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)NA * 512) return;
-  prepare_T_f16c_item(src, dst, i, sa, sb, sc, alternate, tmax[0]);
+  prepare_T_f16c_item(src, dst, i, sa, sb, sc, alternate, tmax[per_a ? (int)(i >> 9) : 0]);   // per_a: one scale per block a
+}
+// out[a] = max |W[(128 a + c) * ldw + b]|, b, c < 128: one workgroup per block
+__global__ __launch_bounds__(256) void absmax_blocks128_kernel(const float* __restrict__ W, long ldw, float* __restrict__ out) {
+  const float* blk = W + (long)blockIdx.x * 128 * ldw;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < 128 * 32; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(blk + (long)(i >> 5) * ldw + 4 * (i & 31));
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  __shared__ float wm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
 }
 
 // Weight operands of the edge / dense kernels in the fp16 form: one workgroup per 128 x 128 block `a` keeps the block
@@ -1551,6 +1566,23 @@ int prepare_T_f16c_launch(const float* src, void* dst, int NA, long sa, long sb,
   CGAT_TRY(absmax_launch(src, total, tmax, stream));
   hipLaunchKernelGGL(prepare_T_f16c_kernel, dim3(cdiv((long)NA * 512, 256)), dim3(256), 0, stream, src, (uint4*)dst, NA,
                      sa, sb, sc, alternate, (const float*)tmax);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
+// The same image for a dense-layer weight given as W2 output rows of 128 contiguous inputs (row stride ldw; block a = rows
+// 128 a .. 128 a + 127), e.g. a column slice of a stacked weight: the maximum is taken over exactly those elements
+// (edgez.hip, edge_zc_kernel) -- and PER BLOCK a: an output block whose weights are small beside the tensor's largest keeps
+// its own 24 bits.  NA * F16C_A_FLOATS floats + the NA maxima.
+size_t prepare_W_f16c_rows_floats(int W2) { return (size_t)(W2 / 128) * F16C_A_FLOATS + (size_t)(W2 / 128) + 4; }
+int prepare_W_f16c_rows_launch(const float* W, long ldw, int W2, void* dst, hipStream_t stream) {
+  const int NA = W2 / 128;
+  if (NA <= 0) return CGAT_OK;
+  float* tmax = (float*)dst + (size_t)NA * F16C_A_FLOATS;
+  hipLaunchKernelGGL(absmax_blocks128_kernel, dim3(NA), dim3(256), 0, stream, W, ldw, tmax);
+  CGAT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prepare_T_f16c_kernel, dim3(cdiv((long)NA * 512, 256)), dim3(256), 0, stream, W, (uint4*)dst, NA,
+                     (long)128 * ldw, 1l, ldw, 0, (const float*)tmax, 1);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

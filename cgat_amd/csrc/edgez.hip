@@ -327,6 +327,281 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// f16x3c form of the per-edge launch (round 5):  Z[t, :] = W_e e[perm[t]] + Pi[dst[t]] + Pj[src[t]]  + attention logits, with
+// 24-bit operands at 3.75 matrix pass-equivalents per product where edge_z_kernel<6, true> pays six.
+// The machinery is bilinear_rows128_ring16c_kernel's (bilinear.hip): 512 threads = 8 waves x 32 rows, the lane's two rows
+// scaled per row and split ONCE into two fp16 planes + three 6-bit images (100 VGPRs), the weight as prepare_T_f16c's
+// image (a = 128-column block of the output; 25-KB chunks (a, column half, pair of 16-column blocks)) through a 4-slot
+// LDS-DMA ring, per chunk 8 groups of fp16 MFMAs + 6 correction instructions.  What differs from the contraction kernel:
+//  * every chunk is a finished 32-column slice of the output, so the 64 registers of cross-`a` accumulators are free: they
+//    hold the chunk's partial sums in TWO sets (odd k-steps multiply the negated row fragments into the second one, which
+//    is subtracted: the matrix instruction's accumulator rounding bias cancels) and the GATHERED
+//    addends of the NEXT chunk (8 x 16 bytes per lane), requested a whole chunk of matrix work before their use;
+//  * counted waits that never wait for a store: per chunk a wave issues, in this order, 3 (wave 0: 4) LDS-DMA pieces for
+//    chunk i + 3, the 8 gathers of chunk i + 1, and -- after the matrix work -- the 4 stores of chunk i.  The gathers of
+//    chunk i are needed after the matrix work of chunk i: younger than them are the 4 stores of chunk i - 1 and this
+//    iteration's 3 (4) + 8 loads, so the wait is vmcnt(4 + 3 + 8) = 15 (16 in wave 0) -- it also covers the ring (chunk i + 2's pieces are
+//    older still) and leaves every store two chunks of matrix work to drain.  Rows beyond E are clamped (they rewrite row
+//    E - 1 with identical values) so that every wave issues exactly these operations.
+// edge_z_kernel<6, true> alternates two 128-row workgroups per CU and waits vmcnt(3) per k-step: every wait behind an
+// epilogue drains that epilogue's stores (in-order vmcnt) and its gathers are requested where they are used: 3.2 ms at the
+// BASELINE shape with 1.9 ms of matrix work and 0.66 of wave cycles waiting on memory.
+// ---------------------------------------------------------------------------------------
+#ifndef EZC_ABL
+#define EZC_ABL 0   // timing-only ablations (wrong results): 1 no Z stores, 2 no gathers, 4 no matrix instructions
+#endif
+template <bool ZB>
+__global__ __launch_bounds__(512, 2) void edge_zc_kernel(const float* __restrict__ e, long lde, const int* __restrict__ perm,
+                                                         const uint4* __restrict__ Tq, int ncb,
+                                                         const float* __restrict__ Pi, const int* __restrict__ dsti,
+                                                         const float* __restrict__ Pj, const int* __restrict__ srci,
+                                                         long ld_add, float* __restrict__ Z, long ldz, int E,
+                                                         const float* __restrict__ wA, const float* __restrict__ bA,
+                                                         int H, int cb_per_head, float* __restrict__ a_out) {
+  constexpr int CH16 = F16C_CHUNK16;
+  constexpr int SLOTS = 4;
+  __shared__ uint4 smem[SLOTS * CH16 + 512 + 8];      // the ring + fc_out_A's weight (<= 2048 floats) + 32 block scales
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int row_w = blockIdx.x * 256 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;
+  const int rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wave_t = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned char* cring = reinterpret_cast<const unsigned char*>(smem) + 16384;
+  const unsigned t_off = (unsigned)tid * 16;
+  const long last_chunk = (long)ncb * 4 - 1;
+  const float* tmax = reinterpret_cast<const float*>(Tq) + (size_t)ncb * F16C_A_FLOATS;
+
+  // the lane's two edge rows e[row, 32 s + 8 kg + j], scaled per row: fp16 planes q1 / q2 [2 s + nb] (odd k-steps negated)
+  // + the three 6-bit images
+  bf16x8 q1[8], q2[8];
+  frag6 ql6[2], qh6[2], qt6[2];
+  float rs_a, rs_b;
+  {
+    const long ea = perm ? perm[rca] : rca, eb = perm ? perm[rcb] : rcb;
+    float qv[2][32];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        qv[nb][8 * s + 0] = t0.x; qv[nb][8 * s + 1] = t0.y; qv[nb][8 * s + 2] = t0.z; qv[nb][8 * s + 3] = t0.w;
+        qv[nb][8 * s + 4] = t1.x; qv[nb][8 * s + 5] = t1.y; qv[nb][8 * s + 6] = t1.z; qv[nb][8 * s + 7] = t1.w;
+      }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(qv[nb][j]));
+      m = fmaxf(m, __shfl_xor(m, 16));          // the row's 128 values live in the four lanes n16 + 16 kg
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sq, iq;
+      pow2_scale(m, sq, iq);
+      (nb ? rs_b : rs_a) = iq;                  // (the weight block's inverse scale joins it per block `a`)
+#pragma unroll
+      for (int j = 0; j < 32; ++j) qv[nb][j] *= sq;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qv[nb][8 * s + j];
+        split2_x8_f16(v, q1[2 * s + nb], q2[2 * s + nb]);
+        if (s & 1) { q1[2 * s + nb] = neg_x8(q1[2 * s + nb]); q2[2 * s + nb] = neg_x8(q2[2 * s + nb]); }
+      }
+      f16c_pack32(qv[nb], ql6[nb], qh6[nb], qt6[nb]);   // element 8 s + j <-> k = 32 s + 8 kg + j, as in the image
+    }
+  }
+  // gathered rows as 32-bit byte offsets from Pi / Pj (< 4 GB: checked by the launcher)
+  const unsigned oia = (unsigned)(((long)dsti[rca] * ld_add + 4 * kg) * 4), oib = (unsigned)(((long)dsti[rcb] * ld_add + 4 * kg) * 4);
+  const unsigned oja = (unsigned)(((long)srci[rca] * ld_add + 4 * kg) * 4), ojb = (unsigned)(((long)srci[rcb] * ld_add + 4 * kg) * 4);
+  const int ncbA = (a_out && wA) ? H * cb_per_head : 0;      // column blocks that belong to the attention network
+  float* wAs = reinterpret_cast<float*>(smem + SLOTS * CH16);
+  for (int i = tid; i < ncbA * 128; i += 512) wAs[i] = wA[i];
+  float* its = wAs + 2048;                           // 1 / scale of weight block a (a global load in the loop would make the
+  if (tid < ncb && tid < 32) {                       // compiler wait vmcnt(0) there, i.e. for every store in flight)
+    float st_, it_;
+    pow2_scale(tmax[tid], st_, it_);
+    its[tid] = it_;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#define ZC_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Tq + gi * CH16;                                                          \
+    const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
+    glds_b128(tb, t_off, dst);                                                                 \
+    glds_b128(tb + 512, t_off, dst + 8192);                                                    \
+    glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
+    if (wave_u == 0) glds_b128(tb + 1536, t_off, dst + 24576);                                 \
+  }
+  // the 8 gathered 16-byte pieces of chunk gi_ (clamped): [cb2] x {Pi row a, Pj row a, Pi row b, Pj row b}; issued from inline
+  // asm and tied to the counted wait (the compiler cannot see the LDS-DMA and would wait vmcnt(0) before their first use)
+#define ZC_GATHER(G_, gi_)                                                                     \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const unsigned cbyte = (unsigned)(((gi >> 2) * 128 + ((gi >> 1) & 1) * 64 + (gi & 1) * 32) * 4); \
+    if (EZC_ABL & 2) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) G_[i_] = f32x4{1.f, 2.f, 3.f, 4.f}; } else \
+    _Pragma("unroll") for (int cb2 = 0; cb2 < 2; ++cb2) {                                      \
+      asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %9\n\t"      \
+                   "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %9"          \
+                   : "=&v"(G_[4 * cb2 + 0]), "=&v"(G_[4 * cb2 + 1]), "=&v"(G_[4 * cb2 + 2]), "=&v"(G_[4 * cb2 + 3]) \
+                   : "v"(oia + cbyte + 64 * cb2), "v"(oja + cbyte + 64 * cb2), "v"(oib + cbyte + 64 * cb2),  \
+                     "v"(ojb + cbyte + 64 * cb2), "s"(Pi), "s"(Pj)                             \
+                   : "memory");                                                                \
+    }                                                                                          \
+  }
+  f32x4 GA[8], GB[8];
+  ZC_TLOAD(0l);
+  ZC_TLOAD(1l);
+  ZC_TLOAD(2l);
+  ZC_GATHER(GA, 0l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fb1, fb2;
+  frag6 ce;
+#define ZC_READ(F1_, F2_, slot_, g_)                                                           \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * CH16 + ((((g_) >> 1) * 2) * 2 + ((g_) & 1)) * 64;      \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[2 * 64];                                                                          \
+  }
+#define ZC_CREAD(slot_, j_)                                                                    \
+  {                                                                                            \
+    const unsigned char* cp = cring + (slot_) * (CH16 * 16) + (j_) * 1536;                     \
+    const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
+    const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
+    ce.w[0] = u_.x; ce.w[1] = u_.y; ce.w[2] = u_.z; ce.w[3] = u_.w; ce.w[4] = w_.x; ce.w[5] = w_.y; \
+  }
+  // group g = 2 s + cb2: even k-steps into part, odd ones (negated row fragments) into partn
+#define ZC_MFMA(F1_, F2_, g_)                                                                  \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = (((g_) >> 1) & 1) ? partn[2 * ((g_) & 1) + nb] : part[2 * ((g_) & 1) + nb];  \
+      if (EZC_ABL & 4) { P_[0] += F1_[0] * (float)q1[2 * ((g_) >> 1) + nb][0] + (float)F2_[1] * (float)q2[2 * ((g_) >> 1) + nb][1]; continue; } \
+      P_ = mma16<true>(F2_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q2[2 * ((g_) >> 1) + nb], P_);                                     \
+      P_ = mma16<true>(F1_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
+    }                                                                                          \
+  }
+#define ZC_CORR(j_)                                                                            \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = part[2 * ((j_) / 3) + nb];                                                   \
+      if ((j_) % 3 == 0) P_ = f16c_mma_th(ce, qh6[nb], P_);                                    \
+      else if ((j_) % 3 == 1) P_ = f16c_mma_ht(ce, qt6[nb], P_);                               \
+      else P_ = f16c_mma_ll(ce, ql6[nb], P_);                                                  \
+    }                                                                                          \
+  }
+  // epilogue of chunk (a_, ch_): z = (part - partn) * row scale + gathered addends; store; logits
+#define ZC_EPILOGUE(G_, a_, ch_)                                                               \
+  {                                                                                            \
+    asm volatile("" : "+v"(G_[0]), "+v"(G_[1]), "+v"(G_[2]), "+v"(G_[3]), "+v"(G_[4]), "+v"(G_[5]), "+v"(G_[6]), "+v"(G_[7])); \
+    int ra_ = rca, rb_ = rcb, lk_ = lane;   /* laundered: the 64-bit row addresses are formed HERE, not kept (= spilled: a   \
+                                              scratch reload in this loop waits vmcnt(0), i.e. for every store) */        \
+    asm volatile("" : "+v"(ra_), "+v"(rb_), "+v"(lk_));                                        \
+    const int col0 = (a_) * 128 + ((ch_) >> 1) * 64 + ((ch_) & 1) * 32 + 4 * (lk_ >> 4);       \
+    const float it_ = its[a_];        /* the block's inverse scale */                           \
+    const bool isA = (a_) < ncbA;                                                              \
+    _Pragma("unroll") for (int cb2 = 0; cb2 < 2; ++cb2) {                                      \
+      const int col = col0 + 16 * cb2;                                                         \
+      const f32x4 pa = (part[2 * cb2 + 0] - partn[2 * cb2 + 0]) * (rs_a * it_), pb = (part[2 * cb2 + 1] - partn[2 * cb2 + 1]) * (rs_b * it_); \
+      const f32x4 ia = G_[4 * cb2 + 0], ja = G_[4 * cb2 + 1], ib = G_[4 * cb2 + 2], jb = G_[4 * cb2 + 3]; \
+      const float4 va = make_float4(pa[0] + ia[0] + ja[0], pa[1] + ia[1] + ja[1], pa[2] + ia[2] + ja[2], pa[3] + ia[3] + ja[3]); \
+      const float4 vb = make_float4(pb[0] + ib[0] + jb[0], pb[1] + ib[1] + jb[1], pb[2] + ib[2] + jb[2], pb[3] + ib[3] + jb[3]); \
+      if (EZC_ABL & 1) {                                                                       \
+        if (va.x == 123.456f) Z[0] = vb.y;                                                     \
+      } else if constexpr (ZB) {                                                               \
+        store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)ra_ * ldz + col, va);                 \
+        store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)rb_ * ldz + col, vb);                 \
+      } else {                                                                                 \
+        *reinterpret_cast<float4*>(Z + (long)ra_ * ldz + col) = va;                            \
+        *reinterpret_cast<float4*>(Z + (long)rb_ * ldz + col) = vb;                            \
+      }                                                                                        \
+      if (isA) {                                                                               \
+        const float4 w = *reinterpret_cast<const float4*>(wAs + col);                          \
+        dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y + \
+                 (va.z > 0.f ? va.z : 0.01f * va.z) * w.z + (va.w > 0.f ? va.w : 0.01f * va.w) * w.w; \
+        asm volatile("" : "+v"(dot_a));   /* keep the two accumulations apart: see the note on packed math above */ \
+        dot_b += (vb.x > 0.f ? vb.x : 0.01f * vb.x) * w.x + (vb.y > 0.f ? vb.y : 0.01f * vb.y) * w.y + \
+                 (vb.z > 0.f ? vb.z : 0.01f * vb.z) * w.z + (vb.w > 0.f ? vb.w : 0.01f * vb.w) * w.w; \
+        asm volatile("" : "+v"(dot_b));                                                        \
+      }                                                                                        \
+    }                                                                                          \
+    if (isA && (ch_) == 3 && ((a_) + 1) % cb_per_head == 0) {   /* a head is complete: reduce over the 4 lane groups */ \
+      const int h = (a_) / cb_per_head;                                                        \
+      float da = dot_a, db = dot_b;                                                            \
+      da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);                              \
+      db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);                              \
+      if ((lk_ >> 4) == 0) {   /* (clamped rows rewrite row E - 1's logits with identical values) */ \
+        const float bh = bA ? bA[h] : 0.f;                                                     \
+        a_out[(long)ra_ * H + h] = da + bh;                                                    \
+        a_out[(long)rb_ * H + h] = db + bh;                                                    \
+      }                                                                                        \
+      dot_a = 0.f; dot_b = 0.f;                                                                \
+    }                                                                                          \
+  }
+  // one chunk: ring prefetch, the next chunk's gathers, 8 groups + 6 corrections (every fragment read one group ahead), the
+  // counted wait, the epilogue, the barrier
+#define ZC_CHUNK(a_, ch_, GCUR_, GNEXT_)                                                       \
+  {                                                                                            \
+    constexpr int sl_ = (ch_), sn_ = ((ch_) + 1) & 3;   /* ring slot = chunk index mod 4 = ch_ */ \
+    ZC_TLOAD((long)(a_) * 4 + (ch_) + 3);                                                      \
+    ZC_GATHER(GNEXT_, (long)(a_) * 4 + (ch_) + 1);                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { part[i] = f32x4{0.f, 0.f, 0.f, 0.f}; partn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+    _Pragma("unroll") for (int gp = 0; gp < 4; ++gp) {                                         \
+      ZC_READ(fb1, fb2, sl_, 2 * gp + 1);                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      if (2 * gp < 6) { ZC_CORR(2 * gp); ZC_CREAD(sl_, 2 * gp + 1); }                          \
+      ZC_MFMA(fa1, fa2, 2 * gp);                                                               \
+      if (gp < 3) ZC_READ(fa1, fa2, sl_, 2 * gp + 2)                                           \
+      else ZC_READ(fa1, fa2, sn_, 0);                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      if (2 * gp + 1 < 6) {                                                                    \
+        ZC_CORR(2 * gp + 1);                                                                   \
+        if (2 * gp + 2 < 6) ZC_CREAD(sl_, 2 * gp + 2)                                          \
+        else ZC_CREAD(sn_, 0);                                                                 \
+      }                                                                                        \
+      ZC_MFMA(fb1, fb2, 2 * gp + 1);                                                           \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    /* gathers of THIS chunk (issued one iteration ago): younger are the 4 stores of the previous chunk and this       \
+       iteration's 3 (4) pieces + 8 gathers; the ring needs nothing more (chunk i + 2's pieces are older still) */        \
+    if (EZC_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+    else if (wave_u == 0) wait_vmcnt<16>(); else wait_vmcnt<15>();                             \
+    ZC_EPILOGUE(GCUR_, a_, ch_)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("" ::: "memory");                                                             \
+  }
+  ZC_READ(fa1, fa2, 0, 0);
+  ZC_CREAD(0, 0);
+  f32x4 part[4], partn[4];
+  float dot_a = 0.f, dot_b = 0.f;
+  for (int a = 0; a < ncb; ++a) {
+    ZC_CHUNK(a, 0, GA, GB)
+    ZC_CHUNK(a, 1, GB, GA)
+    ZC_CHUNK(a, 2, GA, GB)
+    ZC_CHUNK(a, 3, GB, GA)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ZC_TLOAD
+#undef ZC_GATHER
+#undef ZC_READ
+#undef ZC_CREAD
+#undef ZC_MFMA
+#undef ZC_CORR
+#undef ZC_EPILOGUE
+#undef ZC_CHUNK
+}
+
+// ---------------------------------------------------------------------------------------
 // The per-edge launch with the x_j projection folded in (f16x3 arithmetic):
 //     Z[t, :] = [W_e | W_j] [e[perm[t]] ; x[src[t]]] + Pi[dst[t], :]
 // Why, and what bounds these kernels: timing-only ablations (tools/edgez_ablation.sh; E = 1 000 080)
@@ -641,7 +916,21 @@ bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz,
 }
 
 // floats of workspace for the pre-split weight
-size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
+size_t edge_z_wq_floats(int W2) {
+  const size_t a = ((size_t)W2 * 128 * 3 + 1) / 2, b = prepare_W_f16c_rows_floats(W2);   // three bf16 planes / the f16x3c image
+  return a > b ? a : b;
+}
+// the per-edge launch in the f16x3c form (edge_zc_kernel): OPT-IN (CGAT_EDGE_ZC=1).  Measured (round 5, BASELINE shape):
+// 3.2 -> 2.85 ms per launch, and with it the number of tensors of the sin-filled fixture `net_mean` that need the
+// oracle-noise term of the parity criterion goes from 3 to 11 (all within 2.8 x the oracle's own fp32 deviation from
+// fp64; the h + l + t form is 1.26 x the error of the exact six-pass split, tests/arith_cases.py) -- 1 % of the step is
+// not worth the margin, so the default per-edge forward stays the six-pass kernel.  What the experiment established
+// (tools/edgezc_ablate.sh): this launch is bound by its memory path, not by the matrix cores -- without the Z stores
+// 1.86 ms, without the gathers 2.22, without both 1.42, without any matrix instruction still 2.83.
+static bool edge_zc_on() {
+  static const bool on = [] { const char* e = getenv("CGAT_EDGE_ZC"); return e && e[0] == '1'; }();
+  return on;
+}
 
 // We: the edge_attr slice of the stacked first-layer weight, element (out, k) at We[out * ldw + k].
 // With Pj == nullptr the kernel computes the plain product Z = e We^T + bias (Pi = bias vector or nullptr, no logits):
@@ -649,12 +938,26 @@ size_t edge_z_wq_floats(int W2) { return ((size_t)W2 * 128 * 3 + 1) / 2; }
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream, int act,
-                  float* omax, int z_bf16) {
+                  float* omax, int z_bf16, int n_add_rows) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   CGAT_CHECK_ARG(!z_bf16 || (Pj != nullptr && bilinear_mode() != 2 && bilinear_mode() != 3 && bilinear_mode() != 0 &&
                              act == CGAT_ACT_NONE && !omax),
                  "edge_z: bf16 storage is the per-edge launch of the six-pass form only");
+  // (fc_out_A's weight is staged in 8 KB of LDS; the gathered rows are addressed by 32-bit byte offsets)
+  if (bilinear_mode() == 4 && Pj != nullptr && perm && act == CGAT_ACT_NONE && !omax && edge_zc_on() && (ldw % 4) == 0 &&
+      (((uintptr_t)We) & 15) == 0 && (!a_out || (long)H * Hd <= 2048) && ncb <= 32 && n_add_rows > 0 && (long)n_add_rows * 4 * ld_add < (1l << 32)) {
+    CGAT_TRY(prepare_W_f16c_rows_launch(We, ldw, W2, Wq, stream));
+    CGAT_PROF("edge_z", stream);
+    if (z_bf16)
+      hipLaunchKernelGGL(edge_zc_kernel<true>, dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi,
+                         dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
+    else
+      hipLaunchKernelGGL(edge_zc_kernel<false>, dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi,
+                         dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   // operand (a = column block, b = k, c = column in block) = We[(128 a + c) * ldw + b]
   if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, stream));
   else CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));

@@ -113,6 +113,9 @@ int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, 
 // three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
 int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
                           hipStream_t stream);
+// f16x3c image (bilinear.hip, prepare_T_f16c_kernel) of a dense-layer weight: W2 output rows of 128 inputs, row stride ldw
+size_t prepare_W_f16c_rows_floats(int W2);
+int prepare_W_f16c_rows_launch(const float* W, long ldw, int W2, void* dst, hipStream_t stream);
 // ---- fused edge pre-activations + attention logits, edgez.hip ----
 bool edge_z_fast(int Ce, int W2, int H, int Hd, long lde, long ld_add, long ldz, const void* e, const void* Pi,
                  const void* Pj, const void* Z, const void* wA);
@@ -128,7 +131,8 @@ int edge_zx_launch(const float* e, long lde, const int* perm, const float* x, lo
 int edge_z_launch(const float* e, long lde, const int* perm, const float* We, long ldw, float* Wq, int W2,
                   const float* Pi, const int* dsti, const float* Pj, const int* srci, long ld_add, float* Z, long ldz,
                   int E, const float* wA, const float* bA, int H, int Hd, float* a_out, hipStream_t stream,
-                  int act = CGAT_ACT_NONE, float* omax = nullptr, int z_bf16 = 0);   // z_bf16: as edge_zx_launch
+                  int act = CGAT_ACT_NONE, float* omax = nullptr, int z_bf16 = 0,   // z_bf16: as edge_zx_launch
+                  int n_add_rows = 0);   // rows of Pi / Pj (0 = unknown: the f16x3c kernel addresses them by 32-bit offsets)
 int absmax_launch(const float* src, long n, float* out, hipStream_t stream);   // zeroes out[0] first
 int absmax_rows128_launch(const float* t, long ld, int rows, float* out, hipStream_t stream);  // folds into out[0]
 // fp16 form for weight operands: planes of 2^k(a) W[a], max |W[a]| in ((float*)dst)[NA * 16384 + a]

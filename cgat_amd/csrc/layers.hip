@@ -725,7 +725,7 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
                        plan->src_sorted, d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, zb ? 1 : 0));
   } else if (fused_z) {
     RUN(edge_z_launch(e, d.Ce, plan->dst_perm, Wcat + d.C, d.D, Wq, d.W2, Pi, plan->dst_sorted, Pj, plan->src_sorted,
-                      d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, CGAT_ACT_NONE, nullptr, zb ? 1 : 0));
+                      d.W2, sv.Z, d.W2, d.E, p->A_out_w, p->A_out_b, d.H, d.Hd, a, c.s, CGAT_ACT_NONE, nullptr, zb ? 1 : 0, d.N));
   } else {
     GemmParams g = gemm_params(d.E, d.W2, d.Ce, e, d.Ce, Wcat + d.C, d.D, sv.Z, d.W2);
     g.a_rgather = plan->dst_perm;
