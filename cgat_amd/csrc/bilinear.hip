@@ -1270,6 +1270,36 @@ __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __r
   }
 }
 
+// The same three-plane image (NA = 1, no sign alternation) for SEVERAL 128 x 128 weights in one launch: the operands of the
+// dense-layer kernel (edgez.hip, linear128_launch) in the 24-bit modes -- the hypernetwork's linear terms prepared their
+// weight per product: 12 launches of 4.5 us per predicted-layer block and direction (round 5: one launch).
+// Element (k, o) of item i is src[i][o * sc[i] + k * sb[i]]; image i at dst + i * 24576 floats.
+__global__ void prepare_T_bf16_batch_kernel(WPrepBatch b, __bf16* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // 16384 elements per item
+  const float* src = b.src[blockIdx.y];
+  const long sb = b.sb[blockIdx.y], sc = b.sc[blockIdx.y];
+  int bb, c;
+  if (sc == 1) { bb = (i >> 7) & 127; c = i & 127; }              // thread order follows the fastest source stride
+  else { c = (i >> 7) & 127; bb = i & 127; }
+  const float v = src[(long)c * sc + (long)bb * sb];
+  const int half = c >> 6, cb = (c & 63) >> 4, i16 = c & 15;
+  const int kh = bb >> 6, s2 = (bb >> 5) & 1, kg = (bb & 31) >> 3, j = bb & 7;
+  const long blk = ((((long)half) * 2 + kh) * 2 + s2) * 3;
+  const long in = (((long)cb * 4 + kg) * 16 + i16) * 8 + j;
+  __bf16 x1, x2, x3;
+  split3_bf16(v, x1, x2, x3);
+  __bf16* d = dst + (size_t)blockIdx.y * 49152;                   // 24576 floats = 49152 bf16
+  d[(blk + 0) * 2048 + in] = x1;
+  d[(blk + 1) * 2048 + in] = x2;
+  d[(blk + 2) * 2048 + in] = x3;
+}
+int prepare_T_bf16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream) {
+  if (b.n <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_T_bf16_batch_kernel, dim3(64, b.n), dim3(256), 0, stream, b, (__bf16*)dst);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // f16x3c (mfma_bf16.h): the prepared T of the contraction kernels' 24-bit form.  One chunk = (a, column half, pair of
 // 16-column blocks) = everything the forward kernel needs for 32 output columns of one `a`, 25 KB contiguous:
 //   [k-step s = b/32 (4)][plane: h, l (2)][cb2 (2)][lane 64 x 16 B]          two fp16 planes of 2^k sgn(a) T[a]  (16 KB)

@@ -996,7 +996,9 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   if (rows <= 0) return CGAT_OK;
   const int ncb = n_out / 128;
   // operand (a = output block, b = k, c = output in block) = W[(128 a + c) * so + b * sk]
-  if (prepared && bilinear_mode() == 2 && n_out == 128) ws = const_cast<void*>(prepared);
+  // prepared: the mode's image of this weight made ahead of time (f16x3: prepare_W_f16_batch_launch; the bf16 forms:
+  // prepare_T_bf16_batch_launch), n_out == 128 only
+  if (prepared && n_out == 128) ws = const_cast<void*>(prepared);
   else if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(W, ws, ncb, 128 * so, sk, so, stream));
   else CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
   CGAT_PROF("linear128", stream);

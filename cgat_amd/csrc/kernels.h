@@ -163,6 +163,8 @@ struct WPrepBatch {
   int n;
 };
 int prepare_W_f16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);
+// three-bf16-plane images (the dense-layer kernel's operand in the 24-bit modes) of b.n 128 x 128 weights, 24576 floats each
+int prepare_T_bf16_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);
 int prepare_T_bf16_rows_launch(const float* rows, long ld, const int* gather, int nrows, void* dst, int NA,
                                hipStream_t stream, const float* emax = nullptr);   // emax: fp16 form scaled by max |rows|
 int prepare_T_f16_scaled_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, const float* tmax,

@@ -22,9 +22,28 @@ struct Ctx {
   // 128 x 128 dense-layer weights prepared ahead in one launch (f16x3 mode): looked up by (pointer, strides) in gemm()
   WPrepBatch wprep;
   float* wprep_images;
+  // ... and, in the 24-bit modes, the dense-layer kernel's own images (three bf16 planes) of the weights gemm() multiplies
+  // by: one launch for all of them instead of one per product
+  WPrepBatch tprep;
+  float* tprep_images;
   Ctx(void* ws, size_t bytes, bool dry_, hipStream_t st)
       : w(dry_ ? nullptr : ws, dry_ ? (size_t)-1 / 2 : bytes), dry(dry_), s(st), scratch_need(0), scratch(nullptr),
-        scratch_bytes(0), wprep_images(nullptr) { wprep.n = 0; }
+        scratch_bytes(0), wprep_images(nullptr), tprep_images(nullptr) { wprep.n = 0; tprep.n = 0; }
+  void tprep_reserve(int max_items) { tprep_images = take<float>((size_t)max_items * 24576); }
+  void tprep_add(const float* W, long so, long sk) {
+    if (tprep.n < WPREP_MAX) { tprep.src[tprep.n] = W; tprep.sb[tprep.n] = sk; tprep.sc[tprep.n] = so; ++tprep.n; }
+  }
+  static bool tprep_mode() { return bilinear_mode() == 4 || bilinear_mode() == 6; }
+  int tprep_run() {
+    if (dry || !tprep_mode() || tprep.n == 0 || !tprep_images) { if (!tprep_mode()) tprep.n = 0; return CGAT_OK; }
+    return prepare_T_bf16_batch_launch(tprep, tprep_images, s);
+  }
+  const void* tprep_find(const float* W, long so, long sk) const {
+    if (dry || !tprep_mode() || !tprep_images) return nullptr;
+    for (int i = 0; i < tprep.n; ++i)
+      if (tprep.src[i] == W && tprep.sb[i] == sk && tprep.sc[i] == so) return tprep_images + (size_t)i * 24576;
+    return nullptr;
+  }
   // call before seal(): reserves the image space; add items, then wprep_run() once
   // (images of the current arithmetic mode: the fp16 chain's in "f16x3", the six-pass bf16 chain's in the 24-bit modes;
   // the space is reserved for the larger of the two so that a size query does not depend on the mode)
@@ -65,7 +84,7 @@ struct Ctx {
     if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes(p.N)) {
       const long so = p.b_kmajor ? 1 : p.ldb, sk = p.b_kmajor ? p.ldb : 1;
       return linear128_launch(p.A, p.lda, p.B, so, sk, p.bias, p.act, p.beta == 1.f, p.C, p.ldc, p.M, scratch, s, p.N,
-                              p.N == 128 ? wprep_find(p.B, so, sk) : nullptr);
+                              p.N != 128 ? nullptr : (bilinear_mode() == 2 ? wprep_find(p.B, so, sk) : tprep_find(p.B, so, sk)));
     }
     return gemm_launch(p, scratch, scratch_bytes, s);
   }
@@ -1271,7 +1290,7 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
   float* Tp = c.take<float>((batch_T ? (size_t)p->n_hyper : 1) * Tfl);
   float* Tpart = c.take<float>(bilinear_prepare_T_batch_ws_floats(p->n_hyper));
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
-  if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
+  if (batch_w) { c.wprep_reserve(p->n_hyper * (p->n_fc + 2)); c.tprep_reserve(2 * p->n_hyper); }
   c.seal();
   bool T_ready = false;
   if (batch_T && !c.dry) {
@@ -1286,9 +1305,11 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], W, 1);
       if (bilinear_mode() == 2) c.wprep_add(p->layer[l].head_b, W, 1);   // read by linear128_launch in that mode only
+      else c.tprep_add(p->layer[l].head_b, W, 1);                        // (the 24-bit modes: the dense-layer kernel's image)
       c.wprep_add(p->layer[l].head_w + WW * W, W, 1);
     }
     CGAT_TRY(c.wprep_run());
+    CGAT_TRY(c.tprep_run());
   }
   HnetSaved sv = hnet_saved(saved, rows, p);
   const float* hin = h0;
@@ -1410,7 +1431,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const HnetSideLayout SL = hnet_side_layout(rows, p);
   float* g_pre_all = (side && defer_dw) ? (c.dry ? nullptr : (float*)((char*)side->ws + SL.gpre))
                                         : c.take<float>((size_t)(defer_dw ? p->n_hyper : 1) * nfc1 * rw);
-  if (batch_w) c.wprep_reserve(p->n_hyper * (p->n_fc + 2));
+  if (batch_w) { c.wprep_reserve(p->n_hyper * (p->n_fc + 2)); c.tprep_reserve(2 * p->n_hyper); }
   c.seal();
   DwBatchDesc dwb;
   memset(&dwb, 0, sizeof(dwb));
@@ -1426,9 +1447,11 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
     for (int l = 0; l < p->n_hyper; ++l) {
       for (int s = 0; s < p->n_fc; ++s) c.wprep_add(p->layer[l].fc_w[s], 1, W);
       if (bilinear_mode() == 2) c.wprep_add(p->layer[l].head_b, 1, W);
+      else { c.tprep_add(p->layer[l].head_b, 1, W); c.tprep_add(p->layer[l].head_w + WW * W, 1, W); }
       c.wprep_add(p->layer[l].head_w + WW * W, 1, W);
     }
     CGAT_TRY(c.wprep_run());
+    CGAT_TRY(c.tprep_run());
   }
   bool T_ready = false;   // the [a = i][b = o][c = k] operands of all predicted layers in two launches
   if (batch_T && !c.dry) {

@@ -9,7 +9,7 @@ src, dst = sys.argv[1], sys.argv[2]
 path = sorted(glob.glob(src + "/*/*_kernel_trace.csv"))[0]
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"])
              for r in csv.DictReader(open(path))), key=lambda e: e[0])
-first = [i for i, e in enumerate(ev) if e[2].startswith("void edge_z_kernel<6, true>") or e[2].startswith("void edge_zx_kernel")]
+first = [i for i, e in enumerate(ev) if e[2].startswith("void edge_z_kernel<6, true") or e[2].startswith("void edge_zx_kernel")]
 assert len(first) >= 3, "needs at least three steps in the trace"
 a, b = first[-2], first[-1]
 step = ev[a:b]
@@ -22,7 +22,7 @@ def short(n):
     return re.sub(r"\(.*", "", n)
 
 
-out = ["# One layer step (forward + backward) of the final round-4 build, default mode f16x3c, serial order (no side stream in",
+out = ["# One layer step (forward + backward) of the final round-5 build, default mode f16x3c, serial order (no side stream in",
        "# the 24-bit modes): rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass",
        "# --no-extra-legs` (tools/collect_profiles.sh, tools/step_timeline.py); the last full step, times in ms from the start of",
        "# the per-edge forward kernel; kernels under 20 us are folded into the count column of the next listed kernel.",
