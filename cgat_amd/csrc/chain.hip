@@ -328,7 +328,8 @@ int prepare_W_x6_batch_launch(const WPrepBatch& b, float* dst, hipStream_t strea
   return CGAT_OK;
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_chain128_x6_kernel(ChainDesc d) {
+// (the body as a device function: the single and the batched kernel below call it with their descriptor)
+__device__ __forceinline__ void mlp_chain128_x6_body(const ChainDesc& d) {
   constexpr int CH16 = 2 * 3 * 2 * 64;          // 16-byte pieces per chunk: two k-steps x three planes x two blocks x 64 lanes
   constexpr int XP = 36;                        // pitch (floats) of the layout-exchange tile: 32 columns + 4
   __shared__ uint4 smem[4 * CH16];
@@ -534,6 +535,13 @@ int prepare_W_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream) 
   return CGAT_ERR_UNSUPPORTED;
 }
 
+__global__ __launch_bounds__(256, 2) void mlp_chain128_x6_kernel(ChainDesc d) { mlp_chain128_x6_body(d); }
+// several independent chains over the same row count in ONE launch (blockIdx.y = chain): the four predicted layers' trunks of
+// a hypernetwork forward all read the hyper input.  At 83 340 rows a chain is 652 workgroups on 512 slots -- two rounds for
+// 1.27 rounds of work; four chains together are six rounds instead of eight, and at 64 crystals one launch instead of four
+struct ChainBatch { ChainDesc d[CHAIN_BATCH_MAX]; };
+__global__ __launch_bounds__(256, 2) void mlp_chain128_x6_batch_kernel(ChainBatch b) { mlp_chain128_x6_body(b.d[blockIdx.y]); }
+
 bool mlp_chain128_fast(const ChainDesc& d) {
   if (wprep_image_floats() == 0 || d.n_layers < 1 || d.n_layers > CHAIN_MAX) return false;
   uintptr_t bits = (uintptr_t)d.x | (uintptr_t)d.in_dact | (uintptr_t)d.in_store;
@@ -546,6 +554,26 @@ bool mlp_chain128_fast(const ChainDesc& d) {
   return (bits & 15) == 0 && (lds & 3) == 0;
 }
 
+int mlp_chain128_batch_launch(const ChainDesc* d, int n, hipStream_t stream) {
+  if (n <= 0) return CGAT_OK;
+  bool same = n <= CHAIN_BATCH_MAX && bilinear_mode() != 2;
+  for (int i = 1; i < n; ++i) same = same && d[i].rows == d[0].rows;
+  if (!same || n == 1) {
+    for (int i = 0; i < n; ++i) CGAT_TRY(mlp_chain128_launch(d[i], stream));
+    return CGAT_OK;
+  }
+  if (d[0].rows <= 0) return CGAT_OK;
+  ChainBatch b;
+  for (int i = 0; i < n; ++i) {
+    CGAT_CHECK_ARG(mlp_chain128_fast(d[i]), "mlp_chain128: needs a split arithmetic mode, 1..%d layers and 16-byte aligned rows", CHAIN_MAX);
+    b.d[i] = d[i];
+  }
+  for (int i = n; i < CHAIN_BATCH_MAX; ++i) b.d[i] = d[0];
+  CGAT_PROF("mlp_chain", stream);
+  hipLaunchKernelGGL(mlp_chain128_x6_batch_kernel, dim3(cdiv(d[0].rows, 128), n), dim3(256), 0, stream, b);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
 int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream) {
   if (d.rows <= 0) return CGAT_OK;
   CGAT_CHECK_ARG(mlp_chain128_fast(d), "mlp_chain128: needs a split arithmetic mode, 1..%d layers and 16-byte aligned rows", CHAIN_MAX);

@@ -204,6 +204,9 @@ struct ChainDesc {
 int prepare_W_batch_launch(const WPrepBatch& b, float* dst, hipStream_t stream);   // the current mode's chain images
 bool mlp_chain128_fast(const ChainDesc& d);
 int mlp_chain128_launch(const ChainDesc& d, hipStream_t stream);
+#define CHAIN_BATCH_MAX 4
+// n independent chains over the same rows in one launch (24-bit modes; otherwise one launch each)
+int mlp_chain128_batch_launch(const ChainDesc* d, int n, hipStream_t stream);
 // ---- split-bf16 backward products over gZ, edgebwd.hip ----
 // The pre-activation gradient of the scalar-attention layer is never stored when its consumers can rebuild it
 // (edge_seg_bwd_kernel step 3, layers.hip): for destination-sorted slot t and column col of the stacked hidden layer

@@ -1317,20 +1317,20 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
     RUN(mix_launch(h0, v, p->damping, sv.hin(), (long)rows * W, c.s));
     hin = sv.hin();
   }
-  const float* vin = v;
-  for (int l = 0; l < p->n_hyper; ++l) {
-    const cgat_hyperlinear_params& L = p->layer[l];
-    float* u = c.dry ? nullptr : ((l == p->n_hyper - 1) ? y : sv.u(l));
-    const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
-    // The trunk (n_fc x [Linear + Tanh]) and the trunk-side linear term of the head, u = z @ U^T + b0, as ONE chain
-    // launch (chain.hip) when the weights of the pass have been prepared in a batch (f16x3 mode, width 128, <= 4 trunk
-    // layers); the remaining linear term u += vin @ Bm^T follows.  Bm = head_b[:W*W] as [o,i], U = head_w[W*W:]
-    bool chained = false;
-    if (batch_w && !c.dry && wprep_image_floats() != 0 && p->n_fc + 1 <= CHAIN_MAX) {
-      ChainDesc cd;
+  // The trunk (n_fc x [Linear + Tanh]) and the trunk-side linear term of the head, u = z @ U^T + b0, as ONE chain per
+  // predicted layer (chain.hip) when the weights of the pass have been prepared in a batch (width 128, <= 4 trunk layers)
+  // -- and, since every predicted layer's trunk reads the same hyper input, the chains of ALL predicted layers as ONE
+  // launch (round 5); the remaining linear term u += vin @ Bm^T follows per layer.  Bm = head_b[:W*W] as [o,i],
+  // U = head_w[W*W:]
+  bool chained_all = false;
+  if (batch_w && !c.dry && wprep_image_floats() != 0 && p->n_fc + 1 <= CHAIN_MAX && p->n_hyper <= CGAT_MAX_HYPER) {
+    ChainDesc cds[CGAT_MAX_HYPER];
+    bool ok = true;
+    for (int l = 0; l < p->n_hyper; ++l) {
+      const cgat_hyperlinear_params& L = p->layer[l];
+      ChainDesc& cd = cds[l];
       memset(&cd, 0, sizeof(cd));
       cd.n_layers = p->n_fc + 1; cd.rows = rows; cd.x = hin; cd.ldx = W;
-      bool ok = true;
       for (int s = 0; s < p->n_fc; ++s) {
         ChainLayer& cl = cd.layer[s];
         cl.W = (const uint4*)c.wprep_find(L.fc_w[s], W, 1);
@@ -1339,15 +1339,26 @@ static int hnet_forward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const 
       }
       ChainLayer& cu = cd.layer[p->n_fc];
       cu.W = (const uint4*)c.wprep_find(L.head_w + WW * W, W, 1);
-      cu.bias = L.head_b + WW; cu.act = CGAT_ACT_NONE; cu.out = u; cu.ld_out = W;
+      cu.bias = L.head_b + WW; cu.act = CGAT_ACT_NONE; cu.out = (l == p->n_hyper - 1) ? y : sv.u(l); cu.ld_out = W;
       ok = ok && cu.W && mlp_chain128_fast(cd);
-      if (ok) {
-        CGAT_TRY(mlp_chain128_launch(cd, c.s));
-        GemmParams g = gemm_params(rows, W, W, vin, W, L.head_b, W, u, W);
-        g.beta = 1.f;
-        CGAT_TRY(c.gemm(g));
-        chained = true;
-      }
+    }
+    if (ok) {
+      for (int l0 = 0; l0 < p->n_hyper; l0 += CHAIN_BATCH_MAX)
+        CGAT_TRY(mlp_chain128_batch_launch(cds + l0, p->n_hyper - l0 < CHAIN_BATCH_MAX ? p->n_hyper - l0 : CHAIN_BATCH_MAX, c.s));
+      chained_all = true;
+    }
+  }
+  const float* vin = v;
+  for (int l = 0; l < p->n_hyper; ++l) {
+    const cgat_hyperlinear_params& L = p->layer[l];
+    float* u = c.dry ? nullptr : ((l == p->n_hyper - 1) ? y : sv.u(l));
+    const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
+    bool chained = false;
+    if (chained_all) {
+      GemmParams g = gemm_params(rows, W, W, vin, W, L.head_b, W, u, W);
+      g.beta = 1.f;
+      CGAT_TRY(c.gemm(g));
+      chained = true;
     }
     if (!chained) {
       const float* t = hin;

@@ -67,7 +67,7 @@ __global__ void wgc_absmax_kernel(WgradPrepDesc d, int l0, long ldp, long ldq, l
   block_absmax_commit(m, mx + 4 * (l0 + layer) + which);
 }
 
-// One 64-row chunk of one layer per workgroup (256 threads), all three operands:
+// One 64-row chunk of one operand of one layer per workgroup (256 threads; blockIdx.z = operand):
 //  pT [128][rows_pad]      = (p * 2^k * sign(n))^T: 2^k from max|p| max|q| (the products must fit fp16), sign(n) = -1 in the
 //                            odd 512-row groups of n's row split (the kernel's partial sums alternate in sign)
 //  qF [chunk][wb 4][j 8][lane 64][4]  = q in the order a lane of wave wb consumes it: value i = 4 j + e of lane (r, hi)
@@ -81,9 +81,10 @@ __global__ __launch_bounds__(256) void wgc_prep_kernel(WgradPrepDesc d, int l0, 
                                                        const float* __restrict__ mx) {
   __shared__ float tile[64][129];
   const int layer = blockIdx.y, chunk = blockIdx.x, n0 = chunk * WGC_ROWS, tid = threadIdx.x;
+  const int which = blockIdx.z;      // 0 p, 1 q, 2 r: one operand per workgroup (three independent streams in flight per chunk)
   const float* mxl = mx + 4 * (l0 + layer);
   // ---- p: transpose, scale, sign ----
-  {
+  if (which == 0) {
     float spq, ipq;
     pow2_scale(mxl[0] * mxl[1], spq, ipq);
     if ((((n0 % rows_per_split) >> 6) >> 3) & 1) spq = -spq;       // a 64-row chunk never straddles a 512-row group
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void wgc_prep_kernel(WgradPrepDesc d, int l0, 
     __syncthreads();
   }
   // ---- q: fragment order ----
-  {
+  if (which == 1) {
     const float* q = d.q[layer];
     for (int i = tid; i < 64 * 128; i += 256) {
       const int n = i >> 7, c = i & 127;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void wgc_prep_kernel(WgradPrepDesc d, int l0, 
     __syncthreads();
   }
   // ---- r: fp16 planes + 6-bit images; thread = (column block, lane) ----
-  {
+  if (which == 2) {
     const float* rr = d.r[layer];
     float sr, ir;
     pow2_scale(mxl[2], sr, ir);
@@ -579,7 +580,7 @@ int wgradc_prep(int l0, int n, int n_layers, const float* const* p, long ldp, co
   hipLaunchKernelGGL(wgc_absmax_kernel, dim3(nrows < 2048 ? cdiv(nrows, 8) : 256, 3 * n), dim3(256), 0, stream, pd, l0, ldp,
                      ldq, ldr, nrows, NA, mx);
   CGAT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wgc_prep_kernel, dim3(np / WGC_ROWS, n), dim3(256), 0, stream, pd, l0, ldp, ldq, ldr, nrows, NA, np, rps,
+  hipLaunchKernelGGL(wgc_prep_kernel, dim3(np / WGC_ROWS, n, 3), dim3(256), 0, stream, pd, l0, ldp, ldq, ldr, nrows, NA, np, rps,
                      (float*)((char*)ws + o_pT), (float*)((char*)ws + o_qF), (unsigned char*)ws + o_Rs, (long)np * 128,
                      (long)(np / WGC_ROWS) * WGC_RS_B, (const float*)mx);
   CGAT_LAUNCH_CHECK();

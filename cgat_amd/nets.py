@@ -10,6 +10,7 @@ convention is applied through the batch's CSR plan: x_j = x[edge_index[0]], x_i 
 x[edge_index[1]], softmax and aggregation keyed by edge_index[1].
 """
 import itertools
+import os
 
 import torch
 import torch.nn as nn
@@ -431,7 +432,8 @@ class CGAtNet(nn.Module):
         # (per-layer fork / join: worth it inside a hipGraph, where it is a graph edge -- 13.76 -> 13.45 ms per replayed
         # 64-crystal step; in eager mode the eight extra stream switches cost more host time than the overlap returns)
         ebranch = (branch_stream(batch.x.device, edge_index.shape[1], which=1)
-                   if (branch is not None and torch.cuda.is_current_stream_capturing()) else None)
+                   if (branch is not None and torch.cuda.is_current_stream_capturing() and
+                       os.environ.get("CGAT_EDGE_BRANCH", "1") != "0") else None)
         for graph_func in self.graphs:
             edge = graph_func['Edge']
             shipped = edge.no_hyper and type(edge).forward is GATConvEdges.forward

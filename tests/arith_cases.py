@@ -32,10 +32,10 @@ def run_rows(_lib, ops, dev, rows=4096, seed=5):
     ref = torch.einsum("na,nb,abc->nc", p.double(), q.double(), T.double())
     den = torch.einsum("na,nb,abc->nc", p.double().abs(), q.double().abs(), T.double().abs())
     out = torch.empty(rows, W, device=dev)
-    ws = torch.empty(max(_lib.lib.cgat_bilinear_rows_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
     res = {}
     for mode in MODES:
         ops.set_bilinear_mode(mode)
+        ws = torch.empty(max(_lib.lib.cgat_bilinear_rows_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib.cgat_bilinear_rows(p.data_ptr(), W, q.data_ptr(), W, T.data_ptr(), None, W, out.data_ptr(), W, rows,
                                                W, W, W, ws.data_ptr(), ws.numel(), None), "bilinear_rows")
         torch.cuda.synchronize()
@@ -53,10 +53,10 @@ def run_dual(_lib, ops, dev, rows=4096, seed=6):
     r1, d1 = torch.einsum("na,nac->nc", p.double(), M), torch.einsum("na,nac->nc", p.double().abs(), Ma)
     r2, d2 = torch.einsum("nc,nac->na", z.double(), M), torch.einsum("nc,nac->na", z.double().abs(), Ma)
     o1, o2 = torch.empty(rows, W, device=dev), torch.empty(rows, W, device=dev)
-    ws = torch.empty(max(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), 256), dtype=torch.uint8, device=dev)
     res = {}
     for mode in MODES:
         ops.set_bilinear_mode(mode)
+        ws = torch.empty(max(_lib.lib.cgat_bilinear_dual_workspace_bytes(rows), 256), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib.cgat_bilinear_dual(p.data_ptr(), W, q.data_ptr(), W, z.data_ptr(), W, T.data_ptr(), None, W,
                                                o1.data_ptr(), W, None, W, o2.data_ptr(), W, rows, ws.data_ptr(), ws.numel(),
                                                None), "dual")
@@ -86,10 +86,10 @@ def run_wgrad(_lib, ops, dev, rows=4096, seed=7):
     ref = torch.einsum("na,nb,nc->abc", p.double(), q.double(), r.double())
     den = torch.einsum("na,nb,nc->abc", p.double().abs(), q.double().abs(), r.double().abs())
     out = torch.empty(W, W, W, device=dev)
-    ws = torch.empty(max(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
     res = {}
     for mode in MODES:
         ops.set_bilinear_mode(mode)
+        ws = torch.empty(max(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, W, W, W), 256), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib.cgat_bilinear_wgrad(p.data_ptr(), W, q.data_ptr(), W, r.data_ptr(), W, out.data_ptr(), rows, W, W, W,
                                                 ws.data_ptr(), ws.numel(), None), "wgrad")
         torch.cuda.synchronize()

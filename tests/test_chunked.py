@@ -205,6 +205,10 @@ def test_config5_bf16_edge_storage_vs_oracle():
     y32, g32 = run()
     P.set_edge_storage("bf16")
     try:
+        if P.get_bilinear_mode() == "f32":              # the diagnostic f32-MFMA mode has no bf16 form: it must refuse
+            with pytest.raises(RuntimeError, match="bf16"):
+                run()
+            return
         y16, g16 = run()
     finally:
         P.set_edge_storage("f32")
@@ -276,6 +280,10 @@ def test_bf16_edge_storage_at_1m_edges_matches_fp32_storage():
     a = run()
     P.set_edge_storage("bf16")
     try:
+        if P.get_bilinear_mode() == "f32":              # (no bf16 form in the diagnostic f32-MFMA mode: refused)
+            with pytest.raises(RuntimeError, match="bf16"):
+                run()
+            return
         c = run()
     finally:
         P.set_edge_storage("f32")

@@ -217,6 +217,35 @@ def test_bilinear_wgrad(env, W, rows, mode):
     assert rel(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("NA,rows", [(1, 200), (37, 1000), (128, 4097), (2, 70000)])
+@pytest.mark.parametrize("mode", ["bf16x6", "f16x3", "f16x3c"])
+def test_bilinear_wgrad_narrow_first_operand(env, NA, rows, mode):
+    """out[a,b,c] = sum_n p[n,a] q[n,b] r[n,c] with FEWER than 128 columns of p (an odd count leaves half of the last
+    workgroup's `a` pair empty; NA = 2 at 70 000 rows is one pair split over many row splits) and row counts that are not
+    multiples of the kernels' 64-row chunks; bitwise repeatable."""
+    _, _lib, ops, dev = env
+    ops.set_bilinear_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(NA * 7 + rows)
+        p = torch.randn(rows, NA, generator=g).to(dev)
+        q, r = (torch.randn(rows, 128, generator=g).to(dev) for _ in range(2))
+        out = torch.full((NA, 128, 128), float("nan"), device=dev)
+        ref = torch.einsum("na,nb,nc->abc", p.double(), q.double(), r.double())
+        ws = torch.empty(max(_lib.lib.cgat_bilinear_wgrad_workspace_bytes(rows, NA, 128, 128), 256), dtype=torch.uint8, device=dev)
+
+        def call():
+            _lib.check(_lib.lib.cgat_bilinear_wgrad(p.data_ptr(), NA, q.data_ptr(), 128, r.data_ptr(), 128, out.data_ptr(), rows,
+                                                    NA, 128, 128, ws.data_ptr(), ws.numel(), None), "bilinear_wgrad")
+            torch.cuda.synchronize()
+        call()
+        first = out.clone()
+        assert rel(out, ref) <= TOL
+        call()
+        assert torch.equal(first, out)
+    finally:
+        ops.set_bilinear_mode(ops.DEFAULT_MODE)
+
+
 @pytest.mark.parametrize("W,rows", [(128, 257), (16, 33), (100, 5)])
 def test_layernorm_tanh(env, W, rows):
     _, _lib, ops, dev = env
