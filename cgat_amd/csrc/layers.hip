@@ -33,7 +33,10 @@ struct Ctx {
   void tprep_add(const float* W, long so, long sk) {
     if (tprep.n < WPREP_MAX) { tprep.src[tprep.n] = W; tprep.sb[tprep.n] = sk; tprep.sc[tprep.n] = so; ++tprep.n; }
   }
-  static bool tprep_mode() { return bilinear_mode() == 4 || bilinear_mode() == 6; }
+  static bool tprep_mode() {   // CGAT_NO_TPREP=1: prepare per product, as before round 5 (A/B switch)
+    static const bool off = [] { const char* e = getenv("CGAT_NO_TPREP"); return e && e[0] == '1'; }();
+    return !off && (bilinear_mode() == 4 || bilinear_mode() == 6);
+  }
   int tprep_run() {
     if (dry || !tprep_mode() || tprep.n == 0 || !tprep_images) { if (!tprep_mode()) tprep.n = 0; return CGAT_OK; }
     return prepare_T_bf16_batch_launch(tprep, tprep_images, s);

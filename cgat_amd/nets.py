@@ -437,21 +437,24 @@ class CGAtNet(nn.Module):
         for graph_func in self.graphs:
             edge = graph_func['Edge']
             shipped = edge.no_hyper and type(edge).forward is GATConvEdges.forward
+            # shipped form: Edge(...) = Pooling_NN(edge_attr) (its attention is dead code, CGAT.py:224-225); the residual
+            # add of CGAT.py:582 rides in the same launch.  It is issued BEFORE the node update in every execution mode --
+            # on the edge branch stream where there is one -- so that the autograd nodes are created in the same order
+            # eagerly and under capture: edge_attr receives three gradient contributions, and the order in which the
+            # engine adds them follows the nodes' sequence numbers (a replayed graph is bit-equal to the eager step)
             if shipped and ebranch is not None:
-                # small batches: the edge update (a function of edge_attr alone) runs beside the node update
                 ebranch.wait_stream(main)
                 with torch.cuda.stream(ebranch):
                     new_edge_attr = edge.Pooling_NN(edge_attr, residual=edge_attr)
+            elif shipped:
+                new_edge_attr = edge.Pooling_NN(edge_attr, residual=edge_attr)
             node_update = graph_func['Node'](elem_fea, edge_index, edge_attr, elem_fea_0)
             if shipped and ebranch is not None:
                 main.wait_stream(ebranch)
                 new_edge_attr.record_stream(main)
                 edge_attr.record_stream(ebranch)
+            if shipped:
                 edge_attr = new_edge_attr
-            elif shipped:
-                # shipped form: Edge(...) = Pooling_NN(edge_attr) (its attention is dead code, CGAT.py:224-225); the
-                # residual add of CGAT.py:582 rides in the same launch
-                edge_attr = edge.Pooling_NN(edge_attr, residual=edge_attr)
             else:
                 edge_attr = edge_attr + edge(elem_fea, edge_index, edge_attr, edge_attr_0)
             elem_fea = elem_fea + node_update

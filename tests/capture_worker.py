@@ -96,6 +96,11 @@ def test_graphed_stack_step_equals_eager_bitwise():
         y = gs.replay()
         torch.cuda.synchronize()
         got = [y] + [p.grad for p in params]
+        names = ["out"] + [n for n, _ in net.named_parameters()]
+        bad = [(n, float((a - w).abs().max()), float(w.abs().max())) for n, a, w in zip(names, got, want)
+               if a is not None and w is not None and not torch.equal(a, w)]
+        if bad:
+            print("GRAPH != EAGER on", len(bad), "tensors; first:", bad[:8], flush=True)
         for a, w in zip(got, want):
             assert (a is None) == (w is None)
             if a is not None:
