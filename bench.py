@@ -834,7 +834,7 @@ def main():
     # ---- extra legs (N = 1, after the timed region, never part of `value`): the same step in the two arithmetic modes
     # whose operands carry >= 24 significand bits, and the full 4-layer stack of BASELINE configs[2] ----
     mode = P.get_bilinear_mode()
-    modes_ms, stack_ms = {mode: 1e3 * elapsed / args.steps}, None
+    modes_ms, stack_ms, side_ms = {mode: 1e3 * elapsed / args.steps}, None, None
     if world == 1 and not args.no_extra_legs and args.workload == "layer" and K_used == K_NBR:
         del step
         torch.cuda.empty_cache()
@@ -858,6 +858,18 @@ def main():
             except Exception as ex:                        # a failed leg must not take the headline down with it
                 modes_ms[m] = None
                 sys.stderr.write(f"bench.py: mode leg {m} failed: {ex}\n")
+        # the same timed region in THIS mode with the weight-gradient launch on the side stream (opt-in in the 24-bit
+        # modes, cgat_amd/ops.py: it halves the chip for the dominant kernel's launch) -- informational, never `value`
+        if not ops.overlap_enabled():
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", str(args.steps), "--warmup",
+                   str(args.warmup), "--graphs", str(args.graphs), "--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                                   env=dict(os.environ, CGAT_OVERLAP_WGRAD="1"))
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                side_ms = float(json.loads(line)["ms_per_step"])
+            except Exception as ex:
+                sys.stderr.write(f"bench.py: side-stream leg failed: {ex}\n")
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -1093,6 +1105,13 @@ def main():
                                     "f16x3c and bf16x6 carry 24-bit operands, f16x3 22-bit, f32 is the f32-input MFMA",
                             **{m: (round(v, 3) if v is not None else None) for m, v in modes_ms.items()},
                             "edges_per_s": {m: (round(E / (v * 1e-3), 1) if v else None) for m, v in modes_ms.items()}}
+            if side_ms is not None:
+                out["side_stream"] = {"ms_per_step": round(side_ms, 3), "edges_per_s": round(E / (side_ms * 1e-3), 1),
+                                      "what": "the same timed region, same arithmetic, fresh child process with "
+                                              "CGAT_OVERLAP_WGRAD=1: the batched weight-gradient launch on a side stream on "
+                                              "half of the chip beside the HBM-bound attention backward.  Not `value`: in "
+                                              "that order the dominant kernel's launch duration is shared, and `roofline` "
+                                              "would not be a statement about the kernel"}
             if stack_ms is not None:
                 out["stack_fwd_bwd_ms"] = {"ms_per_step": round(stack_ms, 2), "batch_edges_per_s": round(E / (stack_ms * 1e-3), 1),
                                            "edge_layer_passes_per_s": round(4 * E / (stack_ms * 1e-3), 1),

@@ -1725,11 +1725,16 @@ extern "C" int cgat_hnet_backward_overlapped(int32_t rows, const cgat_hnet_param
     side_wgs = e ? atoi(e) : 128;
     if (side_wgs < 8 || side_wgs > 256) side_wgs = 128;
   }
-  static int dw_side = -1;
-  if (dw_side < 0) {
-    const char* e = getenv("CGAT_SIDE_DW");   // default: main stream (behind the dT launch on the side stream the batch
-    dw_side = (e && e[0] == '1') ? 1 : 0;     // collided with the matrix-bound edge_ge: 24.14 vs 23.95 ms per step)
+  // the batched dense-layer weight gradients: f16x3 -- main stream (behind the dT launch on the side stream the batch
+  // collided with the matrix-bound edge_ge: 24.14 vs 23.95 ms per step); f16x3c -- side stream (the 24-bit dT launch is
+  // twice as long and still running when edge_ge starts either way: 29.0-29.4 vs 29.5 ms, serial order 29.9-30.0;
+  // tools/side_stream_sweep.sh, profiles/r05_side_stream_sweep.txt).  CGAT_SIDE_DW=0/1 overrides.
+  static int dw_env = -2;
+  if (dw_env == -2) {
+    const char* e = getenv("CGAT_SIDE_DW");
+    dw_env = e ? ((e[0] == '1') ? 1 : 0) : -1;
   }
+  const int dw_side = dw_env >= 0 ? dw_env : (bilinear_mode() == 4 ? 1 : 0);
   HnetSide side = {(hipStream_t)side_stream, side_ws, side_ws_bytes, side_wgs, dw_side};
   return hnet_backward_impl(c, rows, p, h0, v, saved, g_y, g_h0, g_v, g, &side);
 }

@@ -537,7 +537,10 @@ __global__ void wgc_slab_sum_kernel(const float* __restrict__ slab, int splits, 
 // a split is a whole number of 512-row sign groups unless it is the only one
 int wgradc_pick(int n_layers, int nrows, int NA, int* rps_out) {
   const int npairs = cdiv(NA, 2), np = cdiv(nrows, WGC_ROWS) * WGC_ROWS;
-  int splits = 256 / (n_layers * npairs);
+  // work units (layer x row split x pair of a) ~ one per CU; CGAT_WGC_UNITS: tuning knob for the side-stream launch,
+  // where units finer than the launch's workgroups balance a grid that is not a divisor of 256
+  static const int target = [] { const char* e = getenv("CGAT_WGC_UNITS"); const int v = e ? atoi(e) : 256; return v >= 64 && v <= 2048 ? v : 256; }();
+  int splits = target / (n_layers * npairs);
   if (splits > np / 256) splits = np / 256;
   if (splits < 1) splits = 1;
   int rps = cdiv(np / WGC_ROWS, splits) * WGC_ROWS;

@@ -311,11 +311,15 @@ def _hnet_struct(cls, W, n_fc, n_hyper, flat, damping):
 
 # Side stream for the hypernetwork's weight-gradient contractions (cgat_hnet_backward_overlapped, used by NodeLayerFn):
 # they are off the critical path of the backward pass and matrix-core bound, the attention backward is HBM bound.
-# Decided by timeline per arithmetic mode (round 4): in the 22-bit "f16x3" mode the overlap is worth 0.5 ms of a 23.9 ms
-# step (the batched dT launch on half of the chip beside the HBM-bound attention backward); in the 24-bit modes the
-# weight-gradient contractions are two to four times as long as the kernels they would run beside and same-box A/Bs
-# measure nothing (33.13 / 33.12 ms with, 33.04 / 33.08 without the side stream): the default there is the serial order
-# (every kernel alone on the chip).  CGAT_OVERLAP_WGRAD=0/1 or set_overlap_wgrad() override.
+# Decided by same-box A/Bs per arithmetic mode: in the 22-bit "f16x3" mode the overlap is worth 0.5 ms of a 23.9 ms step
+# (the batched dT launch on half of the chip beside the HBM-bound attention backward) and is the default.  In the default
+# 24-bit "f16x3c" mode, since its dT is ONE batched launch (round 5), it is worth 0.5-0.9 ms of 30.0 (29.0-29.5 vs
+# 29.9-30.0 ms: the HBM-bound segment backward, source-side sums and dense weight gradients lose little on the other half
+# of the chip; profiles/r05_side_stream_sweep.txt) -- opt-in there (CGAT_OVERLAP_WGRAD=1 / set_overlap_wgrad(True)): on
+# half of the chip the dominant kernel's launch takes 8.2-8.8 ms instead of 4.6, and the step's per-kernel durations --
+# the bench line's roofline, the rocprof statistics -- stop being statements about the kernels; the default keeps every
+# kernel alone on the chip.  "bf16x6" (four six-pass dT launches, two to four times as long as the kernels they would
+# run beside) gains nothing: 33.13 / 33.12 ms with, 33.04 / 33.08 without.
 _side_streams = {}
 _overlap_wgrad = {"0": False, "1": True}.get(os.environ.get("CGAT_OVERLAP_WGRAD", ""), None)
 
