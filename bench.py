@@ -998,7 +998,8 @@ def main():
                 gbs = nbytes / (ms_t / args.steps * 1e-3) / 1e9      # bytes of the step / the tag's time in the step
                 # counter bytes of one step for the tag (builder-collected rocprofv3 --pmc passes, profiles/): the largest
                 # launch of each kernel name = the per-edge launch at the headline batch; only valid for that batch
-                kn = {"edge_z": ("edge_zx_kernel",) if mode == "f16x3" else ("edge_z_kernel",),
+                kn = {"edge_z": ("edge_zx_kernel",) if mode == "f16x3" else
+                                ("edge_z6w_kernel",) if mode in ("f16x3c", "bf16x6") else ("edge_z_kernel",),
                       "edge_seg_bwd": ("edge_seg_bwd_kernel",) if mode == "f16x3" else
                                       ("seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel")}[tag]
                 tb = traffic.get("hbm_bound_kernels", {}) if (args.workload == "layer" and args.graphs == GRAPHS and

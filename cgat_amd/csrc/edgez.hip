@@ -602,6 +602,232 @@ __global__ __launch_bounds__(512, 2) void edge_zc_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// The six-pass per-edge launch on edge_zc_kernel's skeleton (round 5): the SAME arithmetic as edge_z_kernel<6, true>
+// -- three bf16 planes per operand, the six products in the same order, even / odd k-steps into the two accumulator sets,
+// the same epilogue order: bit-identical Z and logits -- with what made the f16x3c form faster although the matrix work was
+// never its bound: 256-row workgroups (half the weight traffic through the ring per row), the gathered addends of the
+// NEXT 32-column chunk requested a whole chunk of matrix work before their use into registers the 32-column
+// granularity frees, and counted waits that never wait for a store (derivation at edge_zc_kernel).
+// Operand: prepare_T_bf16's image as it is (12-KB k-step chunks (a, half, s) = [plane][cb][lane] x 16 B); a ring chunk
+// here is (a, half, pair of 16-column blocks) = 24 one-KB pieces [s][plane][cb2] picked out of four of those, three per
+// wave.  LDS: 4 slots x 24 KB + fc_out_A's weight.
+// ---------------------------------------------------------------------------------------
+template <bool ZB>
+__global__ __launch_bounds__(512, 2) void edge_z6w_kernel(const float* __restrict__ e, long lde, const int* __restrict__ perm,
+                                                          const uint4* __restrict__ Wq, int ncb,
+                                                          const float* __restrict__ Pi, const int* __restrict__ dsti,
+                                                          const float* __restrict__ Pj, const int* __restrict__ srci,
+                                                          long ld_add, float* __restrict__ Z, long ldz, int E,
+                                                          const float* __restrict__ wA, const float* __restrict__ bA,
+                                                          int H, int cb_per_head, float* __restrict__ a_out, int act,
+                                                          float* __restrict__ omax) {
+  constexpr int CH = 24 * 64;                         // 16-byte pieces per ring chunk (24 KB)
+  constexpr int SLOTS = 4;
+  __shared__ uint4 smem[SLOTS * CH + 512];            // the ring + fc_out_A's weight (<= 2048 floats)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int row_w = blockIdx.x * 256 + wave * 32;
+  const int row_a = row_w + n16, row_b = row_w + 16 + n16;
+  const int rca = row_a < E ? row_a : E - 1, rcb = row_b < E ? row_b : E - 1;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const bf16x8* ring = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const unsigned l_off = (unsigned)lane * 16;
+  const long last_chunk = (long)ncb * 4 - 1;
+  // this wave's three pieces pc = 3 wave + i of a chunk: (s, plane, cb2) = (pc / 6, (pc % 6) / 2, pc % 2); source offset
+  // inside the (a, half) group of four k-step chunks in 16-byte units, destination offset inside the slot in bytes
+  int psrc[3];
+  unsigned pdst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int pc = 3 * wave_u + i, s4 = pc / 6, pl = (pc % 6) >> 1, c2 = pc & 1;
+    psrc[i] = s4 * 768 + pl * 256 + c2 * 64;
+    pdst[i] = __builtin_amdgcn_readfirstlane(sbase + (unsigned)pc * 1024);
+  }
+
+  // the lane's two edge rows, split once: q[plane][2 s + nb] holds e[row(nb), 32 s + 8 kg + 0..7]; odd k-steps negated
+  bf16x8 q1[8], q2[8], q3[8];
+  {
+    const long ea = perm ? perm[rca] : rca, eb = perm ? perm[rcb] : rcb;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float4* qp = reinterpret_cast<const float4*>(e + (nb ? eb : ea) * lde + 32 * s4 + 8 * kg);
+        const float4 t0 = qp[0], t1 = qp[1];
+        const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        split3_x8(v, q1[2 * s4 + nb], q2[2 * s4 + nb], q3[2 * s4 + nb]);
+        if (s4 & 1) {
+          q1[2 * s4 + nb] = neg_x8(q1[2 * s4 + nb]);
+          q2[2 * s4 + nb] = neg_x8(q2[2 * s4 + nb]);
+          q3[2 * s4 + nb] = neg_x8(q3[2 * s4 + nb]);
+        }
+      }
+  }
+  // gathered rows as 32-bit byte offsets from Pi / Pj (< 4 GB: checked by the launcher)
+  const unsigned oia = (unsigned)(((long)dsti[rca] * ld_add + 4 * kg) * 4), oib = (unsigned)(((long)dsti[rcb] * ld_add + 4 * kg) * 4);
+  const unsigned oja = (unsigned)(((long)srci[rca] * ld_add + 4 * kg) * 4), ojb = (unsigned)(((long)srci[rcb] * ld_add + 4 * kg) * 4);
+  const int ncbA = (a_out && wA) ? H * cb_per_head : 0;      // column blocks that belong to the attention network
+  float* wAs = reinterpret_cast<float*>(smem + SLOTS * CH);
+  for (int i = tid; i < ncbA * 128; i += 512) wAs[i] = wA[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // chunk gi = 4 a + ch, ch = 2 half + pair: its 24 pieces live at Wq + ((2 a + half) * 4) * 768 + pair * 128 + psrc
+#define Z6_TLOAD(gi_)                                                                          \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const uint4* tb = Wq + (gi >> 1) * (4 * 768) + (gi & 1) * 128;                             \
+    const unsigned so = (unsigned)((gi_) & 3) * (CH * 16);                                     \
+    glds_b128(tb + psrc[0], l_off, pdst[0] + so);                                              \
+    glds_b128(tb + psrc[1], l_off, pdst[1] + so);                                              \
+    glds_b128(tb + psrc[2], l_off, pdst[2] + so);                                              \
+  }
+#define Z6_GATHER(G_, gi_)                                                                     \
+  {                                                                                            \
+    const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
+    const unsigned cbyte = (unsigned)(((gi >> 2) * 128 + ((gi >> 1) & 1) * 64 + (gi & 1) * 32) * 4); \
+    _Pragma("unroll") for (int cb2 = 0; cb2 < 2; ++cb2) {                                      \
+      asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %9\n\t"      \
+                   "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %9"          \
+                   : "=&v"(G_[4 * cb2 + 0]), "=&v"(G_[4 * cb2 + 1]), "=&v"(G_[4 * cb2 + 2]), "=&v"(G_[4 * cb2 + 3]) \
+                   : "v"(oia + cbyte + 64 * cb2), "v"(oja + cbyte + 64 * cb2), "v"(oib + cbyte + 64 * cb2),  \
+                     "v"(ojb + cbyte + 64 * cb2), "s"(Pi), "s"(Pj)                             \
+                   : "memory");                                                                \
+    }                                                                                          \
+  }
+  f32x4 GA[8], GB[8];
+  Z6_TLOAD(0l);
+  Z6_TLOAD(1l);
+  Z6_TLOAD(2l);
+  Z6_GATHER(GA, 0l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa1, fa2, fa3, fb1, fb2, fb3;
+  // group g = 2 s + cb2: the three planes of 16-column block cb2 at k-step s
+#define Z6_READ(F1_, F2_, F3_, slot_, g_)                                                      \
+  {                                                                                            \
+    const bf16x8* fp = ring + (slot_) * CH + (((g_) >> 1) * 6 + ((g_) & 1)) * 64;              \
+    F1_ = fp[0];                                                                               \
+    F2_ = fp[2 * 64];                                                                          \
+    F3_ = fp[4 * 64];                                                                          \
+  }
+  // even k-steps into part, odd ones (negated row fragments) into partn; the six products in edge_z_kernel's order
+#define Z6_MFMA(F1_, F2_, F3_, g_)                                                             \
+  {                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
+      f32x4& P_ = (((g_) >> 1) & 1) ? partn[2 * ((g_) & 1) + nb] : part[2 * ((g_) & 1) + nb];  \
+      const int qi_ = 2 * ((g_) >> 1) + nb;                                                    \
+      P_ = mma16<false>(F3_, q1[qi_], P_);                                                     \
+      P_ = mma16<false>(F1_, q3[qi_], P_);                                                     \
+      P_ = mma16<false>(F2_, q2[qi_], P_);                                                     \
+      P_ = mma16<false>(F2_, q1[qi_], P_);                                                     \
+      P_ = mma16<false>(F1_, q2[qi_], P_);                                                     \
+      P_ = mma16<false>(F1_, q1[qi_], P_);                                                     \
+    }                                                                                          \
+  }
+  // epilogue of chunk (a_, ch_): z = (part - partn) + gathered addends; store; logits
+#define Z6_EPILOGUE(G_, a_, ch_)                                                               \
+  {                                                                                            \
+    asm volatile("" : "+v"(G_[0]), "+v"(G_[1]), "+v"(G_[2]), "+v"(G_[3]), "+v"(G_[4]), "+v"(G_[5]), "+v"(G_[6]), "+v"(G_[7])); \
+    int ra_ = rca, rb_ = rcb, lk_ = lane;   /* laundered: the 64-bit row addresses are formed HERE, not kept (a scratch \
+                                              reload in this loop waits vmcnt(0), i.e. for every store) */                \
+    asm volatile("" : "+v"(ra_), "+v"(rb_), "+v"(lk_));                                        \
+    const int col0 = (a_) * 128 + ((ch_) >> 1) * 64 + ((ch_) & 1) * 32 + 4 * (lk_ >> 4);       \
+    const bool isA = (a_) < ncbA;                                                              \
+    _Pragma("unroll") for (int cb2 = 0; cb2 < 2; ++cb2) {                                      \
+      const int col = col0 + 16 * cb2;                                                         \
+      const f32x4 pa = part[2 * cb2 + 0] - partn[2 * cb2 + 0], pb = part[2 * cb2 + 1] - partn[2 * cb2 + 1]; \
+      const f32x4 ia = G_[4 * cb2 + 0], ja = G_[4 * cb2 + 1], ib = G_[4 * cb2 + 2], jb = G_[4 * cb2 + 3]; \
+      float4 va = make_float4(pa[0] + ia[0] + ja[0], pa[1] + ia[1] + ja[1], pa[2] + ia[2] + ja[2], pa[3] + ia[3] + ja[3]); \
+      float4 vb = make_float4(pb[0] + ib[0] + jb[0], pb[1] + ib[1] + jb[1], pb[2] + ib[2] + jb[2], pb[3] + ib[3] + jb[3]); \
+      if (act == CGAT_ACT_LEAKY) {   /* (kernel argument: uniform) the hidden activations instead of the pre-activations */ \
+        va = make_float4(va.x > 0.f ? va.x : 0.01f * va.x, va.y > 0.f ? va.y : 0.01f * va.y,   \
+                         va.z > 0.f ? va.z : 0.01f * va.z, va.w > 0.f ? va.w : 0.01f * va.w);  \
+        vb = make_float4(vb.x > 0.f ? vb.x : 0.01f * vb.x, vb.y > 0.f ? vb.y : 0.01f * vb.y,   \
+                         vb.z > 0.f ? vb.z : 0.01f * vb.z, vb.w > 0.f ? vb.w : 0.01f * vb.w);  \
+      }                                                                                        \
+      if constexpr (ZB) {                                                                      \
+        store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)ra_ * ldz + col, va);                 \
+        store4_bf16(reinterpret_cast<__bf16*>(Z) + (long)rb_ * ldz + col, vb);                 \
+      } else {                                                                                 \
+        *reinterpret_cast<float4*>(Z + (long)ra_ * ldz + col) = va;                            \
+        *reinterpret_cast<float4*>(Z + (long)rb_ * ldz + col) = vb;                            \
+      }                                                                                        \
+      if (omax) {   /* (kernel argument: uniform) max |stored value|; dot_b is free in a launch without logits */ \
+        dot_b = fmaxf(fmaxf(dot_b, fmaxf(fabsf(va.x), fabsf(va.y))), fmaxf(fabsf(va.z), fabsf(va.w))); \
+        dot_b = fmaxf(fmaxf(dot_b, fmaxf(fabsf(vb.x), fabsf(vb.y))), fmaxf(fabsf(vb.z), fabsf(vb.w))); \
+      }                                                                                        \
+      if (isA) {                                                                               \
+        const float4 w = *reinterpret_cast<const float4*>(wAs + col);                          \
+        dot_a += (va.x > 0.f ? va.x : 0.01f * va.x) * w.x + (va.y > 0.f ? va.y : 0.01f * va.y) * w.y + \
+                 (va.z > 0.f ? va.z : 0.01f * va.z) * w.z + (va.w > 0.f ? va.w : 0.01f * va.w) * w.w; \
+        asm volatile("" : "+v"(dot_a));   /* keep the two accumulations apart: see the note on packed math above */ \
+        dot_b += (vb.x > 0.f ? vb.x : 0.01f * vb.x) * w.x + (vb.y > 0.f ? vb.y : 0.01f * vb.y) * w.y + \
+                 (vb.z > 0.f ? vb.z : 0.01f * vb.z) * w.z + (vb.w > 0.f ? vb.w : 0.01f * vb.w) * w.w; \
+        asm volatile("" : "+v"(dot_b));                                                        \
+      }                                                                                        \
+    }                                                                                          \
+    if (isA && (ch_) == 3 && ((a_) + 1) % cb_per_head == 0) {   /* a head is complete: reduce over the 4 lane groups */ \
+      const int h = (a_) / cb_per_head;                                                        \
+      float da = dot_a, db = dot_b;                                                            \
+      da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);                              \
+      db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);                              \
+      if ((lk_ >> 4) == 0) {   /* (clamped rows rewrite row E - 1's logits with identical values) */ \
+        const float bh = bA ? bA[h] : 0.f;                                                     \
+        a_out[(long)ra_ * H + h] = da + bh;                                                    \
+        a_out[(long)rb_ * H + h] = db + bh;                                                    \
+      }                                                                                        \
+      dot_a = 0.f; dot_b = 0.f;                                                                \
+    }                                                                                          \
+  }
+  // one chunk: ring prefetch, the next chunk's gathers, 8 groups of 12 matrix instructions (every fragment read one
+  // group ahead), the counted wait, the epilogue, the barrier
+#define Z6_CHUNK(a_, ch_, GCUR_, GNEXT_)                                                       \
+  {                                                                                            \
+    constexpr int sl_ = (ch_), sn_ = ((ch_) + 1) & 3;   /* ring slot = chunk index mod 4 = ch_ */ \
+    Z6_TLOAD((long)(a_) * 4 + (ch_) + 3);                                                      \
+    Z6_GATHER(GNEXT_, (long)(a_) * 4 + (ch_) + 1);                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { part[i] = f32x4{0.f, 0.f, 0.f, 0.f}; partn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+    _Pragma("unroll") for (int gp = 0; gp < 4; ++gp) {                                         \
+      Z6_READ(fb1, fb2, fb3, sl_, 2 * gp + 1);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      Z6_MFMA(fa1, fa2, fa3, 2 * gp);                                                          \
+      if (gp < 3) Z6_READ(fa1, fa2, fa3, sl_, 2 * gp + 2)                                      \
+      else Z6_READ(fa1, fa2, fa3, sn_, 0);                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      Z6_MFMA(fb1, fb2, fb3, 2 * gp + 1);                                                      \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    /* gathers of THIS chunk (issued one iteration ago): younger are the 4 stores of the previous chunk and this       \
+       iteration's 3 pieces + 8 gathers; the ring needs nothing more (chunk i + 2's pieces are older still) */          \
+    wait_vmcnt<15>();                                                                          \
+    Z6_EPILOGUE(GCUR_, a_, ch_)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("" ::: "memory");                                                             \
+  }
+  Z6_READ(fa1, fa2, fa3, 0, 0);
+  f32x4 part[4], partn[4];
+  float dot_a = 0.f, dot_b = 0.f;
+  for (int a = 0; a < ncb; ++a) {
+    Z6_CHUNK(a, 0, GA, GB)
+    Z6_CHUNK(a, 1, GB, GA)
+    Z6_CHUNK(a, 2, GA, GB)
+    Z6_CHUNK(a, 3, GB, GA)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (omax) block_absmax_commit(dot_b, omax);
+#undef Z6_TLOAD
+#undef Z6_GATHER
+#undef Z6_READ
+#undef Z6_MFMA
+#undef Z6_EPILOGUE
+#undef Z6_CHUNK
+}
+
+// ---------------------------------------------------------------------------------------
 // The per-edge launch with the x_j projection folded in (f16x3 arithmetic):
 //     Z[t, :] = [W_e | W_j] [e[perm[t]] ; x[src[t]]] + Pi[dst[t], :]
 // Why, and what bounds these kernels: timing-only ablations (tools/edgez_ablation.sh; E = 1 000 080)
@@ -927,6 +1153,10 @@ size_t edge_z_wq_floats(int W2) {
 // not worth the margin, so the default per-edge forward stays the six-pass kernel.  What the experiment established
 // (tools/edgezc_ablate.sh): this launch is bound by its memory path, not by the matrix cores -- without the Z stores
 // 1.86 ms, without the gathers 2.22, without both 1.42, without any matrix instruction still 2.83.
+static bool edge_z6w_on() {   // CGAT_EDGE_Z6W=0: the 128-row form of the six-pass per-edge launch (A/B switch)
+  static const bool on = [] { const char* e = getenv("CGAT_EDGE_Z6W"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static bool edge_zc_on() {
   static const bool on = [] { const char* e = getenv("CGAT_EDGE_ZC"); return e && e[0] == '1'; }();
   return on;
@@ -962,6 +1192,19 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   if (bilinear_mode() == 2) CGAT_TRY(prepare_W_f16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, stream));
   else CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
   CGAT_PROF(Pj ? "edge_z" : "edge_proj", stream);   // the per-edge launch / the per-node projections
+  // the six-pass per-edge launch on 256-row workgroups (edge_z6w_kernel: same arithmetic, bit-identical results)
+  if ((bilinear_mode() == 4 || bilinear_mode() == 6) && Pj != nullptr && perm && (act == CGAT_ACT_NONE || act == CGAT_ACT_LEAKY) &&
+      !(omax && a_out) && edge_z6w_on() &&   // (the running maximum shares a register with the logits)
+      (!a_out || (long)H * Hd <= 2048) && n_add_rows > 0 && (long)n_add_rows * 4 * ld_add < (1l << 32)) {
+    if (z_bf16)
+      hipLaunchKernelGGL(edge_z6w_kernel<true>, dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi,
+                         dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, omax);
+    else
+      hipLaunchKernelGGL(edge_z6w_kernel<false>, dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi,
+                         dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, omax);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   const int grid = cdiv(E, 128);
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \

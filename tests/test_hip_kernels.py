@@ -822,3 +822,25 @@ def test_f16x3_row_and_tensor_scales(env, mode):
         assert float(((y.double() - refy).abs().amax(1) / refy.abs().amax(1)).max()) <= TOL
     finally:
         ops.set_bilinear_mode(ops.DEFAULT_MODE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,storage", [("f16x3c", "f32"), ("bf16x6", "f32"), ("f16x3c", "bf16")])
+def test_per_edge_forward_wide_tile_is_bit_identical(mode, storage):
+    """The six-pass per-edge forward on 256-row workgroups (csrc/edgez.hip edge_z6w_kernel: ring chunks of 32 columns, the
+    next chunk's gathered addends prefetched, counted waits) is the 128-row kernel's arithmetic in another order of memory
+    operations: saved Z / coefficients / weighted sums, output and every gradient must be BIT-identical between the two
+    forms (tests/edgez_worker.py in two child processes: the library reads CGAT_EDGE_Z6W once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for form in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "edgez_worker.py"), mode, storage, "61"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, CGAT_EDGE_Z6W=form))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        got[form] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][-1][7:])
+    assert got["1"]["E"] % 256 != 0 and len(got["1"]["saved"]) >= 1
+    assert got["1"] == got["0"], (got["1"], got["0"])

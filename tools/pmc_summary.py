@@ -51,7 +51,7 @@ alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           #
        "bilinear_wgrad128_f16c_kernel": 4 * (2 * N * C * 4 + (N // 64 + 1) * 51200 + C ** 3 * 4)}
 # HBM-bound kernels of the edge phase (bench.py hbm_bound_kernels: the fraction of 8 TB/s from COUNTER bytes): reported as
 # measured, no algorithmic figure here (bench.py holds it)
-HBM_KERNELS = ("edge_z_kernel", "edge_zx_kernel", "seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel",
+HBM_KERNELS = ("edge_z_kernel", "edge_z6w_kernel", "edge_zx_kernel", "seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel",
                "edge_seg_bwd_kernel", "seg_wsum_vec_kernel", "seg_softmax_fwd_kernel", "edge_gj_kernel", "edge_ge_kernel",
                "edge_gw_kernel", "mlp_chain128_x6_kernel", "rows_dw128_split_batch_kernel")
 import subprocess

@@ -9,7 +9,8 @@ src, dst = sys.argv[1], sys.argv[2]
 path = sorted(glob.glob(src + "/*/*_kernel_trace.csv"))[0]
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"])
              for r in csv.DictReader(open(path))), key=lambda e: e[0])
-first = [i for i, e in enumerate(ev) if e[2].startswith("void edge_z_kernel<6, true") or e[2].startswith("void edge_zx_kernel")]
+first = [i for i, e in enumerate(ev) if e[2].startswith("void edge_z_kernel<6, true") or e[2].startswith("void edge_z6w_kernel")
+         or e[2].startswith("void edge_zx_kernel")]
 assert len(first) >= 3, "needs at least three steps in the trace"
 a, b = first[-2], first[-1]
 step = ev[a:b]
