@@ -532,8 +532,11 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifndef RC_ABL
+#define RC_ABL 0   // timing-only ablations (wrong results; tools/rc_ablate.sh): 1 no LDS-DMA, 2 no fragment reads, 4 no matrix
+#endif             // instructions, 8 no flush, 16 no wait + barrier per chunk
 #define RC_TLOAD(gi_)                                                                          \
-  {                                                                                            \
+  { if (!(RC_ABL & 1)) {                                                                         \
     const long gi = (gi_) < last_chunk ? (gi_) : last_chunk;                                   \
     const uint4* tb = Tq + gi * CH16;                                                          \
     const unsigned dst = wave_t + (unsigned)((gi_) & 3) * (CH16 * 16);                         \
@@ -541,12 +544,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
     glds_b128(tb + 512, t_off, dst + 8192);                                                    \
     glds_b128(tb + 1024, t_off, dst + 16384);                                                  \
     if (wave_u == 0) glds_b128(tb + 1536, t_off, dst + 24576);                                 \
-  }
+  } }
 #define RC_PLOAD(a_)                                                                           \
-  {                                                                                            \
+  { if (!(RC_ABL & 1)) {                                                                         \
     const int aa = (a_) < a_end ? (a_) : a_end - 1;                                            \
     glds_b32(p + aa, prow_off, wave_p + (unsigned)((a_) & 3) * (PST * 4));                     \
-  }
+  } }
   // everything except the N_ youngest vector-memory operations of this wave (wave 0: + its extra piece) has landed
 #define RC_WAIT(N_) { if (wave_u == 0) wait_vmcnt<(N_) + 1>(); else wait_vmcnt<(N_)>(); }
   RC_PLOAD(a_beg);
@@ -562,20 +565,21 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
   frag6 ce;
   // group g = 2 s + cb2 of a chunk: the two planes of block cb2 at k-step s
 #define RC_READ(F1_, F2_, slot_, g_)                                                           \
-  {                                                                                            \
+  { if (!(RC_ABL & 2)) {                                                                         \
     const bf16x8* fp = ring + (slot_) * CH16 + ((((g_) >> 1) * 2) * 2 + ((g_) & 1)) * 64;      \
     F1_ = fp[0];                                                                               \
     F2_ = fp[2 * 64];                                                                          \
-  }
+  } }
   // 6-bit fragment j = 3 cb2 + term of a chunk
 #define RC_CREAD(slot_, j_)                                                                    \
-  {                                                                                            \
+  { if (!(RC_ABL & 2)) {                                                                         \
     const unsigned char* cp = cring + (slot_) * (CH16 * 16) + (j_) * 1536;                     \
     const uint4 u_ = *reinterpret_cast<const uint4*>(cp + lane * 16);                          \
     const uint2 w_ = *reinterpret_cast<const uint2*>(cp + 1024 + lane * 8);                    \
     ce.w[0] = u_.x; ce.w[1] = u_.y; ce.w[2] = u_.z; ce.w[3] = u_.w; ce.w[4] = w_.x; ce.w[5] = w_.y; \
-  }
+  } }
 #define RC_MFMA(F1_, F2_, g_)                                                                  \
+  { if (RC_ABL & 4) { part[2 * ((g_) & 1)][0] += (float)F1_[0] + (float)F2_[1]; } else           \
   {                                                                                            \
     _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
       f32x4& P_ = part[2 * ((g_) & 1) + nb];                                                   \
@@ -583,9 +587,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
       P_ = mma16<true>(F1_, q2[2 * ((g_) >> 1) + nb], P_);                                     \
       P_ = mma16<true>(F1_, q1[2 * ((g_) >> 1) + nb], P_);                                     \
     }                                                                                          \
-  }
+  } }
   // correction fragment j (held in ce) into the partial accumulators of its block
 #define RC_CORR(j_)                                                                            \
+  { if (RC_ABL & 4) { part[2 * ((j_) / 3)][1] += __uint_as_float(ce.w[0]); } else                \
   {                                                                                            \
     _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                         \
       f32x4& P_ = part[2 * ((j_) / 3) + nb];                                                   \
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
       else if ((j_) % 3 == 1) P_ = f16c_mma_ht(ce, qt6[nb], P_);                               \
       else P_ = f16c_mma_ll(ce, ql6[nb], P_);                                                  \
     }                                                                                          \
-  }
+  } }
   RC_READ(fa1, fa2, 0, 0);
   RC_CREAD(0, 0);
   f32x4 part[4];
@@ -621,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
         RC_MFMA(fb1, fb2, 2 * gp + 1);
       }
       __builtin_amdgcn_sched_barrier(0);       // the flush stays HERE: moved into the next chunk it would keep two sets
+      if (RC_ABL & 8) { acc[4 * ch][0] += part[0][0] + part[1][1] + part[2][2] + part[3][3]; } else
       {                                        // of partial accumulators alive
         float pva = pst[(a & 3) * PST] * rs_a, pvb = pst[(a & 3) * PST + 16] * rs_b;
         const float pas_a = (a & 1) ? -pva : pva, pas_b = (a & 1) ? -pvb : pvb;
@@ -639,9 +645,11 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
       __builtin_amdgcn_sched_barrier(0);
       // chunk i + 2 (issued one iteration ago) must have landed.  Younger than it: this iteration's three (four) T loads
       // and, for ch < 2, the p load issued right behind the T loads of ch == 0
-      if (ch < 2) RC_WAIT(4)
-      else RC_WAIT(3)
-      __builtin_amdgcn_s_barrier();
+      if (!(RC_ABL & 16)) {
+        if (ch < 2) RC_WAIT(4)
+        else RC_WAIT(3)
+        __builtin_amdgcn_s_barrier();
+      }
       asm volatile("" ::: "memory");
     }
   }
