@@ -66,7 +66,9 @@ class _MultiTensor(torch.optim.Optimizer):
                 live.append(g)
             tab[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
         self._live_grads = live
-        return self._plan[key], torch.from_numpy(tab).to(dev)
+        # pinned staging: from pageable memory the upload is a synchronous copy -- the one host synchronisation a training
+        # step still had (tools/sync_probe.py); the caching host allocator keeps the pinned block until the copy has run
+        return self._plan[key], torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
 
 
 class FusedAdamW(_MultiTensor):
