@@ -531,6 +531,12 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
       acc[2 * cb + nb][0] = v.x; acc[2 * cb + nb][1] = v.y; acc[2 * cb + nb][2] = v.z; acc[2 * cb + nb][3] = v.w;
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ... and the compiler must KNOW that these loads have landed: it does not see the wait above, keeps them pending across
+  // the loop header and waits for them at their first use -- the flush of every chunk, an `s_waitcnt vmcnt(0)` inside the
+  // loop that also drains the LDS-DMA pieces just issued for three chunks ahead (round 5: found in the ISA after the
+  // kernel's ablations showed the stream costing 0.3 ms per launch that nothing else accounted for)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(acc[i]));
 
 #ifndef RC_ABL
 #define RC_ABL 0   // timing-only ablations (wrong results; tools/rc_ablate.sh): 1 no LDS-DMA, 2 no fragment reads, 4 no matrix

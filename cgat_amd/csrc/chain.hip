@@ -329,6 +329,9 @@ int prepare_W_x6_batch_launch(const WPrepBatch& b, float* dst, hipStream_t strea
 }
 
 // (the body as a device function: the single and the batched kernel below call it with their descriptor)
+#ifndef CX_ABL
+#define CX_ABL 0   // timing-only ablations (wrong results): 1 no epilogue loads (bias, residual, derivative, accumulate), 2 no stores
+#endif
 __device__ __forceinline__ void mlp_chain128_x6_body(const ChainDesc& d) {
   constexpr int CH16 = 2 * 3 * 2 * 64;          // 16-byte pieces per chunk: two k-steps x three planes x two blocks x 64 lanes
   constexpr int XP = 36;                        // pitch (floats) of the layout-exchange tile: 32 columns + 4
@@ -428,6 +431,28 @@ __device__ __forceinline__ void mlp_chain128_x6_body(const ChainDesc& d) {
     for (int hc = 0; hc < 4; ++hc) {             // hc = 2 half + cbp: output columns 32 hc .. 32 hc + 31
 #pragma unroll
       for (int i = 0; i < 4; ++i) { part[i] = f32x4{0.f, 0.f, 0.f, 0.f}; partn[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      // The epilogue's per-row operand of these 32 columns -- the saved activation for the derivative, the residual, or
+      // the output that is accumulated into: at most one of them in the chains the library builds (pre[] below; a layer
+      // with two of them loads the others in the epilogue as before) -- and the bias are requested HERE, two ring steps
+      // before their use.  Loaded where they are used (rounds 3-5) every epilogue paid their full latency: the compiler's
+      // wait for them is vmcnt(0), which also drains the LDS-DMA pieces in flight (it cannot see those), and the ring
+      // steps behind it stalled in turn -- 0.46 of the chains' 1.22 ms per step (CX_ABL=1).
+      float4 pre[4], pbias[2];
+      const float* pre_src = L.dact ? L.dact : (L.resid ? L.resid : ((L.out && L.accumulate) ? L.out : nullptr));
+      const long pre_ld = L.dact ? L.ld_dact : (L.resid ? L.ld_resid : L.ld_out);
+      if (pre_src && !(CX_ABL & 1)) {
+#pragma unroll
+        for (int cb2 = 0; cb2 < 2; ++cb2) {
+          const int col = 16 * (2 * hc + cb2) + 4 * kg;
+          pre[2 * cb2 + 0] = *reinterpret_cast<const float4*>(pre_src + rca * pre_ld + col);
+          pre[2 * cb2 + 1] = *reinterpret_cast<const float4*>(pre_src + rcb * pre_ld + col);
+        }
+      }
+      if (L.bias && !(CX_ABL & 1)) {
+#pragma unroll
+        for (int cb2 = 0; cb2 < 2; ++cb2) pbias[cb2] = *reinterpret_cast<const float4*>(L.bias + 16 * (2 * hc + cb2) + 4 * kg);
+      }
+      __builtin_amdgcn_sched_barrier(0);         // the requests stay HERE
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {           // chunk (l, hc, kh) sits in ring slot (2 hc + kh) % 4
         const int slot = (2 * hc + kh) & 3;
@@ -458,31 +483,34 @@ __device__ __forceinline__ void mlp_chain128_x6_body(const ChainDesc& d) {
         const int col = 16 * b16 + 4 * kg;
         const f32x4 pa = part[2 * cb2 + 0] - partn[2 * cb2 + 0], pb = part[2 * cb2 + 1] - partn[2 * cb2 + 1];
         float4 va = make_float4(pa[0], pa[1], pa[2], pa[3]), vb = make_float4(pb[0], pb[1], pb[2], pb[3]);
-        if (L.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(L.bias + col);
+        if (L.bias && !(CX_ABL & 1)) {
+          const float4 b4 = pbias[cb2];
           va.x += b4.x; va.y += b4.y; va.z += b4.z; va.w += b4.w;
           vb.x += b4.x; vb.y += b4.y; vb.z += b4.z; vb.w += b4.w;
         }
         va = chain_act(va, L.act);
         vb = chain_act(vb, L.act);
-        if (L.resid) {
-          const float4 ra = *reinterpret_cast<const float4*>(L.resid + rca * L.ld_resid + col);
-          const float4 rb = *reinterpret_cast<const float4*>(L.resid + rcb * L.ld_resid + col);
+        if (L.resid && !(CX_ABL & 1)) {
+          const bool hoisted = !L.dact;            // (uniform) the residual is the hoisted operand unless a derivative is
+          const float4 ra = hoisted ? pre[2 * cb2 + 0] : *reinterpret_cast<const float4*>(L.resid + rca * L.ld_resid + col);
+          const float4 rb = hoisted ? pre[2 * cb2 + 1] : *reinterpret_cast<const float4*>(L.resid + rcb * L.ld_resid + col);
           va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
           vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
         }
-        if (L.dact) {
-          va = chain_deriv(va, *reinterpret_cast<const float4*>(L.dact + rca * L.ld_dact + col), L.dact_type);
-          vb = chain_deriv(vb, *reinterpret_cast<const float4*>(L.dact + rcb * L.ld_dact + col), L.dact_type);
+        if (L.dact && !(CX_ABL & 1)) {
+          va = chain_deriv(va, pre[2 * cb2 + 0], L.dact_type);
+          vb = chain_deriv(vb, pre[2 * cb2 + 1], L.dact_type);
         }
         if (L.out) {
           float* oa = L.out + rca * L.ld_out + col;
           float* ob = L.out + rcb * L.ld_out + col;
-          if (L.accumulate) {
-            const float4 ua = *reinterpret_cast<const float4*>(oa), ub = *reinterpret_cast<const float4*>(ob);
+          if (L.accumulate && !(CX_ABL & 1)) {
+            const bool hoisted = !L.dact && !L.resid;
+            const float4 ua = hoisted ? pre[2 * cb2 + 0] : *reinterpret_cast<const float4*>(oa);
+            const float4 ub = hoisted ? pre[2 * cb2 + 1] : *reinterpret_cast<const float4*>(ob);
             if (row_a < rows) *reinterpret_cast<float4*>(oa) = make_float4(ua.x + va.x, ua.y + va.y, ua.z + va.z, ua.w + va.w);
             if (row_b < rows) *reinterpret_cast<float4*>(ob) = make_float4(ub.x + vb.x, ub.y + vb.y, ub.z + vb.z, ub.w + vb.w);
-          } else {
+          } else if (!(CX_ABL & 2)) {
             if (row_a < rows) *reinterpret_cast<float4*>(oa) = va;
             if (row_b < rows) *reinterpret_cast<float4*>(ob) = vb;
           }
