@@ -22,6 +22,11 @@
 // out slightly wrong and differ from run to run on MI355X (Z, computed from the same registers, stays bit-exact;
 // found by tests/test_hip_golden.py::test_determinism_bitwise, bisected with an empty asm between the two
 // accumulations).  This file is therefore built with -fno-slp-vectorize and the two accumulators are pinned apart.
+//
+// Kernels in this file (round 5): edge_z_kernel (below: 128-row workgroups; the per-node projections, the dense layer at
+// width 128, and the per-edge launch of shapes / modes the wide-tile kernels do not take), edge_z6w_kernel (the per-edge
+// launch of the default 24-bit modes: the same six-pass arithmetic on 256-row workgroups, bit-identical, 3.20 -> 2.84 ms),
+// edge_zc_kernel (the per-edge launch in the h + l + t arithmetic, opt-in), edge_zx_kernel (f16x3 mode, K = 256).
 #include "common.h"
 #include "kernels.h"
 #include "mfma_bf16.h"
