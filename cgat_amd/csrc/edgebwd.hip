@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
                                                          const uint4* __restrict__ Eq, float* __restrict__ slab,
                                                          int E, int ncb, int nsteps, int S,
                                                          const float* __restrict__ gmax, const float* __restrict__ emax,
-                                                         const EdgeRC rc) {
+                                                         const EdgeRC rc, int xcd_order) {
   // PASSES == 2: two fp16 planes, three passes; both operands are indexed by the reduction index (the edge slot), so
   // both scales are per tensor: gmax[0] = max |gZ| (from its producer), emax[0] = max |e| (the planes carry 2^k e)
   constexpr bool F16 = PASSES == 2;
@@ -295,7 +295,27 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   const int n16 = lane & 15, kg = lane >> 4;
   const int grp = wave >> 2, wq = wave & 3;              // column block of the pair, 32-column slice in it
   const int npair = ncb / 2;
-  const int pair = blockIdx.x % npair, split = blockIdx.x / npair;
+  // XCD-aware order: consecutive workgroup ids go to different XCDs (own L2 each), and the npair workgroups of one range
+  // read the same e planes.  The first 8 * floor(S / 8) ranges are dealt out so that a range's workgroups sit on ONE XCD,
+  // next to each other in its dispatch order (the planes then come from HBM once and from that L2 afterwards; in plain
+  // order every column-block pair fetched them into its own XCD: 6.5 GB of FETCH_SIZE for 0.77 GB of planes at
+  // W2 = 1536); the remaining S % 8 ranges keep the plain order.  Same number of workgroups either way.
+  int pair, split;
+  {
+    const int s8 = S >> 3, body = 8 * s8 * npair;
+    if (xcd_order && (int)blockIdx.x < body) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      pair = j % npair;
+      split = xcd * s8 + j / npair;
+    } else if (xcd_order) {
+      const int r = blockIdx.x - body;
+      pair = r % npair;
+      split = 8 * s8 + r / npair;
+    } else {
+      pair = blockIdx.x % npair;
+      split = blockIdx.x / npair;
+    }
+  }
   // ranges in units of two k-steps (the loop is unrolled by two without a tail); a k-step past nsteps holds slots >= E,
   // which contribute zeros, and its e planes are the zero padding of the last 128-slot block
   const int npairs = (nsteps + 1) / 2;
@@ -620,6 +640,10 @@ bool edge_gw_fast(int Ce, int W2, long ldg, long gzb, const void* gZ) {
   return bilinear_mode() != 0 && Ce == 128 && W2 % 256 == 0 && gzb != 0 && (gzb % 4) == 0 && (ldg % 4) == 0 &&
          (((uintptr_t)gZ) & 15) == 0;
 }
+static int gw_xcd_order() {   // CGAT_GW_XCD=0: plain workgroup order (A/B switch)
+  static const int v = [] { const char* e = getenv("CGAT_GW_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
 static int edge_gw_splits(int W2) {   // ranges x column-block pairs ~ one workgroup per CU
   const int npair = W2 / 256;
   if (npair <= 0) return 1;
@@ -652,7 +676,7 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
     const EdgeRC none = {};
 #define GW_GO(P_, R_)                                                                                                  \
   hipLaunchKernelGGL((edge_gw_kernel<P_, R_>), dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb,                \
-                     (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax, R_ ? *rc : none)
+                     (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax, R_ ? *rc : none, gw_xcd_order())
     if (rc) { if (f16) GW_GO(2, true); else if (bilinear_mode() != 3) GW_GO(6, true); else GW_GO(3, true); }
     else { if (f16) GW_GO(2, false); else if (bilinear_mode() != 3) GW_GO(6, false); else GW_GO(3, false); }
 #undef GW_GO
