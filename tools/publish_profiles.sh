@@ -8,6 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/profiles
 cp $D/bench.json $P/${T}_final_bench.json
 cp $(ls $D/stats/*/*_kernel_stats.csv | head -1) $P/${T}_final_kernel_stats.csv
+[ -s $D/stats_bench.json ] && cp $D/stats_bench.json $P/${T}_final_kernel_stats_bench.json
 for c in FETCH_SIZE WRITE_SIZE; do cp $(ls $D/pmc_$c/*/*_counter_collection.csv | head -1) $P/${T}_final_pmc_${c}_counter_collection.csv; done
 python3 $R/tools/pmc_summary.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE $T
 COUNTER_JSON=$P/mfma_counters.json python3 $R/tools/counter_summary.py $D/pmc_mfma > $P/${T}_final_counters_mfma.txt
