@@ -88,6 +88,29 @@ class ChainDesc(C.Structure):
                 ("layer", ChainLayer * 5)]
 
 
+class RowProgOp(C.Structure):
+    """cgat_rowprog_op"""
+    _fields_ = [("phase", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", vp), ("a_rs", C.c_int64), ("a_ks", C.c_int64),
+                ("dact", vp), ("d_rs", C.c_int64), ("d_ks", C.c_int64), ("dact_type", C.c_int32),
+                ("B0", vp), ("b0_rs", C.c_int64), ("b0_ks", C.c_int64),
+                ("B1", vp), ("b1_rs", C.c_int64), ("b1_ks", C.c_int64),
+                ("bias", vp), ("act", C.c_int32),
+                ("resid", vp), ("ld_resid", C.c_int64),
+                ("out", vp), ("ldo", C.c_int64), ("accumulate", C.c_int32),
+                ("h_out", vp), ("ld_h", C.c_int64),
+                ("rowsum", vp)]
+
+
+ROWPROG_MAX_OPS = 24
+ROWPROG_SYNC_WORDS = (1024 + 1) * 16
+
+
+class RowProg(C.Structure):
+    """cgat_rowprog"""
+    _fields_ = [("n_ops", C.c_int32), ("op", RowProgOp * ROWPROG_MAX_OPS)]
+
+
 PROTOTYPES = {
     "cgat_abi_version": (C.c_int, []),
     "cgat_last_error": (C.c_char_p, []),
@@ -132,6 +155,7 @@ PROTOTYPES = {
                                                        vp, vp, vp, vp, C.c_int64, vp, vp]),
     "cgat_mlp_chain_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "cgat_mlp_chain": (C.c_int, [C.POINTER(ChainDesc), vp, C.c_size_t, vp]),
+    "cgat_rowprog_run": (C.c_int, [C.POINTER(RowProg), vp, vp]),
     "cgat_dense_wgrad_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "cgat_dense_wgrad_batch": (C.c_int, [C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp,
                                           C.c_size_t, vp]),

@@ -4,7 +4,7 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libcgat_hip.so"
-SRCS=(api gemm gemmsplit bilinear wgradc edgez edgebwd rowsdw collate optim rowops segment plan layers chain)
+SRCS=(api gemm gemmsplit bilinear wgradc edgez edgebwd rowsdw collate optim rowops segment plan layers chain rowprog)
 OBJS=()
 PIDS=()
 mkdir -p "$HERE/csrc/build"

@@ -4,7 +4,7 @@ the fp32 MFMA GEMM kernel with its activation fused into the epilogue."""
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, rowprog
 from .ops import ChainMLPFn, linear
 
 
@@ -23,6 +23,13 @@ class SimpleNetwork(nn.Module):
         ws = [fc.weight for fc in self.fcs] + [self.fc_out.weight]
         bs = [fc.bias for fc in self.fcs] + [self.fc_out.bias]
         x2 = fea.reshape(-1, fea.shape[-1])
+        if rowprog.eligible(x2):
+            # a few hundred rows (the composition branch, per-crystal rows): the whole network is one launch per direction
+            r2 = None if residual is None else residual.reshape(x2.shape[0], -1)
+            spec = (rowprog.mlp_spec(len(self.fcs), _lib.ACT_LEAKY),)
+            flat = [t for w, b in zip(ws, bs) for t in (w, b, None)]
+            (out,) = rowprog.RowNetsFn.apply(x2, r2, spec, *flat)
+            return out.reshape(*fea.shape[:-1], out.shape[-1])
         if all(b is not None for b in bs) and ChainMLPFn.eligible(x2, ws, None if residual is None else residual.reshape(x2.shape)):
             # all layers of width 128: one launch per direction, hidden rows never leave the registers (csrc/chain.hip)
             r2 = None if residual is None else residual.reshape(x2.shape)
@@ -66,6 +73,19 @@ class ResidualNetwork(nn.Module):
             self.rezeros = nn.ModuleList([Rezero() for _ in range(len(dims) - 1)])
 
     def forward(self, fea, *, last_layer=True):
+        x2 = fea.reshape(-1, fea.shape[-1])
+        if not self.if_rezero and rowprog.eligible(x2):
+            # the head at G rows: every layer with its skip product is one phase of ONE launch per direction
+            spec, flat = [], []
+            for fc, res in zip(self.fcs, self.res_fcs):
+                ident = isinstance(res, nn.Identity)
+                spec.append((_lib.ACT_RELU, 1 if ident else 2, True))
+                flat += [fc.weight, fc.bias, None if ident else res.weight]
+            if last_layer:
+                spec.append((_lib.ACT_NONE, 0, True))
+                flat += [self.fc_out.weight, self.fc_out.bias, None]
+            (out,) = rowprog.RowNetsFn.apply(x2, None, (tuple(spec),), *flat)
+            return out.reshape(*fea.shape[:-1], out.shape[-1])
         for k, (fc, res) in enumerate(zip(self.fcs, self.res_fcs)):
             h = linear(fea, fc.weight, fc.bias, _lib.ACT_RELU)
             if self.if_rezero:

@@ -362,6 +362,48 @@ int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const 
                            float* const* out, int64_t ldo, float* const* bsum, int32_t rows, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* ---- small-row dense-layer programs: a whole G-row / Nc-row network per launch ------------------------------------
+ * At the batch the reference harness ships (--batch-size 64, CGAT/lightning_module.py:468-473) the output head
+ * (ResidualNetwork, CGAT/message_changed.py:81-138: per layer act(fc(x)) + res_fc(x), then fc_out), Roost's gate and
+ * message networks (SimpleNetwork, CGAT/roost_message.py:137-153, 324-355) and the per-crystal networks of MHAttention
+ * (CGAT/CGAT.py:14-62) are products over 64 ... 2 048 rows: bound by kernel boundaries, not by flops.  A program is a
+ * list of products
+ *     out[m,n] = act( sum_k A'(m,k) B0(n,k) + bias[n] ) [-> h_out[m,n]]  +  sum_k A(m,k) B1(n,k)  +  resid[m,n]  (+ out[m,n])
+ *     A'(m,k)  = A(m,k) * dact_type'(dact(m,k))     (dact = saved activation VALUES; NULL: A' = A)
+ *     rowsum[m] = sum_k A'(m,k)                       (optional: a bias gradient)
+ * with X(r,k) = X[r * x_rs + k * x_ks] for A, dact, B0, B1 -- so one op is a forward layer with its residual product
+ * (A = x, B0 = fc.weight, B1 = res_fc.weight), an input gradient (A = g_y, dact = h, B0 = W^T, B1 = R^T) or a weight
+ * gradient (A = g_y^T, dact = h^T, B0 = x^T, rowsum = the bias gradient) -- run by ONE persistent launch phase by
+ * phase: the ops of a phase must not depend on each other, phase p may read what phases < p wrote (a grid barrier with
+ * device-scope release / acquire separates them).  Exact fp32 products with fp32 accumulation (f32-input MFMA), fixed
+ * summation order; no workspace, no operand images.  act / dact_type: 0 none, 1 tanh, 2 LeakyReLU(0.01), 3 ReLU.
+ * B1, bias, resid, h_out, rowsum, dact may be NULL.  Meant for M, N <= a few thousand.
+ * sync_words: CGAT_ROWPROG_SYNC_WORDS uint32 of device memory, 64-byte aligned, zero-filled by the caller ONCE and then
+ * left to the library for the life of the process (barrier counters that every launch returns to zero, and one sticky
+ * word -- index CGAT_ROWPROG_SYNC_WORDS - 16 -- that is set to 1 if a barrier ever gave up instead of hanging: the
+ * results of that launch are void). */
+#define CGAT_ROWPROG_MAX_OPS 24
+#define CGAT_ROWPROG_SYNC_WORDS ((1024 + 1) * 16)
+typedef struct cgat_rowprog_op {
+  int32_t phase;            /* non-decreasing over the op list, starting at 0, no gaps */
+  int32_t M, N, K;
+  const float* A;     int64_t a_rs, a_ks;
+  const float* dact;  int64_t d_rs, d_ks;  int32_t dact_type;
+  const float* B0;    int64_t b0_rs, b0_ks;
+  const float* B1;    int64_t b1_rs, b1_ks;
+  const float* bias;  /* [N] */
+  int32_t act;
+  const float* resid; int64_t ld_resid;
+  float* out;         int64_t ldo;         int32_t accumulate;
+  float* h_out;       int64_t ld_h;
+  float* rowsum;      /* [M] */
+} cgat_rowprog_op;
+typedef struct cgat_rowprog {
+  int32_t n_ops;
+  cgat_rowprog_op op[CGAT_ROWPROG_MAX_OPS];
+} cgat_rowprog;
+int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, void* stream);
+
 /* Storage of the per-edge intermediates of cgat_nodes_attention_*: the pre-activations Z saved by forward, and their
  * gradient gZ inside backward -- which at the benchmark widths is NOT stored at all but rebuilt by its consumers from
  * one sign bit per element and per-node rows (same values to fp32 rounding).
