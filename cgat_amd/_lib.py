@@ -97,7 +97,7 @@ class RowProgOp(C.Structure):
                 ("B1", vp), ("b1_rs", C.c_int64), ("b1_ks", C.c_int64),
                 ("bias", vp), ("act", C.c_int32),
                 ("resid", vp), ("ld_resid", C.c_int64),
-                ("out", vp), ("ldo", C.c_int64), ("accumulate", C.c_int32),
+                ("out", vp), ("ldo", C.c_int64), ("alpha", C.c_float), ("beta", C.c_float),
                 ("h_out", vp), ("ld_h", C.c_int64),
                 ("rowsum", vp)]
 

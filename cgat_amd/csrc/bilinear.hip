@@ -1248,6 +1248,38 @@ __global__ __launch_bounds__(256) void dual_finish_kernel(const float* __restric
   }
 }
 
+// The same at a few hundred rows (the harness' shipped batch: 1 280 atoms, up to 32 a-splits): one thread per output,
+// the slab loads of an output issued eight at a time -- the 32-row workgroups above are 40 workgroups whose threads each
+// walk 32 slabs for 16 outputs (35 us per launch at 1 280 rows, sixteen launches per step); same summation order.
+__global__ __launch_bounds__(256) void dual_finish_small_kernel(const float* __restrict__ slab, int splits,
+                                                                long slab_stride, int nrows, float* __restrict__ out1,
+                                                                long ldo1, const float* __restrict__ dvp, int dv_ld, int NA,
+                                                                const float* __restrict__ init2, long ldi2,
+                                                                float* __restrict__ out2, long ldo2, int nhalf) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = i >> 7;
+  const int c = (int)(i & 127);
+  if (row >= nrows) return;
+  if (splits > 1) {
+    const float* sl = slab + row * 128 + c;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = sl[(long)(z + k) * slab_stride];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; z < splits; ++z) s += sl[(long)z * slab_stride];
+    out1[row * ldo1 + c] = s;
+  }
+  const long o = (long)c * dv_ld + row;
+  float t = dvp[o];
+  for (int h = 1; h < nhalf; ++h) t += dvp[(long)h * NA * dv_ld + o];
+  out2[row * ldo2 + c] = (init2 ? init2[row * ldi2 + c] : 0.f) + t;
+}
+
 // sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
 // (layout in the header above); element (a, b, c) of the [NA,128,128] operand is src[a*sa + b*sb + c*sc].
 // F16: two fp16 planes of 2^k sgn(a) T[a], 2^k from tmax[0] = max |T| (pow2_scale), same order with 2 planes per k-step
@@ -1933,8 +1965,12 @@ int bilinear_dual_launch(const float* p, long ldp, const float* q, long ldq, con
                          (const uint4*)T, init1, ldi1, dst, dld, dvp, dv_ld, nrows, 128, tiles, sp, stride, vec_io, tmax);
     CGAT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv(nrows, 32)), dim3(256), 0, stream, slab, sp, stride, nrows, out1, ldo1,
-                     dvp, dv_ld, 128, init2, ldi2, out2, ldo2, c256 ? 4 : 2);
+  if (nrows <= 8192)
+    hipLaunchKernelGGL(dual_finish_small_kernel, dim3(cdiv((long)nrows * 128, 256)), dim3(256), 0, stream, slab, sp, stride,
+                       nrows, out1, ldo1, dvp, dv_ld, 128, init2, ldi2, out2, ldo2, c256 ? 4 : 2);
+  else
+    hipLaunchKernelGGL(dual_finish_kernel, dim3(cdiv(nrows, 32)), dim3(256), 0, stream, slab, sp, stride, nrows, out1, ldo1,
+                       dvp, dv_ld, 128, init2, ldi2, out2, ldo2, c256 ? 4 : 2);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

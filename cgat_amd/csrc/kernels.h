@@ -65,6 +65,13 @@ int splitk_reduce_launch(const float* slab, int splits, int M, int N, float* C, 
                          float alpha = 1.f, float beta = 0.f, const float* bias = nullptr, int act = 0);
 size_t gemm_ws_bytes(const GemmParams& p);
 
+// ---- small-row products as single-op programs of rowprog.hip (exact fp32 MFMA, no workspace) ----
+struct cgat_rowprog_op;
+int rowprog_max_rows();                       // env CGAT_ROWPROG_MAX_ROWS, default 2048; 0: never
+bool rowprog_gemm_ok(const GemmParams& p);    // plain strided product of at most rowprog_max_rows() rows
+int rowprog_gemm(const GemmParams& p, hipStream_t s);
+int rowprog_launch(const cgat_rowprog_op* ops, int n_ops, uint32_t* sync_words, hipStream_t s);
+
 // ---- bilinear (hypernetwork) contractions, bilinear.hip ----
 // out[n,c] = init[n,c] + sum_{a<NA,b<NB} p[n,a] q[n,b] T3[a,b,c], with T = bilinear_prepare_T(T3 source):
 // a permuted copy whose columns are interleaved for the MFMA kernel when NB == NC == 128.

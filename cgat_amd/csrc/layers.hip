@@ -84,6 +84,9 @@ struct Ctx {
                           (p.beta == 0.f || p.beta == 1.f) && (p.act == CGAT_ACT_NONE || p.act == CGAT_ACT_TANH);
     if (dense128) need(linear128_ws_bytes(p.N));
     if (dry) return CGAT_OK;
+    // a few hundred rows (the harness' shipped batch): one wave per 16 x 16 output tile straight from global memory
+    // (rowprog.hip, exact fp32) -- the 128-row ring tiles below leave 250 of 256 CUs idle there
+    if (rowprog_gemm_ok(p)) return rowprog_gemm(p, s);
     if (dense128 && linear128_fast(p.K, p.N, p.lda, p.ldc, p.A, p.C) && scratch_bytes >= linear128_ws_bytes(p.N)) {
       const long so = p.b_kmajor ? 1 : p.ldb, sk = p.b_kmajor ? p.ldb : 1;
       return linear128_launch(p.A, p.lda, p.B, so, sk, p.bias, p.act, p.beta == 1.f, p.C, p.ldc, p.M, scratch, s, p.N,

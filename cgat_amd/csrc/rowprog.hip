@@ -16,11 +16,16 @@
 // workgroups meet at a grid barrier (one device-scope counter, release before the arrival, acquire after the wait:
 // MI355X_MICROARCH.md, inter-workgroup visibility), so the hidden rows of a network never cross a kernel boundary.
 //
-// Arithmetic: exact fp32 products, fp32 accumulation (v_mfma_f32_16x16x4_f32: the matrix cores' f32-input form, a
-// k-ordered fmaf chain per output) -- the reference's own arithmetic up to summation order; no operand splitting, no
-// prepared weight images (at <= 2048 rows the weights are read once, straight from HBM into registers: a 16 x 64 wave
-// tile needs no LDS staging, cdna_hip_programming.md "M <= 16 decode weights" row).  Fixed task -> wave mapping and a
-// fixed k order: results are bitwise reproducible.
+// Arithmetic: fp32 operands converted (exactly) to fp64, products and sums on the fp64 matrix instruction
+// (v_mfma_f64_16x16x4_f64), ONE rounding to fp32 per output -- a correctly rounded fp32 dot product up to the final
+// activation: at least as accurate as the reference's fp32 sequence, and independent of the summation order to fp32
+// resolution.  (An fp32-accumulating form -- v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain -- runs at twice the rate but
+// put 27 instead of 3 tensors of the cancellation-heavy sin-filled fixture `net_mean` beyond 1e-4 |ref|: the weight
+// gradients of the gate networks are sums that cancel over every segment, and the six-pass split products these layers
+// ran on before round 6 summed 32 exact products per rounding.)  No operand splitting, no prepared weight images: at
+// <= 2048 rows the weights are read once, straight from HBM into registers (a 16 x 64 wave tile needs no LDS staging,
+// cdna_hip_programming.md "M <= 16 decode weights" row).  Fixed task -> wave mapping: bitwise reproducible.
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -30,6 +35,7 @@
 #include "kernels.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define RP_MAX_OPS CGAT_ROWPROG_MAX_OPS
 #define RP_WG_THREADS 256
@@ -55,7 +61,8 @@ struct RowOp {
   float* rowsum;
   int a_rs, a_ks, d_rs, d_ks, b0_rs, b0_ks, b1_rs, b1_ks, ld_resid, ldo, ld_h;
   int M, N, K;
-  int act, dact_type, accumulate;
+  int act, dact_type;
+  float alpha, beta;   // out = act(alpha * acc0 + bias) + acc1 + resid + beta * out
   int nb;          // 16-column tiles per task (1, 2, 4)
   int vec;         // RP_VEC_*: operand rows are k-contiguous and 16-byte aligned -> dwordx4 loads
   int task_off;    // first task of this op inside its phase
@@ -115,8 +122,9 @@ struct RpFrag {
   v4f a[NF], d[NF], w0[NB][NF], w1[NB][NF];
 };
 
-// One task = a 16 x (16 NB) output tile by ONE wave.  MFMA 16x16x4 f32: lane l supplies A(row l%16, k = l/16) and
-// B(col l%16, k = l/16); a lane's dwordx4 along k (k = 4 (l/16) + j) feeds four instructions, both operands alike.
+// One task = a 16 x (16 NB) output tile by ONE wave.  MFMA 16x16x4 f64: lane l supplies A(row l%16, k = l/16) and
+// B(col l%16, k = l/16), one double each; a lane's dwordx4 along k (k = 4 (l/16) + j) feeds four instructions, both
+// operands alike (fp32 -> fp64 conversion is exact).
 template <int NB>
 __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
   typedef RpFrag<NB> Frag;
@@ -143,10 +151,10 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
   const bool va = op.vec & RP_VEC_A, vd = op.vec & RP_VEC_D, vb0 = op.vec & RP_VEC_B0, vb1 = op.vec & RP_VEC_B1;
   const int dtype = op.dact_type;
 
-  v4f acc0[NB], acc1[NB];
+  v4d acc0[NB], acc1[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) acc0[b] = acc1[b] = v4f{0.f, 0.f, 0.f, 0.f};
-  float rs = 0.f;
+  for (int b = 0; b < NB; ++b) acc0[b] = acc1[b] = v4d{0., 0., 0., 0.};
+  double rs = 0.;
 
   auto load = [&](Frag& f, int g) {
     const int kb = g * GK + 4 * q;
@@ -183,11 +191,12 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
       for (int j = 0; j < 4; ++j) {
         const float av = f.a[t][j];
         const float at = has_d ? rp_dact(av, f.d[t][j], dtype) : av;
-        rs += at;
+        const double ad = (double)at, avd = (double)av;
+        rs += ad;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          acc0[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, f.w0[b][t][j], acc0[b], 0, 0, 0);
-          if (two) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.w1[b][t][j], acc1[b], 0, 0, 0);
+          acc0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, (double)f.w0[b][t][j], acc0[b], 0, 0, 0);
+          if (two) acc1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(avd, (double)f.w1[b][t][j], acc1[b], 0, 0, 0);
         }
       }
     }
@@ -205,30 +214,37 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
     }
   }
 
-  // epilogue: lane holds rows m0 + 4q + r (r = 0..3) of column n0 + 16 b + i
+  // epilogue.  f64 16x16x4 C/D map: lane holds column n0 + 16 b + i of rows m0 + q + 4 r (r = 0..3); the fp64 sums
+  // are rounded to fp32 ONCE, after alpha and the bias
   const int act = op.act;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int n = n0 + 16 * b + i;
     if (n >= N) continue;
-    const float bv = op.bias ? op.bias[n] : 0.f;
+    const double bv = op.bias ? (double)op.bias[n] : 0.;
+    const double alpha = (double)op.alpha;
+    const float beta = op.beta;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 4 * q + r;
+      const int m = m0 + q + 4 * r;
       if (m >= M) continue;
-      float v = rp_act(acc0[b][r] + bv, act);
+      float v = rp_act((float)(alpha * acc0[b][r] + bv), act);
       if (op.h_out) op.h_out[(long)m * op.ld_h + n] = v;
-      if (two) v += acc1[b][r];
-      if (op.resid) v += op.resid[(long)m * op.ld_resid + n];
       float* o = op.out + (long)m * op.ldo + n;
-      if (op.accumulate) v += *o;
+      if (two || op.resid || beta != 0.f) {
+        double w = (double)v;
+        if (two) w += acc1[b][r];
+        if (op.resid) w += (double)op.resid[(long)m * op.ld_resid + n];
+        if (beta != 0.f) w += (double)beta * (double)*o;
+        v = (float)w;
+      }
       *o = v;
     }
   }
   if (op.rowsum && nt == 0) {
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
-    if (q == 0 && m0 + i < M) op.rowsum[m0 + i] = rs;
+    if (q == 0 && m0 + i < M) op.rowsum[m0 + i] = (float)rs;
   }
 }
 
@@ -296,17 +312,16 @@ static bool rp_vec_ok(const float* p, int64_t rs, int64_t ks) {
   return p && ks == 1 && rs % 4 == 0 && ((uintptr_t)p & 15) == 0;
 }
 
-extern "C" int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, void* stream) {
-  CGAT_CHECK_ARG(prog && prog->n_ops >= 1 && prog->n_ops <= RP_MAX_OPS, "rowprog: 1..%d ops", RP_MAX_OPS);
-  CGAT_CHECK_ARG(sync_words && ((uintptr_t)sync_words & 63) == 0, "rowprog: sync_words must be a 64-byte aligned device buffer");
-  hipStream_t s = (hipStream_t)stream;
+// sync_words may be null for a single-phase program (no barrier)
+int rowprog_launch(const cgat_rowprog_op* ops, int n_ops, uint32_t* sync_words, hipStream_t s) {
+  CGAT_CHECK_ARG(ops && n_ops >= 1 && n_ops <= RP_MAX_OPS, "rowprog: 1..%d ops", RP_MAX_OPS);
   RowProgK K;
   memset(&K, 0, sizeof(K));
-  K.n_ops = prog->n_ops;
+  K.n_ops = n_ops;
   const int total_waves = RP_MAX_WGS * (RP_WG_THREADS / 64);
   int phase = -1, n_phases = 0, max_tasks = 0;
-  for (int o = 0; o < prog->n_ops; ++o) {
-    const cgat_rowprog_op& in = prog->op[o];
+  for (int o = 0; o < n_ops; ++o) {
+    const cgat_rowprog_op& in = ops[o];
     RowOp& op = K.op[o];
     CGAT_CHECK_ARG(in.M >= 1 && in.N >= 1 && in.K >= 0, "rowprog op %d: empty shape %d x %d x %d", o, in.M, in.N, in.K);
     CGAT_CHECK_ARG(in.A && in.B0 && in.out, "rowprog op %d: A, B0 and out are required", o);
@@ -323,7 +338,8 @@ extern "C" int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, 
     op.b0_rs = (int)in.b0_rs; op.b0_ks = (int)in.b0_ks; op.b1_rs = (int)in.b1_rs; op.b1_ks = (int)in.b1_ks;
     op.ld_resid = (int)in.ld_resid; op.ldo = (int)in.ldo; op.ld_h = (int)in.ld_h;
     op.M = in.M; op.N = in.N; op.K = in.K;
-    op.act = in.act; op.dact_type = in.dact ? in.dact_type : 0; op.accumulate = in.accumulate;
+    op.act = in.act; op.dact_type = in.dact ? in.dact_type : 0;
+    op.alpha = in.alpha; op.beta = in.beta;
     op.vec = (rp_vec_ok(in.A, in.a_rs, in.a_ks) ? RP_VEC_A : 0) | (rp_vec_ok(in.dact, in.d_rs, in.d_ks) ? RP_VEC_D : 0) |
              (rp_vec_ok(in.B0, in.b0_rs, in.b0_ks) ? RP_VEC_B0 : 0) | (rp_vec_ok(in.B1, in.b1_rs, in.b1_ks) ? RP_VEC_B1 : 0);
     op.tiles_m = cdiv(in.M, 16);
@@ -344,7 +360,9 @@ extern "C" int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, 
   for (int p = 0; p < n_phases; ++p) max_tasks = K.phase_tasks[p] > max_tasks ? K.phase_tasks[p] : max_tasks;
   int wgs = cdiv(max_tasks, RP_WG_THREADS / 64);
   if (wgs > RP_MAX_WGS) wgs = RP_MAX_WGS;
-  {
+  if (n_phases > 1) {
+    CGAT_CHECK_ARG(sync_words && ((uintptr_t)sync_words & 63) == 0,
+                   "rowprog: a program with more than one phase needs sync_words (64-byte aligned device memory)");
     std::lock_guard<std::mutex> lk(g_rp_mu);
     K.bar = sync_words + (size_t)(g_rp_next++ % RP_BAR_SLOTS) * RP_BAR_STRIDE;
     K.timeout = sync_words + (size_t)RP_BAR_SLOTS * RP_BAR_STRIDE;
@@ -353,4 +371,39 @@ extern "C" int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, 
   hipLaunchKernelGGL(rowprog_kernel, dim3(wgs), dim3(RP_WG_THREADS), 0, s, K);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
+}
+
+extern "C" int cgat_rowprog_run(const cgat_rowprog* prog, uint32_t* sync_words, void* stream) {
+  CGAT_CHECK_ARG(prog, "rowprog: null program");
+  return rowprog_launch(prog->op, prog->n_ops, sync_words, (hipStream_t)stream);
+}
+
+// ---- the layer orchestrators' small-row products (layers.hip, Ctx::gemm) as single-op programs ----
+static int g_rp_max_rows = -1;
+int rowprog_max_rows() {
+  if (g_rp_max_rows < 0) {
+    const char* e = getenv("CGAT_ROWPROG_MAX_ROWS");
+    g_rp_max_rows = e ? atoi(e) : 2048;
+  }
+  return g_rp_max_rows;
+}
+bool rowprog_gemm_ok(const GemmParams& p) {
+  return p.M >= 1 && p.N >= 1 && p.K >= 1 && p.M <= rowprog_max_rows() && p.N <= 4096 && !p.a_rgather && !p.a_block &&
+         !p.b_kgather && !p.c_scatter && !p.add1 && !p.add2 && !p.a_outer && !p.b_outer;
+}
+void rowprog_op_from_gemm(const GemmParams& p, cgat_rowprog_op* o) {
+  memset(o, 0, sizeof(*o));
+  o->M = p.M; o->N = p.N; o->K = p.K;
+  o->A = p.A;
+  if (p.a_kmajor) { o->a_rs = 1; o->a_ks = p.lda; } else { o->a_rs = p.lda; o->a_ks = 1; }
+  o->B0 = p.B;
+  if (p.b_kmajor) { o->b0_rs = 1; o->b0_ks = p.ldb; } else { o->b0_rs = p.ldb; o->b0_ks = 1; }
+  o->bias = p.bias; o->act = p.act;
+  o->out = p.C; o->ldo = p.ldc;
+  o->alpha = p.alpha; o->beta = p.beta;
+}
+int rowprog_gemm(const GemmParams& p, hipStream_t s) {
+  cgat_rowprog_op o;
+  rowprog_op_from_gemm(p, &o);
+  return rowprog_launch(&o, 1, nullptr, s);
 }

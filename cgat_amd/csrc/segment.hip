@@ -534,6 +534,7 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
     if (!PER_F) z.y = z.z = z.w = z.x;
     const float4 den = make_float4(z.x + eps, z.y + eps, z.z + eps, z.w + eps);
     double accd[4] = {0.0, 0.0, 0.0, 0.0};
+    double asum[4] = {0.0, 0.0, 0.0, 0.0};     // the ROUNDED coefficients' own sum (1 up to a few 2^-24)
     for (int r = r0; r < r1; r += AP_U) {
       float4 av[AP_U], mv[AP_U];
       float wv[AP_U];
@@ -557,16 +558,28 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
           } else al.y = al.z = al.w = al.x;
           accd[0] += (double)al.x * (double)mv[u].x; accd[1] += (double)al.y * (double)mv[u].y;
           accd[2] += (double)al.z * (double)mv[u].z; accd[3] += (double)al.w * (double)mv[u].w;
+          asum[0] += (double)al.x; asum[1] += (double)al.y; asum[2] += (double)al.z; asum[3] += (double)al.w;
         }
       }
     }
     const float4 inv = den;   // (stored under the old name: the denominators)
     const float4 oh = make_float4((float)accd[0], (float)accd[1], (float)accd[2], (float)accd[3]);
     *reinterpret_cast<float4*>(out + (long)s * F + f) = oh;
-    if (out_lo)
+    // Backward centres on out_hi + out_lo.  The centre is the weighted sum divided by the rounded coefficients' OWN sum
+    // (round 6): g_a[r] = sum_f alpha_r g (m_r - centre) then adds up to zero over the segment, as the exact gradient
+    // does (softmax shift invariance), whatever way the coefficients were rounded -- with the plain sum as the centre the
+    // segment's g_a add up to (g . out) (1 - sum alpha) ~ 1e-7 (g . out), which for a segment of nearly equal rows is
+    // 1e-5 ... 1e-1 of g_a itself and which the gate networks' weight gradients (h nearly equal over the segment) turn
+    // into an error common to all their entries: +-2e-4 of the value from one ulp of a logit (tools/rowprog_gate_probe.py).
+    // One row: centre = (alpha m) / alpha = m exactly; coefficients that sum to 1 exactly: centre = the sum, as before.
+    if (out_lo) {
+      double c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = asum[j] > 0.0 ? accd[j] / asum[j] : accd[j];
       *reinterpret_cast<float4*>(out_lo + (long)s * F + f) =
-          make_float4((float)(accd[0] - (double)oh.x), (float)(accd[1] - (double)oh.y), (float)(accd[2] - (double)oh.z),
-                      (float)(accd[3] - (double)oh.w));
+          make_float4((float)(c[0] - (double)oh.x), (float)(c[1] - (double)oh.y), (float)(c[2] - (double)oh.z),
+                      (float)(c[3] - (double)oh.w));
+    }
     if (PER_F) {
       *reinterpret_cast<float4*>(mx_out + (long)s * aF + ac) = mx;
       *reinterpret_cast<float4*>(inv_out + (long)s * aF + ac) = inv;

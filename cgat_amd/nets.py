@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, chunked, debug
+from . import _lib, chunked, debug, rowprog
 from .hypernet import H_Net, H_Net_0
 from .mlp import ResidualNetwork, SimpleNetwork
 from .ops import (AttentionPoolFn, attention_pool, EdgeHiddenFn, EdgeHiddenHeadsFn, HeadsLinear1Fn, HeadsLinearFn, NodeLayerFn, NodesAttentionFn, SegmentPlan, SegmentSoftmaxFn, SegmentSumFn, gather_rows, get_plan, get_segment_plan, linear, small_embedding,
@@ -47,6 +47,10 @@ class MultiHeadNetwork(nn.Module):
     def forward(self, fea):
         fea = fea.reshape(-1, self.input_dim)
         H, Hd, O = self.nb_heads, self.hidden_layer_dim, self.output_dim
+        if rowprog.eligible(fea) and 2 * H + 2 <= _lib.ROWPROG_MAX_OPS:
+            # a few hundred rows (the crystal pooling at the harness' batch): both layers of all heads in one launch
+            return rowprog.RowMultiHeadFn.apply(fea, self.fc_in.weight, self.fc_in.bias, self.fc_out.weight,
+                                                self.fc_out.bias, H, Hd, O)
         hid = linear(fea, self.fc_in.weight, self.fc_in.bias, _lib.ACT_LEAKY)            # [M, H*Hd]
         # all heads' second layers as one autograd node (no per-slice zero-filled gradients of hid)
         return HeadsLinear1Fn.apply(hid, self.fc_out.weight, self.fc_out.bias, H, Hd, O)  # [M, H, O]

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import _lib, debug
+from . import _lib, debug, rowprog
 from ._lib import lib, check
 
 
@@ -768,6 +768,11 @@ def small_embedding(idx, table):
 
 def linear(x, w, b=None, act=_lib.ACT_NONE):
     lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if rowprog.eligible(x2):
+        # a few hundred rows: one wave per 16 x 16 output tile (csrc/rowprog.hip), one launch per direction
+        (y,) = rowprog.RowNetsFn.apply(x2, None, (((act, 0, b is not None),),), w, b, None)
+        return y.reshape(*lead, y.shape[-1])
     y = LinearFn.apply(x.reshape(-1, x.shape[-1]), w, b, act)
     return y.reshape(*lead, y.shape[-1])
 

@@ -4,6 +4,7 @@ dense layers in the MFMA GEMM kernel, the weighted softmax (w**pow * exp(g - seg
 import torch
 import torch.nn as nn
 
+from . import _lib, rowprog
 from .mlp import SimpleNetwork
 from .ops import SegmentPlan, attention_pool, gather_rows, get_segment_plan
 
@@ -21,8 +22,18 @@ class WeightedAttention(nn.Module):
         if plan is None:
             n = int(index.max()) + 1 if dim_size is None else dim_size   # reference: scatter's implicit size
             plan = get_segment_plan(index, n)
-        gate = self.gate_nn(fea)                                                       # [M,1]
-        fea = self.message_nn(fea)
+        if (type(self.gate_nn) is SimpleNetwork and type(self.message_nn) is SimpleNetwork and fea.dim() == 2 and
+                rowprog.eligible(fea)):
+            # both networks read the same rows: one launch per direction for the pair (csrc/rowprog.hip)
+            nets, flat = [], []
+            for net in (self.gate_nn, self.message_nn):
+                nets.append(rowprog.mlp_spec(len(net.fcs), _lib.ACT_LEAKY))
+                for fc in list(net.fcs) + [net.fc_out]:
+                    flat += [fc.weight, fc.bias, None]
+            gate, fea = rowprog.RowNetsFn.apply(fea, None, tuple(nets), *flat)
+        else:
+            gate = self.gate_nn(fea)                                                   # [M,1]
+            fea = self.message_nn(fea)
         # (weights ** pow) * exp(gate - segmax) / (segsum + 1e-13), times the message, summed per segment (305-317)
         return attention_pool(gate, fea, plan, index, mult=weights ** self.pow, eps=1e-13)
 

@@ -18,7 +18,7 @@ import torch
 from . import _lib, debug
 from ._lib import lib, check
 
-MAX_ROWS = int(os.environ.get("CGAT_ROWPROG_MAX_ROWS", "2048"))    # 0: never (every dense layer on the generic engine)
+MAX_ROWS = int(os.environ.get("CGAT_ROWPROG_PY_MAX_ROWS", os.environ.get("CGAT_ROWPROG_MAX_ROWS", "2048")))    # 0: never (every dense layer on the generic engine)
 
 _sync = {}
 
@@ -54,7 +54,7 @@ def _st(t, transposed=False):
 
 
 def op(phase, M, N, K, A, B0, out, *, a_t=False, b0_t=False, dact=None, dact_type=0, B1=None, b1_t=False, bias=None,
-       act=0, resid=None, accumulate=False, h_out=None, rowsum=None):
+       act=0, resid=None, accumulate=False, h_out=None, rowsum=None, alpha=1.0):
     """One product of a program (cgat_rowprog_op); every operand a 2-D fp32 tensor view, `x_t`: use it transposed."""
     o = _lib.RowProgOp()
     o.phase, o.M, o.N, o.K = phase, M, N, K
@@ -69,7 +69,7 @@ def op(phase, M, N, K, A, B0, out, *, a_t=False, b0_t=False, dact=None, dact_typ
     o.act = act
     if resid is not None:
         o.resid = resid.data_ptr(); o.ld_resid = resid.stride(0)
-    o.out = out.data_ptr(); o.ldo = out.stride(0); o.accumulate = int(accumulate)
+    o.out = out.data_ptr(); o.ldo = out.stride(0); o.alpha, o.beta = alpha, (1.0 if accumulate else 0.0)
     if h_out is not None:
         o.h_out = h_out.data_ptr(); o.ld_h = h_out.stride(0)
     if rowsum is not None:
@@ -256,3 +256,62 @@ class RowNetsFn(torch.autograd.Function):
 def mlp_spec(n_hidden, act, has_bias=True):
     """SimpleNetwork: n_hidden activated layers, one linear output layer, no skips."""
     return tuple((act, 0, has_bias) for _ in range(n_hidden)) + ((_lib.ACT_NONE, 0, has_bias),)
+
+
+class RowMultiHeadFn(torch.autograd.Function):
+    """MultiHeadNetwork (CGAT.py:65-112: H independent D -> Hd -> O networks with LeakyReLU(0.01), stored as grouped 1x1
+    convolutions) on a few hundred rows: hid = leaky(fea W_in^T + b_in) for all heads as one product, then every head's
+    second layer on its column block -- two phases of ONE launch; the backward likewise (second layers' weight and input
+    gradients, then the first layer's with the activation derivative applied to the operand as it is loaded)."""
+
+    @staticmethod
+    def forward(ctx, fea, w_in, b_in, w_out, b_out, H, Hd, O):
+        dev = fea.device
+        M, D = fea.shape
+        Wi = w_in.detach().reshape(H * Hd, -1)
+        if Wi.shape[1] != D:
+            raise ValueError(f"cgat_amd.rowprog: MultiHeadNetwork expects {Wi.shape[1]} inputs, got {D}")
+        Wo = w_out.detach().reshape(H * O, Hd)
+        bi = None if b_in is None else b_in.detach()
+        bo = None if b_out is None else b_out.detach()
+        hid = torch.empty(M, H * Hd, dtype=torch.float32, device=dev)
+        out = torch.empty(M, H * O, dtype=torch.float32, device=dev)
+        ops = [op(0, M, H * Hd, D, fea, Wi, hid, bias=bi, act=_lib.ACT_LEAKY)]
+        for h in range(H):
+            ops.append(op(1, M, O, Hd, hid[:, h * Hd:(h + 1) * Hd], Wo[h * O:(h + 1) * O], out[:, h * O:(h + 1) * O],
+                          bias=None if bo is None else bo[h * O:(h + 1) * O]))
+        run(ops, dev)
+        if debug.recording():
+            debug.note(w_in, hid > 0)
+        ctx.dims = (H, Hd, O)
+        ctx.shapes = (w_in.shape, w_out.shape, b_in is not None, b_out is not None)
+        ctx.save_for_backward(fea, Wi, Wo, hid)
+        return out.reshape(M, H, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        fea, Wi, Wo, hid = ctx.saved_tensors
+        H, Hd, O = ctx.dims
+        dev = fea.device
+        M, D = fea.shape
+        g = g.reshape(M, H * O)
+        if g.dtype != torch.float32:
+            g = g.float()
+        g_hid = torch.empty(M, H * Hd, dtype=torch.float32, device=dev)
+        g_wo = torch.empty(H * O, Hd, dtype=torch.float32, device=dev)
+        g_bo = torch.empty(H * O, dtype=torch.float32, device=dev) if ctx.shapes[3] else None
+        g_wi = torch.empty(H * Hd, D, dtype=torch.float32, device=dev)
+        g_bi = torch.empty(H * Hd, dtype=torch.float32, device=dev) if ctx.shapes[2] else None
+        need_x = ctx.needs_input_grad[0]
+        g_fea = torch.empty(M, D, dtype=torch.float32, device=dev) if need_x else None
+        ops = []
+        for h in range(H):
+            gh, hh = g[:, h * O:(h + 1) * O], hid[:, h * Hd:(h + 1) * Hd]
+            ops.append(op(0, O, Hd, M, gh, hh, g_wo[h * O:(h + 1) * O], a_t=True, b0_t=True,
+                          rowsum=None if g_bo is None else g_bo[h * O:(h + 1) * O]))
+            ops.append(op(0, M, Hd, O, gh, Wo[h * O:(h + 1) * O], g_hid[:, h * Hd:(h + 1) * Hd], b0_t=True))
+        ops.append(op(1, H * Hd, D, M, g_hid, fea, g_wi, a_t=True, b0_t=True, dact=hid, dact_type=_lib.ACT_LEAKY, rowsum=g_bi))
+        if need_x:
+            ops.append(op(1, M, D, H * Hd, g_hid, Wi, g_fea, b0_t=True, dact=hid, dact_type=_lib.ACT_LEAKY))
+        run(ops, dev)
+        return (g_fea, g_wi.reshape(ctx.shapes[0]), g_bi, g_wo.reshape(ctx.shapes[1]), g_bo, None, None, None)

@@ -368,7 +368,7 @@ int cgat_dense_wgrad_batch(int32_t n, const float* const* G, int64_t ldg, const 
  * message networks (SimpleNetwork, CGAT/roost_message.py:137-153, 324-355) and the per-crystal networks of MHAttention
  * (CGAT/CGAT.py:14-62) are products over 64 ... 2 048 rows: bound by kernel boundaries, not by flops.  A program is a
  * list of products
- *     out[m,n] = act( sum_k A'(m,k) B0(n,k) + bias[n] ) [-> h_out[m,n]]  +  sum_k A(m,k) B1(n,k)  +  resid[m,n]  (+ out[m,n])
+ *     out[m,n] = act( alpha sum_k A'(m,k) B0(n,k) + bias[n] ) [-> h_out[m,n]]  +  sum_k A(m,k) B1(n,k)  +  resid[m,n]  +  beta out[m,n]
  *     A'(m,k)  = A(m,k) * dact_type'(dact(m,k))     (dact = saved activation VALUES; NULL: A' = A)
  *     rowsum[m] = sum_k A'(m,k)                       (optional: a bias gradient)
  * with X(r,k) = X[r * x_rs + k * x_ks] for A, dact, B0, B1 -- so one op is a forward layer with its residual product
@@ -394,7 +394,8 @@ typedef struct cgat_rowprog_op {
   const float* bias;  /* [N] */
   int32_t act;
   const float* resid; int64_t ld_resid;
-  float* out;         int64_t ldo;         int32_t accumulate;
+  float* out;         int64_t ldo;
+  float alpha, beta;  /* beta == 0: out is not read */
   float* h_out;       int64_t ld_h;
   float* rowsum;      /* [M] */
 } cgat_rowprog_op;

@@ -353,6 +353,11 @@ def _report(lines):
 # round 4 (f16x3c): net_mean 3 + 46 of 274 (the 46: the whole composition branch and the crystal pooling's attention
 # network, whose true gradients are ~1e-15 of the case's largest in this fixture, and the four exactly-zero MH_A output
 # biases), nodes_first0 0 + 1 of 52, nodes_first1 3 + 1 of 50; the bounds leave room for borderline roundings only.
+# Round 6: the crystal pooling's backward centres on the weighted sum divided by the rounded coefficients' own sum
+# (csrc/segment.hip), so the logit gradients of a crystal add up to zero as the exact ones do: 40 of the 46 tensors that
+# only the floor admitted before are now within 4 x the oracle's own fp32 deviation (net_mean: 228 plain + 40 noise + 6
+# floor of 274).  The terms are tried in the order 1e-4 |ref|, noise, floor -- a tensor that moves from the floor to the
+# noise term has a SMALLER error -- so the bounds are cumulative: floor <= lim[1], noise + floor <= lim[0] + lim[1].
 _ADMIT_LIMITS = {"net_mean": (6, 48), "nodes_first0": (2, 2), "nodes_first1": (6, 2)}
 
 
@@ -413,7 +418,7 @@ def test_golden_base_full_gradients_vs_oracle(cname):
     if lim is not None:
         n_noise = sum(v for k, v in admitted.items() if "noise" in k)
         n_floor = sum(v for k, v in admitted.items() if "case_scale" in k)
-        assert n_noise <= lim[0] and n_floor <= lim[1], (cname, admitted, lim)
+        assert n_floor <= lim[1] and n_noise + n_floor <= lim[0] + lim[1], (cname, admitted, lim)
 
 
 def test_config1_full_size_forward_vs_oracle():
