@@ -297,6 +297,9 @@ int mix_bwd_launch(const float* g, const float* a, const float* b, const float* 
 int scale_launch(const float* x, float alpha, float* out, long n, hipStream_t s);   // out = alpha * x
 int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s);  // y += alpha*x
 int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t s);
+struct Copy2DJob { const float* src; long lds; float* dst; long ldd; int rows, cols; };
+struct Copy2DJobs { Copy2DJob job[4]; int n; };
+int copy2d_multi_launch(const Copy2DJobs& j, hipStream_t s);   // n <= 4 copies in one launch
 int fill_launch(float* p, float v, long n, hipStream_t s);
 
 // ---- segment kernels (rows sorted by segment, rowptr[S+1]), segment.hip ----

@@ -691,12 +691,15 @@ extern "C" size_t cgat_nodes_attention_saved_floats(int32_t N, int32_t E, int32_
 }
 
 static int stack_in_weights(Ctx& c, const cgat_attn_params* p, const AttnDims& d, float* Wcat, float* bcat) {
-  RUN(copy2d_launch(p->A_in_w, d.D, Wcat, d.D, d.HHd, d.D, c.s));
-  RUN(copy2d_launch(p->M_in_w, d.D, Wcat + (size_t)d.HHd * d.D, d.D, d.HHd, d.D, c.s));
+  Copy2DJobs j;
+  j.n = bcat ? 4 : 2;
+  j.job[0] = {p->A_in_w, d.D, Wcat, d.D, d.HHd, d.D};
+  j.job[1] = {p->M_in_w, d.D, Wcat + (size_t)d.HHd * d.D, d.D, d.HHd, d.D};
   if (bcat) {
-    RUN(copy2d_launch(p->A_in_b, d.HHd, bcat, d.HHd, 1, d.HHd, c.s));
-    RUN(copy2d_launch(p->M_in_b, d.HHd, bcat + d.HHd, d.HHd, 1, d.HHd, c.s));
+    j.job[2] = {p->A_in_b, d.HHd, bcat, d.HHd, 1, d.HHd};
+    j.job[3] = {p->M_in_b, d.HHd, bcat + d.HHd, d.HHd, 1, d.HHd};
   }
+  RUN(copy2d_multi_launch(j, c.s));
   return CGAT_OK;
 }
 
@@ -720,7 +723,9 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
 
   CGAT_TRY(stack_in_weights(c, p, d, Wcat, bcat));
   // first conv layer split by operand: W_in [x_i;e;x_j] = W_i x_i + W_e e + W_j x_j
-  if (!c.dry && d.N > 0 && edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Pi, Pj, Pi, bcat)) {
+  // (a few hundred atoms: the generic branch, whose products run as 16 x 16 wave tiles -- rowprog.hip -- instead of
+  // five 256-row workgroups streaming the whole weight image: 86 -> ~10 us per projection at 1 280 atoms)
+  if (!c.dry && d.N > rowprog_max_rows() && edge_z_fast(d.C, d.W2, d.H, d.Hd, d.C, d.W2, d.W2, x, Pi, Pj, Pi, bcat)) {
     RUN(edge_z_launch(x, d.C, nullptr, Wcat, d.D, Wq, d.W2, bcat, nullptr, nullptr, nullptr, 0, Pi, d.W2, d.N, nullptr,
                       nullptr, d.H, d.Hd, nullptr, c.s));
     if (!zx)
@@ -837,9 +842,21 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
   if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
       ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
-    RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, nullptr, c.s, ns));
-    RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, nullptr, c.s,
-                       ns ? ns + 1 : nullptr));
+    if (d.N <= rowprog_max_rows()) {
+      // a few hundred atoms: the 256-row tiles of the per-edge kernel are 5 workgroups walking K = 1536 (91 us a launch
+      // at 1 280 atoms); as 16 x 16 wave tiles with the k range dealt over a workgroup's waves the chip is full
+      GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
+      g.b_kmajor = 1;
+      CGAT_TRY(c.gemm(g));
+      g = gemm_params(d.N, d.C, d.W2, Gj, d.W2, Wcat + d.C + d.Ce, d.D, g_x, d.C);
+      g.b_kmajor = 1;
+      g.beta = 1.f;
+      CGAT_TRY(c.gemm(g));
+    } else {
+      RUN(edge_ge_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 0, nullptr, c.s, ns));
+      RUN(edge_ge_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, g_x, d.C, nullptr, d.N, 1, nullptr, c.s,
+                         ns ? ns + 1 : nullptr));
+    }
     RUN(edge_gw_launch(Gi, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat, d.D, c.s, ns, ns ? ns + 2 : nullptr));
     RUN(edge_gw_launch(Gj, d.W2, 128, x, d.C, nullptr, d.N, d.W2, gw_ws, gWcat + d.C + d.Ce, d.D, c.s,
                        ns ? ns + 1 : nullptr, ns ? ns + 2 : nullptr));
@@ -1050,10 +1067,15 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   CGAT_TRY(edge_first_layer_backward_tail(c, plan, d, Wcat, gWcat, gbcat, rc_shape ? nullptr : gZ, gz_ld, gzb, Gi, Gj, true,
                                           x, e, g_x, g_e, Wq, gw_ws, have_scales ? scales : nullptr,
                                           rc_shape ? &rc : nullptr));
-  RUN(copy2d_launch(gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D, c.s));
-  RUN(copy2d_launch(gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D, c.s));
-  RUN(copy2d_launch(gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd, c.s));
-  RUN(copy2d_launch(gbcat + d.HHd, d.HHd, gr->M_in_b, d.HHd, 1, d.HHd, c.s));
+  {
+    Copy2DJobs j;
+    j.n = 4;
+    j.job[0] = {gWcat, d.D, gr->A_in_w, d.D, d.HHd, d.D};
+    j.job[1] = {gWcat + (size_t)d.HHd * d.D, d.D, gr->M_in_w, d.D, d.HHd, d.D};
+    j.job[2] = {gbcat, d.HHd, gr->A_in_b, d.HHd, 1, d.HHd};
+    j.job[3] = {gbcat + d.HHd, d.HHd, gr->M_in_b, d.HHd, 1, d.HHd};
+    RUN(copy2d_multi_launch(j, c.s));
+  }
   return check_ws(c, "nodes_attention_backward");
 }
 

@@ -300,6 +300,27 @@ int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, in
   return CGAT_OK;
 }
 
+// up to four such copies in one launch (blockIdx.y = the job): the stacking of MH_A | MH_M first-layer weights and
+// biases and the un-stacking of their gradients were four launches per pass (41 per 4-layer step)
+__global__ void copy2d_multi_kernel(Copy2DJobs j) {
+  const Copy2DJob& b = j.job[blockIdx.y];
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)b.rows * b.cols;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const long r = i / b.cols, c = i % b.cols;
+    b.dst[r * b.ldd + c] = b.src[r * b.lds + c];
+  }
+}
+int copy2d_multi_launch(const Copy2DJobs& j, hipStream_t s) {
+  long most = 0;
+  for (int k = 0; k < j.n; ++k) most = (long)j.job[k].rows * j.job[k].cols > most ? (long)j.job[k].rows * j.job[k].cols : most;
+  if (j.n <= 0 || most <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(copy2d_multi_kernel, dim3(grid_for(most), j.n), dim3(256), 0, s, j);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // Also the library's memset: NO hipMemsetAsync anywhere in the library (round 4).  A 4-byte hipMemsetAsync captured into a
 // hipGraph (cgat_amd.GraphedStep) was not reliably in effect before the kernel that followed it on the SECOND replay
 // (ROCm 7.2, memory from the capture's private pool): the slot of a maximum kept the bits a later operator of the

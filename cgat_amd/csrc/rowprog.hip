@@ -61,11 +61,14 @@ struct RowOp {
   float* rowsum;
   int a_rs, a_ks, d_rs, d_ks, b0_rs, b0_ks, b1_rs, b1_ks, ld_resid, ldo, ld_h;
   int M, N, K;
-  int act, dact_type;
   float alpha, beta;   // out = act(alpha * acc0 + bias) + acc1 + resid + beta * out
-  int nb;          // 16-column tiles per task (1, 2, 4)
-  int vec;         // RP_VEC_*: operand rows are k-contiguous and 16-byte aligned -> dwordx4 loads
-  int task_off;    // first task of this op inside its phase
+  unsigned char act, dact_type;
+  unsigned char nb;      // 16-column tiles per wave tile (1, 2, 4)
+  unsigned char ksplit;  // waves of a workgroup that share one tile, each taking every ksplit-th k group (1, 2, 4; nb == 1 if > 1)
+  unsigned char vec;     // RP_VEC_*: operand rows are k-contiguous and 16-byte aligned -> dwordx4 loads
+  unsigned char pad_[3];
+  int tiles;             // wave tiles of the op
+  int task_off;    // first WORKGROUP task of this op inside its phase (a workgroup task = 4 / ksplit wave tiles)
   int tiles_m;
 };
 
@@ -116,20 +119,31 @@ __device__ __forceinline__ v4f rp_ld4(const float* __restrict__ row, int ks, boo
   return r;
 }
 
-template <int NB>
+// Operand registers of one k group (64 / NB k values: NF dwordx4 per operand row).  EXT: the op has a derivative
+// operand and / or a second product; plain products carry neither and afford a deeper ring.
+template <int NB, bool EXT>
 struct RpFrag {
-  static constexpr int NF = 4 / NB;      // 16-k pieces per group: a group is 64 / NB k values
-  v4f a[NF], d[NF], w0[NB][NF], w1[NB][NF];
+  static constexpr int NF = 4 / NB;
+  v4f a[NF], w0[NB][NF];
+  v4f d[EXT ? NF : 1], w1[EXT ? NB : 1][EXT ? NF : 1];
 };
 
-// One task = a 16 x (16 NB) output tile by ONE wave.  MFMA 16x16x4 f64: lane l supplies A(row l%16, k = l/16) and
-// B(col l%16, k = l/16), one double each; a lane's dwordx4 along k (k = 4 (l/16) + j) feeds four instructions, both
-// operands alike (fp32 -> fp64 conversion is exact).
-template <int NB>
-__device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
-  typedef RpFrag<NB> Frag;
+// One wave tile = 16 x (16 NB) outputs.  MFMA 16x16x4 f64: lane l supplies A(row l%16, k = l/16) and B(col l%16,
+// k = l/16), one double each; a lane's dwordx4 along k (k = 4 (l/16) + j) feeds four instructions, both operands alike
+// (fp32 -> fp64 conversion is exact).
+// ksplit > 1 (NB == 1): the tile's k groups are dealt round-robin to `ksplit` waves of the workgroup (kpart = this
+// wave's share), partial sums meet in LDS in wave order and the first wave of the set finishes the tile -- a layer
+// with few output tiles and a long K (the head's 1024-wide layers at 64 rows) then keeps every wave busy with a
+// quarter of the chain.  `active` = this wave has a tile (all waves of a workgroup pass the same barriers).
+// The loads of DEPTH - 1 groups are in flight behind the group being multiplied: a group is 16 (32) matrix
+// instructions = 0.45 (0.9) us, an L2 / HBM round trip 1-2 us, and a wave is alone on its SIMD.
+template <int NB, bool EXT>
+__device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane, int kpart, int ksplit, bool active,
+                                        double* __restrict__ red, int wave) {
+  typedef RpFrag<NB, EXT> Frag;
   constexpr int NF = Frag::NF;
   constexpr int GK = 16 * NF;
+  constexpr int DEPTH = EXT ? 3 : 5;
   const int i = lane & 15, q = lane >> 4;
   const int tiles_m = op.tiles_m;
   const int nt = task / tiles_m, mt = task - nt * tiles_m;
@@ -137,7 +151,7 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
   const int M = op.M, N = op.N, K = op.K;
   const int arow = min(m0 + i, M - 1);
   const float* __restrict__ Ap = op.A + (long)arow * op.a_rs;
-  const bool has_d = op.dact != nullptr, two = op.B1 != nullptr;
+  const bool has_d = EXT && op.dact != nullptr, two = EXT && op.B1 != nullptr;
   const float* __restrict__ Dp = has_d ? op.dact + (long)arow * op.d_rs : Ap;
   const float* __restrict__ Bp0[NB];
   const float* __restrict__ Bp1[NB];
@@ -151,23 +165,25 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
   const bool va = op.vec & RP_VEC_A, vd = op.vec & RP_VEC_D, vb0 = op.vec & RP_VEC_B0, vb1 = op.vec & RP_VEC_B1;
   const int dtype = op.dact_type;
 
-  v4d acc0[NB], acc1[NB];
+  v4d acc0[NB], acc1[EXT ? NB : 1];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) acc0[b] = acc1[b] = v4d{0., 0., 0., 0.};
+  for (int b = 0; b < NB; ++b) acc0[b] = v4d{0., 0., 0., 0.};
+#pragma unroll
+  for (int b = 0; b < (EXT ? NB : 1); ++b) acc1[b] = v4d{0., 0., 0., 0.};
   double rs = 0.;
 
   auto load = [&](Frag& f, int g) {
     const int kb = g * GK + 4 * q;
-    if (kb - 4 * q + GK <= K) {
+    if (g * GK + GK <= K) {
 #pragma unroll
       for (int t = 0; t < NF; ++t) {
         const int k0 = kb + 16 * t;
         f.a[t] = rp_ld4<true>(Ap, a_ks, va, k0, K);
-        if (has_d) f.d[t] = rp_ld4<true>(Dp, d_ks, vd, k0, K);
+        if (EXT && has_d) f.d[t] = rp_ld4<true>(Dp, d_ks, vd, k0, K);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           f.w0[b][t] = rp_ld4<true>(Bp0[b], b0_ks, vb0, k0, K);
-          if (two) f.w1[b][t] = rp_ld4<true>(Bp1[b], b1_ks, vb1, k0, K);
+          if (EXT && two) f.w1[b][t] = rp_ld4<true>(Bp1[b], b1_ks, vb1, k0, K);
         }
       }
     } else {
@@ -175,11 +191,11 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
       for (int t = 0; t < NF; ++t) {
         const int k0 = kb + 16 * t;
         f.a[t] = rp_ld4<false>(Ap, a_ks, false, k0, K);
-        if (has_d) f.d[t] = rp_ld4<false>(Dp, d_ks, false, k0, K);
+        if (EXT && has_d) f.d[t] = rp_ld4<false>(Dp, d_ks, false, k0, K);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           f.w0[b][t] = rp_ld4<false>(Bp0[b], b0_ks, false, k0, K);
-          if (two) f.w1[b][t] = rp_ld4<false>(Bp1[b], b1_ks, false, k0, K);
+          if (EXT && two) f.w1[b][t] = rp_ld4<false>(Bp1[b], b1_ks, false, k0, K);
         }
       }
     }
@@ -190,29 +206,62 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float av = f.a[t][j];
-        const float at = has_d ? rp_dact(av, f.d[t][j], dtype) : av;
-        const double ad = (double)at, avd = (double)av;
+        const float at = (EXT && has_d) ? rp_dact(av, f.d[t][j], dtype) : av;
+        const double ad = (double)at;
         rs += ad;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           acc0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad, (double)f.w0[b][t][j], acc0[b], 0, 0, 0);
-          if (two) acc1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(avd, (double)f.w1[b][t][j], acc1[b], 0, 0, 0);
+          if (EXT && two) acc1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)f.w1[b][t][j], acc1[b], 0, 0, 0);
         }
       }
     }
   };
 
-  const int ng = (K + GK - 1) / GK;
-  Frag f0, f1;
-  if (ng > 0) load(f0, 0);
-  for (int g = 0; g < ng; g += 2) {          // the next group's loads are in flight behind this group's 16 (32) MFMAs
-    if (g + 1 < ng) load(f1, g + 1);
-    compute(f0);
-    if (g + 1 < ng) {
-      if (g + 2 < ng) load(f0, g + 2);
-      compute(f1);
+  // this wave's k groups: kpart, kpart + ksplit, ...
+  const int ng_all = (K + GK - 1) / GK;
+  const int ng = active ? (ng_all - kpart + ksplit - 1) / ksplit : 0;
+  auto gidx = [&](int g) { return kpart + g * ksplit; };
+  Frag ring[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s)
+    if (s < ng) load(ring[s], gidx(s));
+  for (int g = 0; g < ng; g += DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      if (g + s < ng) {
+        if (g + s + DEPTH - 1 < ng) load(ring[(s + DEPTH - 1) % DEPTH], gidx(g + s + DEPTH - 1));
+        compute(ring[s]);
+      }
     }
   }
+  if (NB == 1 && ksplit > 1) {
+    // partial sums of the set's other waves -> LDS; the set's first wave adds them in wave order
+    double* mine = red + (size_t)wave * (9 * 64);
+    if (kpart > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mine[r * 64 + lane] = acc0[0][r];
+        if (EXT) mine[(4 + r) * 64 + lane] = acc1[0][r];
+      }
+      mine[8 * 64 + lane] = rs;
+    }
+    __syncthreads();
+    if (kpart == 0) {
+      for (int w = 1; w < ksplit; ++w) {
+        const double* other = red + (size_t)(wave + w) * (9 * 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0[0][r] += other[r * 64 + lane];
+          if (EXT) acc1[0][r] += other[(4 + r) * 64 + lane];
+        }
+        rs += other[8 * 64 + lane];
+      }
+    }
+    __syncthreads();          // the slots are free again for the workgroup's next task
+    if (kpart > 0) return;
+  }
+  if (!active) return;
 
   // epilogue.  f64 16x16x4 C/D map: lane holds column n0 + 16 b + i of rows m0 + q + 4 r (r = 0..3); the fp64 sums
   // are rounded to fp32 ONCE, after alpha and the bias
@@ -233,7 +282,7 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane) {
       float* o = op.out + (long)m * op.ldo + n;
       if (two || op.resid || beta != 0.f) {
         double w = (double)v;
-        if (two) w += acc1[b][r];
+        if (EXT && two) w += acc1[b][r];
         if (op.resid) w += (double)op.resid[(long)m * op.ld_resid + n];
         if (beta != 0.f) w += (double)beta * (double)*o;
         v = (float)w;
@@ -274,22 +323,32 @@ __device__ __forceinline__ void rp_grid_barrier(unsigned* ctr, unsigned target, 
 }
 
 __global__ __launch_bounds__(RP_WG_THREADS) void rowprog_kernel(const RowProgK P) {
+  __shared__ double red[(RP_WG_THREADS / 64) * 9 * 64];      // k-split partial sums: 4 waves x (2 x 4 + 1) x 64 lanes
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * (RP_WG_THREADS / 64) + wave, nw = gridDim.x * (RP_WG_THREADS / 64);
   int op_lo = 0;
   for (int ph = 0; ph < P.n_phases; ++ph) {
     const int op_hi = P.phase_end[ph];
     const int ntasks = P.phase_tasks[ph];
-    for (int t = gw; t < ntasks; t += nw) {
+    for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {       // workgroup tasks: uniform over the workgroup
       int o = op_lo;
       while (o + 1 < op_hi && t >= P.op[o + 1].task_off) ++o;
       const RowOp& op = P.op[o];
-      const int task = t - op.task_off;
+      const int ks = op.ksplit;
+      const int tile = (t - op.task_off) * ((RP_WG_THREADS / 64) / ks) + wave / ks;
+      const bool active = tile < op.tiles;
+      const bool ext = op.dact != nullptr || op.B1 != nullptr;
       switch (op.nb) {
-        case 4: rp_tile<4>(op, task, lane); break;
-        case 2: rp_tile<2>(op, task, lane); break;
-        default: rp_tile<1>(op, task, lane); break;
+        case 4:
+          if (active) { if (ext) rp_tile<4, true>(op, tile, lane, 0, 1, true, red, wave); else rp_tile<4, false>(op, tile, lane, 0, 1, true, red, wave); }
+          break;
+        case 2:
+          if (active) { if (ext) rp_tile<2, true>(op, tile, lane, 0, 1, true, red, wave); else rp_tile<2, false>(op, tile, lane, 0, 1, true, red, wave); }
+          break;
+        default:
+          if (ext) rp_tile<1, true>(op, active ? tile : 0, lane, wave % ks, ks, active, red, wave);
+          else rp_tile<1, false>(op, active ? tile : 0, lane, wave % ks, ks, active, red, wave);
+          break;
       }
     }
     op_lo = op_hi;
@@ -318,7 +377,10 @@ int rowprog_launch(const cgat_rowprog_op* ops, int n_ops, uint32_t* sync_words, 
   RowProgK K;
   memset(&K, 0, sizeof(K));
   K.n_ops = n_ops;
-  const int total_waves = RP_MAX_WGS * (RP_WG_THREADS / 64);
+  bool multi = false;
+  for (int o = 1; o < n_ops; ++o) multi = multi || ops[o].phase != ops[0].phase;
+  // waves the program can keep busy: the resident grid of a program with barriers; two rounds of one wave per SIMD otherwise
+  const int total_waves = multi ? RP_MAX_WGS * (RP_WG_THREADS / 64) : 2048;
   int phase = -1, n_phases = 0, max_tasks = 0;
   for (int o = 0; o < n_ops; ++o) {
     const cgat_rowprog_op& in = ops[o];
@@ -338,28 +400,36 @@ int rowprog_launch(const cgat_rowprog_op* ops, int n_ops, uint32_t* sync_words, 
     op.b0_rs = (int)in.b0_rs; op.b0_ks = (int)in.b0_ks; op.b1_rs = (int)in.b1_rs; op.b1_ks = (int)in.b1_ks;
     op.ld_resid = (int)in.ld_resid; op.ldo = (int)in.ldo; op.ld_h = (int)in.ld_h;
     op.M = in.M; op.N = in.N; op.K = in.K;
-    op.act = in.act; op.dact_type = in.dact ? in.dact_type : 0;
+    op.act = (unsigned char)in.act; op.dact_type = (unsigned char)(in.dact ? in.dact_type : 0);
     op.alpha = in.alpha; op.beta = in.beta;
-    op.vec = (rp_vec_ok(in.A, in.a_rs, in.a_ks) ? RP_VEC_A : 0) | (rp_vec_ok(in.dact, in.d_rs, in.d_ks) ? RP_VEC_D : 0) |
-             (rp_vec_ok(in.B0, in.b0_rs, in.b0_ks) ? RP_VEC_B0 : 0) | (rp_vec_ok(in.B1, in.b1_rs, in.b1_ks) ? RP_VEC_B1 : 0);
+    op.vec = (unsigned char)((rp_vec_ok(in.A, in.a_rs, in.a_ks) ? RP_VEC_A : 0) | (rp_vec_ok(in.dact, in.d_rs, in.d_ks) ? RP_VEC_D : 0) |
+             (rp_vec_ok(in.B0, in.b0_rs, in.b0_ks) ? RP_VEC_B0 : 0) | (rp_vec_ok(in.B1, in.b1_rs, in.b1_ks) ? RP_VEC_B1 : 0));
     op.tiles_m = cdiv(in.M, 16);
-    // the widest tile that still gives every wave of the launch a task (A fragments are shared by a task's column tiles)
+    // the widest tile that still gives every wave of the launch a tile (A fragments are shared by a tile's column
+    // blocks); with fewer 16 x 16 tiles than waves, split the k range over 2 or 4 waves while a share keeps >= 64 k
     const int tn = cdiv(in.N, 16);
     int nb = 4;
     while (nb > 1 && (long)op.tiles_m * cdiv(tn, nb) < total_waves) nb >>= 1;
-    op.nb = nb;
+    int ks = 1;
+    if (nb == 1)
+      while (ks < 4 && (long)op.tiles_m * tn * ks * 2 <= total_waves && in.K >= 64 * ks * 2) ks <<= 1;
+    op.nb = (unsigned char)nb;
+    op.ksplit = (unsigned char)ks;
+    op.tiles = op.tiles_m * cdiv(tn, nb);
     if (in.phase != phase) {
       phase = in.phase;
       ++n_phases;
     }
     op.task_off = K.phase_tasks[n_phases - 1];
-    K.phase_tasks[n_phases - 1] += op.tiles_m * cdiv(tn, nb);
+    K.phase_tasks[n_phases - 1] += cdiv(op.tiles, (RP_WG_THREADS / 64) / ks);
     K.phase_end[n_phases - 1] = (unsigned char)(o + 1);
   }
   K.n_phases = n_phases;
   for (int p = 0; p < n_phases; ++p) max_tasks = K.phase_tasks[p] > max_tasks ? K.phase_tasks[p] : max_tasks;
-  int wgs = cdiv(max_tasks, RP_WG_THREADS / 64);
-  if (wgs > RP_MAX_WGS) wgs = RP_MAX_WGS;
+  // a program with barriers needs every workgroup resident; a single phase takes as many workgroups as it has tasks
+  int wgs = max_tasks;
+  const int cap = n_phases > 1 ? RP_MAX_WGS : 4096;
+  if (wgs > cap) wgs = cap;
   if (n_phases > 1) {
     CGAT_CHECK_ARG(sync_words && ((uintptr_t)sync_words & 63) == 0,
                    "rowprog: a program with more than one phase needs sync_words (64-byte aligned device memory)");
