@@ -232,7 +232,8 @@ extern "C" int cgat_heads_linear_backward_dact(const float* x, int64_t ldx, int6
   hipStream_t s = (hipStream_t)stream;
   const bool have_ws = ws && ws_bytes >= cgat_heads_linear_backward_dact_workspace_bytes(M, K, N, H);
   const int kb = K / 128;
-  if (have_ws && H > 1 && M > 0 && bilinear_mode() == 2 && N == 128 && K % 128 == 0 && H * kb <= DW_BATCH_MAX &&
+  if (have_ws && H > 1 && M > 0 && (bilinear_mode() == 2 || bilinear_mode() == 4 || bilinear_mode() == 6) && N == 128 &&
+      K % 128 == 0 && H * kb <= DW_BATCH_MAX &&
       heads_strides_ok(s_x, s_w, s_gy, s_gx) && heads_strides_ok(s_dact, s_gw, s_gb, ld_dact) &&
       linear128_fast(N, K, ldgy, ldgx, g_y, g_x) && (((uintptr_t)gx_dact) & 15) == 0) {
     DwBatchDesc b;

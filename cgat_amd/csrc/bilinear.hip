@@ -1283,11 +1283,15 @@ __global__ __launch_bounds__(256) void dual_finish_small_kernel(const float* __r
 // sgn(a) T[a] (sgn = (-1)^a if alternate, else 1) split into three bf16 planes in the ring kernels' fragment order
 // (layout in the header above); element (a, b, c) of the [NA,128,128] operand is src[a*sa + b*sb + c*sc].
 // F16: two fp16 planes of 2^k sgn(a) T[a], 2^k from tmax[0] = max |T| (pow2_scale), same order with 2 planes per k-step
+// blockIdx.y = head of a multi-head layer: source + head * s_head, image + head * image_elems (0, 0: one operand)
 template <bool F16>
 __global__ void prepare_T_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int NA, long sa, long sb,
-                                      long sc, int alternate, const float* __restrict__ tmax) {
+                                      long sc, int alternate, const float* __restrict__ tmax, long s_head = 0,
+                                      long image_elems = 0) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)NA * 128 * 128) return;
+  src += (long)blockIdx.y * s_head;
+  dst += (long)blockIdx.y * image_elems;
   // thread order follows the fastest source stride so that reads coalesce
   int a = (int)(i >> 14), b, c;
   if (sc == 1) { b = (int)((i >> 7) & 127); c = (int)(i & 127); }
@@ -1607,6 +1611,16 @@ int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb,
   if (total <= 0) return CGAT_OK;
   hipLaunchKernelGGL(prepare_T_bf16_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, (__bf16*)dst, NA,
                      sa, sb, sc, alternate, (const float*)nullptr);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+// the three-plane image of `heads` operands in one launch: head h reads src + h * s_head and writes dst + h * image_floats
+int prepare_T_bf16_heads_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate, int heads,
+                                long s_head, long image_floats, hipStream_t stream) {
+  long total = (long)NA * 128 * 128;
+  if (total <= 0 || heads <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(prepare_T_bf16_kernel<false>, dim3(cdiv(total, 256), heads), dim3(256), 0, stream, src, (__bf16*)dst,
+                     NA, sa, sb, sc, alternate, (const float*)nullptr, s_head, image_floats * 2);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

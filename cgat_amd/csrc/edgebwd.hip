@@ -608,10 +608,13 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
 // heads' weight maxima and fp16 planes through the batched preparation of the contraction kernels (bilinear.hip), then
 // ONE launch of the kernel above with grid.y = head.  f16x3 mode with max |x| known (amax), heads <= TPREP_MAX.
 // ws: heads * edge_ge_heads_image_floats(W2) + bilinear_prepare_T_batch_ws_floats(heads) floats.
-size_t edge_ge_heads_image_floats(int W2) { return (size_t)(W2 / 128) * 16384 + 4; }
+// (the six-pass image is the larger one: three bf16 planes per 128 x 128 block)
+size_t edge_ge_heads_image_floats(int W2) { return (size_t)(W2 / 128) * 24576 + 4; }
 bool edge_ge_heads_fast(int heads, int W2, long ldx, long ldy, long ldw, const void* x, const void* w, const void* y,
                         const float* amax) {
-  return bilinear_mode() == 2 && amax && heads >= 1 && heads <= TPREP_MAX && W2 % 128 == 0 && ldw == W2 &&
+  const bool f16 = bilinear_mode() == 2 && amax;
+  const bool six = bilinear_mode() == 4 || bilinear_mode() == 6;      // round 6: the 24-bit modes batch their heads too
+  return (f16 || six) && heads >= 1 && heads <= TPREP_MAX && W2 % 128 == 0 && ldw == W2 &&
          (((uintptr_t)w) & 15) == 0 && edge_ge_fast(128, W2, ldx, 128, ldy, x, y);
 }
 int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const float* W, long s_w, const float* bias,
@@ -620,6 +623,17 @@ int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const fl
   if (E <= 0 || heads <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   const size_t img = edge_ge_heads_image_floats(W2);
+  const HeadBatch hb = {s_x, (long)(img / 4), s_bias, s_y, 0};
+  const EdgeRC none = {};
+  if (bilinear_mode() != 2) {
+    // operand (a = column block, b = column in block, c = output k) = W_h[c * W2 + 128 a + b], as edge_ge_launch's
+    CGAT_TRY(prepare_T_bf16_heads_launch(W, ws, ncb, 128, 1, W2, /*alternate=*/1, heads, s_w, (long)img, stream));
+    CGAT_PROF("rows_ge", stream);
+    hipLaunchKernelGGL((edge_ge_kernel<6, false>), dim3(cdiv(E, 256), heads), dim3(512), 0, stream, x, ldx, 128l,
+                       (const uint4*)ws, ncb, y, ldy, (const int*)nullptr, E, 0, bias, (const float*)nullptr, none, hb);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   float* part = ws + (size_t)heads * img;
   const float* src[TPREP_MAX];
   float* dst[TPREP_MAX];
@@ -628,8 +642,6 @@ int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const fl
   const int rc_ = bilinear_prepare_T_batch(heads, src, dst, 128, ncb, 128, 1, 2, 0, part, stream, /*alternate=*/1);
   if (rc_ != CGAT_OK) return rc_;
   CGAT_PROF("rows_ge", stream);
-  const HeadBatch hb = {s_x, (long)(img / 4), s_bias, s_y, 0};
-  const EdgeRC none = {};
   hipLaunchKernelGGL((edge_ge_kernel<2, false>), dim3(cdiv(E, 256), heads), dim3(512), 0, stream, x, ldx, 128l,
                      (const uint4*)ws, ncb, y, ldy, (const int*)nullptr, E, 0, bias, amax, none, hb);
   CGAT_LAUNCH_CHECK();

@@ -1267,15 +1267,28 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
 // out + h * s_out.  The per-head second layers of a vector-attention layer at the harness' shipped batch are 2 H chains
 // of [prepare, product] launches of 20-40 us each that fill a fraction of the chip; as grid.y they are one.
 // ws: heads * linear128_heads_image_floats(n_out) floats.
-size_t linear128_heads_image_floats(int n_out) { return (size_t)(n_out / 128) * 16384 + ((n_out / 128 + 3) & ~3); }
+// (sized for the six-pass image: three bf16 planes per 128 x 128 block)
+size_t linear128_heads_image_floats(int n_out) { return (size_t)(n_out / 128) * 24576 + ((n_out / 128 + 3) & ~3); }
 int linear128_heads_launch(int heads, const float* in, long ldi, long s_in, const float* W, long so, long sk, long s_w,
                            const float* bias, long s_bias, int act, int accumulate, float* out, long ldo, long s_out, int rows,
                            void* ws, hipStream_t stream, int n_out, const float* dact, long ld_dact, long s_dact,
                            float* omax) {
   if (rows <= 0 || heads <= 0) return CGAT_OK;
-  CGAT_CHECK_ARG(bilinear_mode() == 2 && n_out % 128 == 0, "linear128_heads: f16x3 mode and 128-wide output blocks only");
+  CGAT_CHECK_ARG((bilinear_mode() == 2 || bilinear_mode() == 4 || bilinear_mode() == 6) && n_out % 128 == 0,
+                 "linear128_heads: split arithmetic modes and 128-wide output blocks only");
   const int ncb = n_out / 128;
   const long img = (long)linear128_heads_image_floats(n_out);
+  if (bilinear_mode() != 2) {     // the 24-bit modes (round 6): one image launch for all heads, one six-pass product launch
+    CGAT_TRY(prepare_T_bf16_heads_launch(W, ws, ncb, 128 * so, sk, so, 0, heads, s_w, img, stream));
+    CGAT_PROF("linear128", stream);
+    const HeadBatch hb6 = {s_in, img / 4, s_bias, s_out, s_dact};
+    hipLaunchKernelGGL((edge_z_kernel<6, false>), dim3(cdiv(rows, 128), heads), dim3(256), 0, stream, in, ldi,
+                       (const int*)nullptr, (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr,
+                       (const int*)nullptr, 0l, out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1,
+                       (float*)nullptr, act, accumulate, omax, dact, ld_dact, hb6);
+    CGAT_LAUNCH_CHECK();
+    return CGAT_OK;
+  }
   CGAT_TRY(prepare_W_f16_heads_launch(W, ws, ncb, 128 * so, sk, so, heads, s_w, img, stream));
   CGAT_PROF("linear128", stream);
   const HeadBatch hb = {s_in, img / 4, s_bias, s_out, s_dact};

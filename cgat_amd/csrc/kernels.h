@@ -120,6 +120,8 @@ int bilinear_wgrad_batch_prep(int slot, int n_layers, const float* p, long ldp, 
 // three bf16 planes of sgn(a) * src[a*sa + b*sb + c*sc] (a < NA; b, c < 128) in the ring kernels' fragment order
 int prepare_T_bf16_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate,
                           hipStream_t stream);
+int prepare_T_bf16_heads_launch(const float* src, void* dst, int NA, long sa, long sb, long sc, int alternate, int heads,
+                                long s_head, long image_floats, hipStream_t stream);
 // f16x3c image (bilinear.hip, prepare_T_f16c_kernel) of a dense-layer weight: W2 output rows of 128 inputs, row stride ldw
 size_t prepare_W_f16c_rows_floats(int W2);
 int prepare_W_f16c_rows_launch(const float* W, long ldw, int W2, void* dst, hipStream_t stream);

@@ -15,7 +15,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 # steps profiled: 12 eager + graph capture (1) + replays: normalise by the calls of a once-per-step kernel
 per=None
 for r in rows:
-    if 'bilinear_wgrad128_f16c_kernel' in r['Name']: per=int(r['Calls'])/4
+    if 'bilinear_wgrad128_f16c_kernel' in r['Name']: per=int(r['Calls'])/(5 if 'lightning' in sys.argv[1] else 4)
 if not per: per=12
 tot=0;n=0
 print(f"steps in profile ~ {per}")
