@@ -583,6 +583,33 @@ def _launch_report(step, steps, world, try_graph):
     return rep
 
 
+def _counters_of_this_build(path, mode, key=None):
+    """(data, source label, stale note): a builder-collected counter summary under profiles/ -- replayed in the line only
+    if its stamp names THIS source tree (tools/tree_id.py) and this arithmetic mode; ({}, None, why) otherwise."""
+    if not os.path.exists(path):
+        return {}, None, None
+    data = json.load(open(path))
+    if key is not None:
+        data = data.get(key, {})
+        if not data:
+            return {}, None, None
+    name = "profiles/" + os.path.basename(path) + (f"[{key}]" if key else "")
+    stamp = str(data.get("collected_at_commit", "unknown commit"))
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from tree_id import tree_id
+        mine = tree_id()
+    except Exception:
+        mine = None
+    import re
+    m = re.search(r"source tree ([0-9a-f]{16})", stamp)
+    if mine is None or m is None or m.group(1) != mine or data.get("mode", mode) != mode:
+        return {}, None, (f"{name} @ {stamp}, mode {data.get('mode', '?')}: not this build (source tree {mine}, mode {mode}) "
+                          "-- not replayed")
+    return data, (f"{name} @ {stamp} (builder-collected rocprofv3 --pmc passes of this command on this source tree, "
+                  "replayed here; not measured in this run)"), None
+
+
 def _fence(world):
     import torch.distributed as dist
     if world > 1:
@@ -845,14 +872,17 @@ def main():
         # the same timed region in the other arithmetic modes: a FRESH child process per mode (no process-global switch
         # behind this process' back), the same --steps / --warmup, no CPU leg, no further legs
         import subprocess
+        # every child runs THIS line's configuration: the same edge storage and neighbour count
+        same_cfg = ["--graphs", str(args.graphs), "--edge-storage", args.edge_storage] + \
+                   (["--nbrs", str(args.nbrs)] if args.nbrs else []) + ["--workload", args.workload]
         for m in ("f16x3c", "bf16x6", "f16x3", "f32"):
-            if m == mode:
+            if m == mode or (m == "f32" and args.edge_storage == "bf16"):      # (the f32 mode has no bf16 storage)
                 continue
             k, w = (args.steps, args.warmup) if m != "f32" else (max(3, args.steps // 4), 2)
-            cmd = [sys.executable, os.path.abspath(__file__), "--mode", m, "--steps", str(k), "--warmup", str(w),
-                   "--graphs", str(args.graphs), "--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", m, "--steps", str(k), "--warmup", str(w)] + same_cfg + \
+                  ["--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                 modes_ms[m] = float(json.loads(line)["ms_per_step"])
             except Exception as ex:                        # a failed leg must not take the headline down with it
@@ -862,9 +892,9 @@ def main():
         # modes, cgat_amd/ops.py: it halves the chip for the dominant kernel's launch) -- informational, never `value`
         if not ops.overlap_enabled():
             cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", str(args.steps), "--warmup",
-                   str(args.warmup), "--graphs", str(args.graphs), "--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
+                   str(args.warmup)] + same_cfg + ["--no-cpu-baseline", "--no-extra-legs", "--no-exclusive-pass"]
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=180,
                                    env=dict(os.environ, CGAT_OVERLAP_WGRAD="1"))
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                 side_ms = float(json.loads(line)["ms_per_step"])
@@ -926,11 +956,10 @@ def main():
                     f"f32-input MFMA roof would be {MFMA_F32_PEAK_TFLOPS}")
         # NOT measured in this run: HBM bytes per launch and matrix-core busy cycles come from separate rocprofv3 --pmc
         # passes of this same command, collected by the builder and committed under profiles/; the line says so
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json")
-        traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
-        traffic_src = ("profiles/pmc_contraction_kernels.json @ " + str(traffic.get("collected_at_commit", "unknown commit")) +
-                       " (builder-collected rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, replayed here; "
-                       "not measured in this run)") if traffic else None
+        # They are only replayed when they were collected on THIS source tree in THIS arithmetic mode (tools/tree_id.py: the
+        # stamp carries the sha of the sources the profiled build was made from); otherwise the fields are null and
+        # `stale_counters` says what was found
+        traffic, traffic_src, stale = _counters_of_this_build(os.path.join(ROOT, "profiles", "pmc_contraction_kernels.json"), mode)
         per_kernel, roof = {}, None
         for tag, kname in kernels.items():
             n_t, ms_t = prof[tag]
@@ -969,12 +998,13 @@ def main():
                                                                         "ms_per_step", "traffic", "concurrent", "exclusive")
                                                      if k in v}
                                                  for t, v in per_kernel.items() if t != dom}
-            counters_file = os.path.join(ROOT, "profiles", "mfma_counters.json")
-            if os.path.exists(counters_file):              # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x clock x time)
-                cnt = json.load(open(counters_file))
-                cnt["source"] = ("profiles/mfma_counters.json @ " + str(cnt.get("collected_at_commit", "unknown commit")) +
-                                 " (builder-collected rocprofv3 --pmc pass, replayed here; not measured in this run)")
+            # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x clock x time)
+            cnt, cnt_src, cnt_stale = _counters_of_this_build(os.path.join(ROOT, "profiles", "mfma_counters.json"), mode)
+            if cnt:
+                cnt["source"] = cnt_src
                 roof["mfma_utilisation_from_counters"] = cnt
+            if stale or cnt_stale:
+                roof["stale_counters"] = "; ".join(x for x in (stale, cnt_stale) if x)
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
         W2b = 2 * HEADS * 256 * (2 if args.edge_storage == "bf16" else 4)
@@ -1005,14 +1035,29 @@ def main():
                 tb = traffic.get("hbm_bound_kernels", {}) if (args.workload == "layer" and args.graphs == GRAPHS and
                                                                 args.edge_storage == "f32") else {}
                 cbytes = sum(tb[k]["hbm_bytes_largest_launch"] for k in kn) if all(k in tb for k in kn) else None
+                csrc = traffic_src
+                per_launch = False
+                if stress and args.graphs == 50000 and K_used == 64:
+                    # the 64 M-edge step runs closed chunks of equal size: counter bytes of ONE chunk's launch of each
+                    # kernel (profiles/pmc_stress_kernels.json, keyed by edge storage) against that launch's mean duration
+                    st_all, st_src, st_stale = _counters_of_this_build(
+                        os.path.join(ROOT, "profiles", "pmc_stress_kernels.json"), mode,
+                        key="stress" if args.edge_storage == "f32" else "stress_bf16")
+                    sb = st_all.get("hbm_bytes_largest_launch", {})
+                    if all(k in sb for k in kn):
+                        cbytes, csrc, per_launch = sum(sb[k] for k in kn), st_src, True
                 hbm[tag] = {"bound": "hbm", "kernel": " + ".join(kn),
                             "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(gbs / 8000.0, 4),
                             "what": "achieved / frac: ALGORITHMIC bytes over the tag's time; traffic: HBM bytes from the PMC "
                                     "counters (2 x FETCH_SIZE + WRITE_SIZE); frac_from_counters: those over the same time -- "
                                     "gathers of per-node rows that hit in L2 are algorithmic bytes, not HBM bytes",
-                            "traffic": cbytes, "traffic_source": traffic_src if cbytes else None,
-                            "frac_from_counters": round(cbytes / (ms_t / args.steps * 1e-3) / 8e12, 4) if cbytes else None,
+                            "traffic": cbytes, "traffic_source": csrc if cbytes else None,
+                            # headline batch: one launch of each kernel per step -> bytes of the step over the tag's time in
+                            # the step; stress: one chunk's launches over the mean duration of one launch of each kernel
+                            "frac_from_counters": (round(cbytes / ((ms_t / n_t * len(kn) if per_launch else ms_t / args.steps)
+                                                                   * 1e-3) / 8e12, 4)
+                                                   if cbytes and (per_launch or n_t / args.steps == len(kn)) else None),
                             "launches_per_step": n_t / args.steps,
                             "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
                             "algorithmic_bytes_per_launch": int(nbytes / (n_t / args.steps))}

@@ -8,6 +8,13 @@ SRCS=(api gemm gemmsplit bilinear wgradc edgez edgebwd rowsdw collate optim rowo
 OBJS=()
 PIDS=()
 mkdir -p "$HERE/csrc/build"
+# objects are stale when the extra flags they were compiled with differ from this call's (a dev tool's -D... ablation must
+# never survive into a later default build: staleness by mtime alone kept the flagged object)
+FLAGS_STAMP="$HERE/csrc/build/.hipcc_flags"
+if [ ! -f "$FLAGS_STAMP" ] || [ "$(cat "$FLAGS_STAMP")" != "${CGAT_HIPCC_FLAGS}" ]; then
+  rm -f "$HERE"/csrc/build/*.o
+  printf '%s' "${CGAT_HIPCC_FLAGS}" > "$FLAGS_STAMP"
+fi
 for s in "${SRCS[@]}"; do
   src="$HERE/csrc/$s.hip"; obj="$HERE/csrc/build/$s.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/kernels.h" -nt "$obj" ] || [ "$HERE/csrc/common.h" -nt "$obj" ] || [ "$HERE/csrc/mfma_bf16.h" -nt "$obj" ] || [ "$HERE/csrc/wgrad_batch.h" -nt "$obj" ] || [ "$HERE/../include/cgat_hip.h" -nt "$obj" ]; then

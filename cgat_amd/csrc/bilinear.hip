@@ -538,7 +538,10 @@ __global__ __launch_bounds__(512, 2) void bilinear_rows128_ring16c_kernel(
 #pragma unroll
   for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(acc[i]));
 
-#ifndef RC_ABL
+#if !defined(CGAT_DEV_ABLATIONS)   // the product build: the timing-only variants below do not exist, whatever -DRC_ABL says
+#undef RC_ABL
+#define RC_ABL 0
+#elif !defined(RC_ABL)
 #define RC_ABL 0   // timing-only ablations (wrong results; tools/rc_ablate.sh): 1 no LDS-DMA, 2 no fragment reads, 4 no matrix
 #endif             // instructions, 8 no flush, 16 no wait + barrier per chunk
 #define RC_TLOAD(gi_)                                                                          \

@@ -329,7 +329,10 @@ int prepare_W_x6_batch_launch(const WPrepBatch& b, float* dst, hipStream_t strea
 }
 
 // (the body as a device function: the single and the batched kernel below call it with their descriptor)
-#ifndef CX_ABL
+#if !defined(CGAT_DEV_ABLATIONS)   // the product build: the timing-only variants below do not exist, whatever -DCX_ABL says
+#undef CX_ABL
+#define CX_ABL 0
+#elif !defined(CX_ABL)
 #define CX_ABL 0   // timing-only ablations (wrong results): 1 no epilogue loads (bias, residual, derivative, accumulate), 2 no stores
 #endif
 __device__ __forceinline__ void mlp_chain128_x6_body(const ChainDesc& d) {

@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
 // epilogue drains that epilogue's stores (in-order vmcnt) and its gathers are requested where they are used: 3.2 ms at the
 // BASELINE shape with 1.9 ms of matrix work and 0.66 of wave cycles waiting on memory.
 // ---------------------------------------------------------------------------------------
-#ifndef EZC_ABL
+#if !defined(CGAT_DEV_ABLATIONS)   // the product build: the timing-only variants below do not exist, whatever -DEZC_ABL says
+#undef EZC_ABL
+#define EZC_ABL 0
+#elif !defined(EZC_ABL)
 #define EZC_ABL 0   // timing-only ablations (wrong results): 1 no Z stores, 2 no gathers, 4 no matrix instructions
 #endif
 template <bool ZB>

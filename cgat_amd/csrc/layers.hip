@@ -678,10 +678,15 @@ static int edge_storage() {
 extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = (mode == 1 || mode == 2) ? mode : 0; }
 extern "C" int32_t cgat_get_edge_storage(void) { return edge_storage(); }
 // (f16x3: the K = 256 per-edge forward and the one-kernel segment backward; the 24-bit modes: the six-pass per-edge forward,
-// the weighted sum and the three-kernel segment backward; the f32 mode has no bf16 storage: cgat_set_edge_storage fails)
+// the weighted sum and the three-kernel segment backward, which exist at Hd == 256 only; the f32 mode has no bf16 storage.
+// A layer this predicate rejects makes cgat_nodes_attention_forward return CGAT_ERR_UNSUPPORTED under edge storage "bf16"
+// -- the forward refuses what the backward could not handle (Hd = 128 / 384 ran forward and failed in backward).)
 static bool attn_bf16(const AttnDims& d) {
-  return edge_storage() == 1 && bilinear_mode() != 0 && bilinear_mode() != 3 && d.C == 128 && d.Ce == 128 && d.Hd % 128 == 0 && d.W2 % 256 == 0 &&
-         d.N > 0 && d.E > 0;
+  if (!(edge_storage() == 1 && bilinear_mode() != 0 && bilinear_mode() != 3 && d.C == 128 && d.Ce == 128 &&
+        d.Hd % 128 == 0 && d.W2 % 256 == 0 && d.N > 0 && d.E > 0))
+    return false;
+  if (bilinear_mode() != 2 && !(d.Hd == 256 && d.Hd % 4 == 0)) return false;   // seg_bwd_msg / _att<true>: two 128-column blocks per head
+  return true;
 }
 
 // (the saved buffer keeps its fp32 size in either storage mode: bf16 Z uses the first half of its region)

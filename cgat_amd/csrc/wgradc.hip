@@ -41,7 +41,10 @@ typedef __bf16 bf16x32 __attribute__((ext_vector_type(32)));
 #ifndef WGC_PRIO
 #define WGC_PRIO 2
 #endif
-#ifndef WGC_ABL
+#if !defined(CGAT_DEV_ABLATIONS)   // the product build: the timing-only variants below do not exist, whatever -DWGC_ABL says
+#undef WGC_ABL
+#define WGC_ABL 0
+#elif !defined(WGC_ABL)
 #define WGC_ABL 0                           // timing-only ablations (wrong results): 1 no q loads, 2 no split arithmetic,
 #endif                                      // 4 no LDS fragment reads, 8 no LDS-DMA, 16 no matrix instructions
 
@@ -184,6 +187,9 @@ __global__ __launch_bounds__(512, 2) void bilinear_wgrad128_f16c_kernel(const fl
                                                                         const unsigned char* __restrict__ Rs_,
                                                                         const float* __restrict__ mx_,
                                                                         WgradBatchDesc u) {
+#if defined(WGC_STAMPS) && !defined(CGAT_DEV_ABLATIONS)
+#error "WGC_STAMPS is a diagnostic build: add -DCGAT_DEV_ABLATIONS"
+#endif
 #ifdef WGC_STAMPS   // diagnostic build (tools/wgrad_stamps.py): s_memtime at the phase boundaries of iterations 100..103 of
   // workgroup 0, left in out[0] instead of that workgroup's results
   __shared__ __attribute__((aligned(16))) unsigned char smem[WGC_SLOTS * WGC_SLOT_B + 2048];

@@ -72,17 +72,27 @@ class GradientAverager:
       FROZEN -- `finish()` then issues no bitmap all-reduce and, above all, no host synchronisation (reading the bitmap
       drains the launch queue: +2.3 ms on the 24.4 ms layer step, measured over a one-rank RCCL communicator); the
       all-reduces are only stream-ordered.  A cold parameter that receives a gradient on some rank after that raises on
-      EVERY rank at the following finish() (a 4-byte flag is all-reduced asynchronously each step and read without
-      blocking one step later: no rank is left waiting in a collective), a hot one that receives none contributes zeros
-      and keeps its (zero-mean) gradient instead of None.
+      EVERY rank in the same finish() call, VIOL_LAG = 2 steps after the step that did it (an 8-byte flag is all-reduced
+      asynchronously each step and its pinned copy is read two steps later: no rank is left waiting in a collective).
+      Until then the replicas have already taken two optimiser steps on the un-reduced -- rank-divergent -- gradient of
+      that parameter: the error means "these replicas have diverged, restart with static_graph=False", it does not
+      prevent the divergence.  Reading the two-step-old flag blocks the host on that step's event, which also bounds the
+      host's run-ahead to two steps.  A hot parameter that receives no gradient contributes zeros and keeps its
+      (zero-mean) gradient instead of None.
     * `force=True` keeps all of this alive at world size 1 (a one-rank communicator): the mean is
       then the identity, and the hooks, the asynchronous collectives and their interplay with the
       layer's side stream can be exercised over RCCL on a single GPU (tests/test_rccl_one_rank.py).
 
+    * `bucket_bytes` (default 8 MB since round 6; 64 MB before): the headline layer's gradients are 37.9 MB -- one 64-MB
+      bucket launched behind the LAST gradient, i.e. no overlap with backward at all; at 8 MB the four 8.45-MB hypernetwork
+      head weights are buckets of their own and the rest packs into a fifth and sixth, each launched from the hook of its
+      last gradient while backward is still running.  A ring all-reduce over 7 xGMI links moves 8 MB in ~50 us: still
+      bandwidth-, not latency-bound.
+
     `stats` after each `finish()`: buckets launched from the hooks (i.e. overlapped with backward)
     and in finish(), cold buckets reduced / skipped, bytes reduced."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, force=False, static_graph=False):
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, force=False, static_graph=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -235,11 +245,21 @@ class GradientAverager:
         leave the others waiting in their next collective, so the violation travels: every step all-reduces one flag
         (8 bytes, asynchronous, stream-ordered; the flag also carries the previous step's global result, so a violation
         stays visible) and copies the sum to pinned memory behind an event.  The entries form a FIFO -- none is ever
-        overwritten -- and the entry of step k is read in the finish() of step k + VIOL_LAG ON EVERY RANK (blocking on an
-        event that is two steps old, i.e. for free): the value is global, the step is fixed, so all ranks raise in the
-        same call and none is left waiting in a collective.  (Round 4 looked at a single slot with event.query(): a
+        overwritten -- and the entry of step k is read in the finish() of step k + VIOL_LAG ON EVERY RANK (blocking the
+        HOST on an event that is two steps old: no GPU idle time, but the host cannot run more than two steps ahead of
+        the device): the value is global, the step is fixed, so all ranks raise in the same call and none is left
+        waiting in a collective.  (Round 4 looked at a single slot with event.query(): a
         not-yet-ready flag was overwritten by the next step's, and readiness differed between ranks.)"""
-        self._check_violation()
+        try:
+            self._check_violation()
+        except RuntimeError:
+            # leave the averager usable (and this step's collectives consumed) before the error travels up: every rank
+            # raises in this same call, so every rank waits the same hot-bucket works
+            for bi in range(self.n_hot):
+                if self._works[bi] is not None:
+                    self._works[bi].wait()
+            self._reset()
+            raise
         local = any(self._used[i] for i in self._cold)
         dev = self.flat[0].device if self.flat else torch.device("cpu")
         flag = torch.full((1,), 1 if local else 0, dtype=torch.int64, device=dev)

@@ -236,17 +236,44 @@ def test_bf16_edge_storage_is_never_silently_ignored():
     N, E = b.num_nodes, b.edge_index.shape[1]
     ei = b.edge_index.to(dev)
 
-    def layer_out(C):
+    def layer_out(C, backward=False):
         torch.manual_seed(3)
         layer = P.GATConvNodes(C, C, C, 3, concat=True).to(dev)
         x, e, x0 = (torch.randn(n, C, generator=g).to(dev) for n in (N, E, N))
+        if backward:                                    # the backward has its own refusals: run it too
+            x.requires_grad_(True); e.requires_grad_(True)
+            y = layer(x, ei, e, x0)
+            y.square().sum().backward()
+            assert torch.isfinite(x.grad).all() and torch.isfinite(e.grad).all()
+            return y.detach()
         return layer(x, ei, e, x0)
+
+    def raw_attention(Hd):
+        """The fused scalar-attention op through the C ABI with a hidden width the module never builds (Hd != 256)."""
+        from cgat_amd import ops
+        H, C = 3, 128
+        D = 3 * C
+        plan = ops.get_plan(ei, N)
+        x, e = torch.randn(N, C, generator=g).to(dev).requires_grad_(True), torch.randn(E, C, generator=g).to(dev)
+        ws = [torch.randn(H * Hd, D, generator=g).to(dev) * 0.05, torch.zeros(H * Hd, device=dev),
+              torch.randn(H, Hd, generator=g).to(dev) * 0.05, torch.zeros(H, device=dev),
+              torch.randn(H * Hd, D, generator=g).to(dev) * 0.05, torch.zeros(H * Hd, device=dev),
+              torch.randn(H * C, Hd, generator=g).to(dev) * 0.05, torch.zeros(H * C, device=dev)]
+        y = ops.NodesAttentionFn.apply(x, e, plan, H, *ws)
+        y.sum().backward()
+        return y
     mode0 = P.get_bilinear_mode()
     P.set_edge_storage("bf16")
     try:
         for mode in ("f16x3c", "bf16x6", "f16x3"):
             P.set_bilinear_mode(mode)
-            assert torch.isfinite(layer_out(128)).all()
+            assert torch.isfinite(layer_out(128, backward=True)).all()
+        for mode in ("f16x3c", "bf16x6"):
+            # Hd = 128 / 384: the 24-bit modes' bf16 backward exists at Hd == 256 only -- the FORWARD must refuse
+            P.set_bilinear_mode(mode)
+            for Hd in (128, 384):
+                with pytest.raises(RuntimeError, match="bf16"):
+                    raw_attention(Hd)
         P.set_bilinear_mode("f32")
         with pytest.raises(RuntimeError, match="bf16"):
             layer_out(128)

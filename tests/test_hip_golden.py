@@ -18,6 +18,8 @@ from golden_util import check_case, floor_open, maxnorm_rel
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# largest |z| / max|z| of a pre-activation whose forced LeakyReLU / ReLU derivative may differ from the oracle's own
+MAX_FORCED_REL_Z = 1e-5
 
 
 def product_ns():
@@ -127,6 +129,10 @@ def _compare_with_oracle(mk_prod, mk_orac, inputs, call, tol=TOL, label=None):
     assert f32.stats["layers"] > 0 or not masks, "no activation layer of the oracle took a recorded mask"
     assert all(not v for v in f32.masks.values()), "recorded masks the oracle never consumed: " + \
         ", ".join(k for k, v in f32.masks.items() if v)
+    # forcing the HIP run's derivative pattern must only ever move pre-activations that are ZERO at fp32 resolution: a
+    # wrong-sign bug on a large |z| would otherwise hide behind the mechanism
+    assert f32.stats["max_rel_z"] <= MAX_FORCED_REL_Z, (
+        f"a forced derivative pattern disagrees with the oracle's own sign at |z| / max|z| = {f32.stats['max_rel_z']:.2e}")
     failures, worst = [], 0.0
     case_scale = max(float(b.detach().abs().max()) for b in go64 if b is not None)
     import os
@@ -383,10 +389,16 @@ def test_golden_base_full_gradients_vs_oracle(cname):
         held["masks"] = cm.masks
         return cm
     yp, gp, _ = recipe.run_case(pc, torch.float32, device="cuda:0", ctx=rec)
-    forced = lambda mod: O.forced_masks(mod, held["masks"])
+    forced_ctxs = []
+
+    def forced(mod):
+        forced_ctxs.append(O.forced_masks(mod, held["masks"]))
+        return forced_ctxs[-1]
     yo, go, _ = recipe.run_case(oc, torch.float32, device="cpu", ctx=forced)
     yo64, go64, _ = recipe.run_case(oc, torch.float64, device="cpu", ctx=forced)
     assert maxnorm_rel(yp.detach().cpu().numpy(), yo64.detach().numpy()) <= TOL
+    for fc in forced_ctxs:        # the forced patterns only moved pre-activations that are zero at fp32 resolution
+        assert fc.stats["max_rel_z"] <= MAX_FORCED_REL_Z, fc.stats
     case_scale = max(float(g.abs().max()) for g in go64.values() if g is not None)
     lines = [f"[{cname}] mode {_mode()} (derivative patterns forced)",
              "  tensor | err/|ref| | err/nf | (hip-ref64)/nf | nf/|ref| | admitted by"]
@@ -471,6 +483,7 @@ def test_dynamic_range_inside_one_batch():
     with O.forced_masks(om, masks) as forced:    # ... forced on the oracle: no flip allowance below
         xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
         gxo, geo = torch.autograd.grad((om(xo, b.edge_index, eo, x0.double()) * cot.double()).sum(), [xo, eo])
+    assert forced.stats["max_rel_z"] <= MAX_FORCED_REL_Z, forced.stats
     worst = [f"  derivative pattern forced in {forced.stats['layers']} layers; {forced.stats['disagree']} of "
              f"{forced.stats['elements']} pre-activations on the other side of 0 in the oracle's fp64 run "
              f"(largest |z| / max|z| among them {forced.stats['max_rel_z']:.1e})"]
@@ -621,6 +634,66 @@ def test_million_edge_properties():
     assert torch.isfinite(y).all()
     assert maxnorm_rel(y_perm.cpu().numpy(), y.cpu().numpy()) <= 1e-5
     assert maxnorm_rel(y_sub.cpu().numpy(), y[:n_sub].cpu().numpy()) <= 1e-5
+
+
+# parameter gradients are sums over all rows of the batch: inside the big batch the same terms are added in a different
+# tree (with exact zeros from the other crystals between them)
+STACK_LOCALITY_TOL = 2e-5
+
+
+def test_million_edge_stack_fwd_bwd_locality():
+    """BASELINE configs[2] at FULL size -- CGAtNet(200, 128, 4 layers, 3 heads), forward + backward, E = 1 000 080 --
+    through a property that needs no oracle run: crystals are independent (no edge and no composition pair crosses
+    them), so with a cotangent that is non-zero on the first 50 crystals only, their outputs, the gradient of their
+    inputs and EVERY parameter gradient must equal those of the 50 crystals evaluated alone (1e-5 of each tensor's
+    largest entry: the summation orders differ)."""
+    import cgat_amd as P
+    dev = "cuda:0"
+    G, A, K, GS = 4167, 20, 12, 50
+    b, roost = P.synthetic_batch(G, A, K, seed=0)
+    assert b.edge_index.shape[1] == 1000080
+    torch.manual_seed(1)
+    net = P.CGAtNet(200, 128, 4, msg_heads=3, neighbor_number=K, update_edges=True).to(dev)
+    params = dict(net.named_parameters())
+    cot = torch.randn(GS, 2, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def run(bb, rr):
+        bb = bb.to(dev)
+        rr = tuple(t.to(dev) for t in rr)
+        bb.x.requires_grad_(True)
+        out = net(bb, rr)
+        g = torch.autograd.grad((out[:GS] * cot).sum(), [bb.x] + list(params.values()), allow_unused=True)
+        return out[:GS].detach(), g[0].detach(), [None if t is None else t.detach() for t in g[1:]]
+
+    y_big, gx_big, gp_big = run(b, roost)
+    # the first GS crystals alone: atoms, edges and composition rows of a crystal are contiguous blocks
+    n_sub, e_sub = GS * A, GS * A * K
+    w, fea, sidx, nidx, cidx = roost
+    nc_sub = int((cidx < GS).sum())
+    mc_sub = int((sidx < nc_sub).sum())
+    sub = P.GraphBatch(b.x[:n_sub].clone(), b.edge_index[:, :e_sub].clone(), b.edge_attr[:e_sub].clone(),
+                       b.batch[:n_sub].clone(), b.y[:GS].clone(), num_graphs=GS)
+    sub_roost = (w[:nc_sub].clone(), fea[:nc_sub].clone(), sidx[:mc_sub].clone(), nidx[:mc_sub].clone(), cidx[:nc_sub].clone())
+    y_sub, gx_sub, gp_sub = run(sub, sub_roost)
+    assert torch.isfinite(y_big).all()
+    assert maxnorm_rel(y_big.cpu().numpy(), y_sub.cpu().numpy()) <= 1e-5
+    assert maxnorm_rel(gx_big[:n_sub].cpu().numpy(), gx_sub.cpu().numpy()) <= 1e-5
+    assert float(gx_big[n_sub:].abs().max()) == 0.0          # nothing leaks into the other 4 117 crystals
+    worst = 0.0
+    case_scale = max(float(c.abs().max()) for c in gp_sub if c is not None)
+    for name, a, c in zip(params, gp_big, gp_sub):
+        assert (a is None) == (c is None), name
+        if a is None:
+            continue
+        ref_max = float(c.abs().max())
+        abs_err = float((a - c).abs().max())
+        if ref_max <= NUM_ZERO * case_scale:       # zero in exact arithmetic (softmax shift invariance): rounding noise
+            assert abs_err <= ZERO_FLOOR * case_scale, (name, abs_err, ref_max)
+            continue
+        worst = max(worst, abs_err / ref_max)
+        assert abs_err <= STACK_LOCALITY_TOL * ref_max, (name, abs_err / ref_max)
+    _report([f"[4-layer stack fwd+bwd locality at E = 1 000 080] mode {_mode()}: 50 crystals inside the batch vs alone, "
+             f"{len(params)} parameter gradients, worst max-norm rel difference {worst:.2e}"])
 
 
 @pytest.mark.gpu

@@ -7,6 +7,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-r05final}
 mkdir -p $O
+python3 $R/tools/tree_id.py > $O/tree_id.txt
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 Q="--no-cpu-baseline --no-exclusive-pass --no-extra-legs"

@@ -31,13 +31,11 @@ def main():
         print(k[:60].ljust(60), " ".join(f"{c}={v:.4g}" for c, v in row.items()))
     if os.environ.get("COUNTER_JSON"):
         # compact form for the bench line: the kernels that use the matrix cores, utilisation to 3 digits
-        import subprocess
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        try:
-            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
-        except Exception:
-            commit = "unknown"
-        brief = {"collected_at_commit": commit + " (HEAD when the counters were summarised; the build profiled is that tree)",
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from tree_id import stamp
+        # the collection directory (parent of the pass directory) holds the tree id the GPU box computed
+        commit = stamp(os.path.dirname(os.path.abspath(sys.argv[1].rstrip("/"))))
+        brief = {"collected_at_commit": commit,
                  "what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per kernel, mean over its "
                          "launches; rocprofv3 --pmc serialises kernels and the pass runs with CGAT_OVERLAP_WGRAD=0, "
                          "so every kernel has the whole chip",

@@ -34,7 +34,24 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") 
     f.write("kernel,dispatches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
     for r in rows:
         f.write("%s,%d,%.1f,%.1f,%d\n" % r)
+HBM_KERNELS = ("edge_z_kernel", "edge_z6w_kernel", "edge_zx_kernel", "seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel",
+               "edge_seg_bwd_kernel", "seg_wsum_vec_kernel", "seg_softmax_fwd_kernel", "edge_gj_kernel", "edge_ge_kernel",
+               "edge_gw_kernel", "mlp_chain128_x6_kernel", "rows_dw128_split_batch_kernel")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tree_id import stamp
+commit = stamp(os.path.dirname(os.path.abspath(fetch_dir.rstrip("/"))))
+MODE = os.environ.get("CGAT_BILINEAR_MODE", "f16x3c")
 if CSV_ONLY:
+    # other workloads (the 64 M-edge stress step, fp32 / bf16 edge storage): the largest launch of every HBM-bound kernel
+    # = one closed chunk's per-edge launch, for bench.py's frac_from_counters of that workload
+    sf = os.path.join(ROOT, "profiles", "pmc_stress_kernels.json")
+    allw = json.load(open(sf)) if os.path.exists(sf) else {}
+    allw[tag.split("_", 1)[1] if "_" in tag else tag] = {
+        "collected_at_commit": commit, "mode": MODE,
+        "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+        "hbm_bytes_largest_launch": {k: int((2 * max(fetch.get(k, [0.0])) + max(write.get(k, [0.0]))) * 1024)
+                                     for k in HBM_KERNELS if k in fetch or k in write}}
+    json.dump(allw, open(sf, "w"), indent=1)
     sys.exit(0)
 N, C = 83340, 128
 # f16x3: the prepared T / r operands are two fp16 planes = 4 bytes per element; f16x3c (the default since round 4): the
@@ -49,17 +66,7 @@ alg = {"bilinear_rows128_ring16_kernel": 4 * N * C * 4 + C ** 3 * 4,           #
        # the batched f16x3c launch (round 5), four predicted layers: pT, qF (fp32), the r stream of 50 KB per 64 rows
        # (6.25 bytes per element), out
        "bilinear_wgrad128_f16c_kernel": 4 * (2 * N * C * 4 + (N // 64 + 1) * 51200 + C ** 3 * 4)}
-# HBM-bound kernels of the edge phase (bench.py hbm_bound_kernels: the fraction of 8 TB/s from COUNTER bytes): reported as
-# measured, no algorithmic figure here (bench.py holds it)
-HBM_KERNELS = ("edge_z_kernel", "edge_z6w_kernel", "edge_zx_kernel", "seg_bwd_msg_kernel", "seg_bwd_soft_kernel", "seg_bwd_att_kernel",
-               "edge_seg_bwd_kernel", "seg_wsum_vec_kernel", "seg_softmax_fwd_kernel", "edge_gj_kernel", "edge_ge_kernel",
-               "edge_gw_kernel", "mlp_chain128_x6_kernel", "rows_dw128_split_batch_kernel")
-import subprocess
-try:
-    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
-except Exception:
-    commit = "unknown"
-out = {"collected_at_commit": commit + " (HEAD when the counters were summarised; the build profiled is that tree)",
+out = {"collected_at_commit": commit, "mode": MODE,
        "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py "
                   "--steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
        "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE halves wide coalesced reads)"}

@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 for abl in 0 1 2 4 8 16 3 5 6 12 20 7 15 31 0; do
   touch cgat_amd/csrc/bilinear.hip
-  CGAT_HIPCC_FLAGS="-DRC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "RC_ABL=$abl build failed"; continue; }
+  CGAT_HIPCC_FLAGS="-DCGAT_DEV_ABLATIONS -DRC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "RC_ABL=$abl build failed"; continue; }
   timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --no-exclusive-pass --steps 10 --warmup 3 2>/dev/null | python -c "
 import json,sys
 try:
@@ -14,3 +14,5 @@ try:
 except Exception as e: print('RC_ABL=$abl failed', e)
 "
 done
+# leave the product build behind (build_lib.sh rebuilds when the flags it was built with change)
+bash cgat_amd/build_lib.sh > /dev/null 2>&1

@@ -5,7 +5,9 @@
 cd "$(dirname "$0")/.."
 for abl in "$@" 0; do
   touch cgat_amd/csrc/wgradc.hip
-  CGAT_HIPCC_FLAGS="-DWGC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "build failed for $abl"; continue; }
+  CGAT_HIPCC_FLAGS="-DCGAT_DEV_ABLATIONS -DWGC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "build failed for $abl"; continue; }
   echo "== WGC_ABL=$abl"
   python tools/wgrad_probe.py 83340 2>&1 | grep "unit  f16x3c"
 done
+# leave the product build behind (build_lib.sh rebuilds when the flags it was built with change)
+bash cgat_amd/build_lib.sh > /dev/null 2>&1

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for abl in "$@"; do
   touch cgat_amd/csrc/wgradc.hip
-  CGAT_HIPCC_FLAGS="-DWGC_STAMPS -DWGC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "build failed for $abl"; continue; }
+  CGAT_HIPCC_FLAGS="-DCGAT_DEV_ABLATIONS -DWGC_STAMPS -DWGC_ABL=$abl" bash cgat_amd/build_lib.sh > /dev/null 2>&1 || { echo "build failed for $abl"; continue; }
   echo "== WGC_ABL=$abl"
   python tools/wgrad_stamps.py 2>&1 | sed -n 11,19p
 done
