@@ -739,7 +739,7 @@ def main():
                     help="layer / stack workloads: also capture the step into one hipGraph and time its replay (reported "
                          "as launch_bound.hipgraph; `value` stays the eager step); on by default below 512 crystals")
     ap.add_argument("--nbrs", type=int, default=None, help="neighbours per atom (default 12; --workload stress: 64)")
-    ap.add_argument("--edge-storage", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--edge-storage", choices=["f32", "bf16", "bf16-mma"], default="f32",
                     help="storage of the per-edge intermediates Z / gZ (bf16 = the 'bf16 activations' of configs[4]; "
                          "tolerance 1e-2 instead of 1e-4: never the default, reported in the line)")
     ap.add_argument("--mode", choices=["f16x3c", "bf16x6", "f16x3", "f32"], default=None,
@@ -876,7 +876,7 @@ def main():
         same_cfg = ["--graphs", str(args.graphs), "--edge-storage", args.edge_storage] + \
                    (["--nbrs", str(args.nbrs)] if args.nbrs else []) + ["--workload", args.workload]
         for m in ("f16x3c", "bf16x6", "f16x3", "f32"):
-            if m == mode or (m == "f32" and args.edge_storage == "bf16"):      # (the f32 mode has no bf16 storage)
+            if m == mode or (m == "f32" and args.edge_storage != "f32"):      # (the f32 mode has no bf16 storage)
                 continue
             k, w = (args.steps, args.warmup) if m != "f32" else (max(3, args.steps // 4), 2)
             cmd = [sys.executable, os.path.abspath(__file__), "--mode", m, "--steps", str(k), "--warmup", str(w)] + same_cfg + \
@@ -1007,7 +1007,7 @@ def main():
                 roof["stale_counters"] = "; ".join(x for x in (stale, cnt_stale) if x)
         # HBM side (the north_star's "fraction of the HBM roofline"): the four per-edge kernels are bound by the
         # Z-sized passes.  Algorithmic bytes per launch with W2 = 2*H*Hd = 1536 fp32 columns per edge:
-        W2b = 2 * HEADS * 256 * (2 if args.edge_storage == "bf16" else 4)
+        W2b = 2 * HEADS * 256 * (2 if args.edge_storage in ("bf16", "bf16-mma") else 4)
         # f16x3: the per-edge forward kernel computes the x_j projection itself (edge_zx_kernel): Z written, e and
         # x[src] rows read, Pi rows once; other modes: Z written, Pj gathered (W2b per edge), e read, Pi rows once
         W2f = 2 * HEADS * 256 * 4                          # per-node rows (Pi, Gi, gS) are fp32 in either storage mode
@@ -1042,7 +1042,7 @@ def main():
                     # kernel (profiles/pmc_stress_kernels.json, keyed by edge storage) against that launch's mean duration
                     st_all, st_src, st_stale = _counters_of_this_build(
                         os.path.join(ROOT, "profiles", "pmc_stress_kernels.json"), mode,
-                        key="stress" if args.edge_storage == "f32" else "stress_bf16")
+                        key={"f32": "stress", "bf16": "stress_bf16", "bf16-mma": "stress_bf16mma"}[args.edge_storage])
                     sb = st_all.get("hbm_bytes_largest_launch", {})
                     if all(k in sb for k in kn):
                         cbytes, csrc, per_launch = sum(sb[k] for k in kn), st_src, True
@@ -1120,7 +1120,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "plan_build_ms": plan_build_ms,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype + ("; Z / gZ of the edge phase stored as bf16 (tolerance 1e-2)"
-                                                   if args.edge_storage == "bf16" else ""),
+                                                   if args.edge_storage == "bf16" else
+                                                   "; Z of the edge phase stored as bf16 and the two per-edge backward products "
+                                                   "on bf16 operands (one matrix pass, fp32 accumulate; tolerance 1e-2)"
+                                                   if args.edge_storage == "bf16-mma" else ""),
             "data": "synthetic", "bilinear_mode": mode, "edge_storage": args.edge_storage,
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
                                     f"{K_used} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention" +

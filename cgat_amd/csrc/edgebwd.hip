@@ -34,7 +34,11 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   if (bias) bias += (long)blockIdx.y * hb.bias;
   // PASSES == 2: two fp16 planes, three passes (mfma_bf16.h).  The rows of gZ are consumed k-step by k-step, so their
   // scale is per tensor: amax[0] = max |gZ| from the kernel that produced it; the weight's max sits behind its planes.
+  // PASSES == 1 (edge storage "bf16-mma", BASELINE configs[4]'s "bf16 activations with MFMA edge-MLP"): ONE bf16 pass on
+  // the leading planes of both operands -- bf16 operands, fp32 accumulation; the three-plane weight image is read as
+  // it is (its first plane is the round-to-nearest bf16 of the weight), only that plane is staged
   constexpr bool F16 = PASSES == 2;
+  constexpr bool ONE = PASSES == 1;
   constexpr int NP = F16 ? 2 : 3;
   constexpr int HP = NP * 256;                   // 16-byte pieces of one (a, half, k-step) block
   __shared__ uint4 Bs[2][2 * HP];                // [buffer][half][plane][cb][lane]
@@ -75,19 +79,28 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   // in front of the barrier)
   uint4 sb0, sb1, sb2, tb0, tb1, tb2;
   const int p1 = tid + 512, p2 = tid + 1024;
+  const int p0 = tid < 256 ? tid : HP + tid - 256;      // ONE: where the thread's plane-0 piece lives in the tile
 #define GE_BLOAD(ks_, B0_, B1_, B2_)                                                                     \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
     const uint4* h0 = Wq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
     const uint4* h1 = Wq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
-    B0_ = h0[tid];                                                                                       \
-    B1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
-    if (NP == 3) B2_ = h1[p2 - HP];                                                                      \
+    if (ONE) {                       /* plane 0 of each half: 256 + 256 pieces, one per thread */          \
+      B0_ = tid < 256 ? h0[tid] : h1[tid - 256];                                                         \
+    } else {                                                                                             \
+      B0_ = h0[tid];                                                                                     \
+      B1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                              \
+      if (NP == 3) B2_ = h1[p2 - HP];                                                                    \
+    }                                                                                                    \
   }
 #define GE_BSTORE(buf_)                                                                                  \
   {                                                                                                      \
-    Bs[buf_][tid] = sb0; Bs[buf_][p1] = sb1;                                                             \
-    if (NP == 3) Bs[buf_][p2] = sb2;                                                                     \
+    if (ONE) {                                                                                           \
+      Bs[buf_][p0] = sb0;                                                                                \
+    } else {                                                                                             \
+      Bs[buf_][tid] = sb0; Bs[buf_][p1] = sb1;                                                           \
+      if (NP == 3) Bs[buf_][p2] = sb2;                                                                   \
+    }                                                                                                    \
   }
   // raw gZ (rows a/b, 8 columns each) of the next k-step (ra*, rb*) and of the one after (sa*, sb*): loads are
   // issued two k-steps (~3 us) before their values are split, enough bytes in flight per CU to cover HBM latency
@@ -152,8 +165,10 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
       P_ = mma16<F16>(F1_, Q3_, P_);                                                                     \
       P_ = mma16<F16>(F2_, Q2_, P_);                                                                     \
     }                                                                                                    \
-    P_ = mma16<F16>(F2_, Q1_, P_);                                                                       \
-    P_ = mma16<F16>(F1_, Q2_, P_);                                                                       \
+    if (!ONE) {                                                                                          \
+      P_ = mma16<F16>(F2_, Q1_, P_);                                                                     \
+      P_ = mma16<F16>(F1_, Q2_, P_);                                                                     \
+    }                                                                                                    \
     P_ = mma16<F16>(F1_, Q1_, P_);                                                                       \
   }
   // One iteration: loads for k-step ks + 2 go into the (S, T) register sets, the (R, SB) sets -- loaded one iteration
@@ -175,13 +190,15 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
     GE_ALOAD(kl_, SA0, SA1, SB0, SB1, SCA, SCB, SMA, SMB);                                               \
     __builtin_amdgcn_sched_barrier(0);     /* the loads are ISSUED here, not where the scheduler likes them */ \
     /* the raw values in the R set belong to k-step ks + 1: split them while this step's MFMAs run */      \
-    bf16x8 f1 = bs[0], f2 = bs[256], f3;                                                                 \
+    bf16x8 f1 = bs[0], f2, f3;                                                                           \
+    if (!ONE) f2 = bs[256];                                                                              \
     if (PASSES >= 6) f3 = bs[512];                                                                       \
     _Pragma("unroll") for (int g = 0; g < 8; ++g) {      /* 16-column output block g = (half, cb) */        \
       bf16x8 n1, n2, n3;                                                                                 \
       if (g < 7) {                                                                                       \
         const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;                                          \
-        n1 = bs[o]; n2 = bs[o + 256];                                                                    \
+        n1 = bs[o];                                                                                      \
+        if (!ONE) n2 = bs[o + 256];                                                                      \
         if (PASSES >= 6) n3 = bs[o + 512];                                                               \
       }                                                                                                  \
       GE_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);                                               \
@@ -190,7 +207,8 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
       if (g == 4) GE_SPLIT(RB0, RB1, RCB, RMB, nb1, nb2, nb3);                                           \
       if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }                                                          \
     }                                                                                                    \
-    Bs[(buf_) ^ 1][tid] = UB0; Bs[(buf_) ^ 1][p1] = UB1; if (NP == 3) Bs[(buf_) ^ 1][p2] = UB2;         \
+    if (ONE) { Bs[(buf_) ^ 1][p0] = UB0; }                                                               \
+    else { Bs[(buf_) ^ 1][tid] = UB0; Bs[(buf_) ^ 1][p1] = UB1; if (NP == 3) Bs[(buf_) ^ 1][p2] = UB2; } \
     /* LDS writes of this wave done, then the barrier -- NOT __syncthreads(): its fence also drains vmcnt, i.e. the */ \
     /* operand loads just issued two k-steps ahead */                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
@@ -278,7 +296,9 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
                                                          const EdgeRC rc, int xcd_order) {
   // PASSES == 2: two fp16 planes, three passes; both operands are indexed by the reduction index (the edge slot), so
   // both scales are per tensor: gmax[0] = max |gZ| (from its producer), emax[0] = max |e| (the planes carry 2^k e)
+  // PASSES == 1 (edge storage "bf16-mma"): one bf16 pass on the leading planes of both operands (see edge_ge_kernel)
   constexpr bool F16 = PASSES == 2;
+  constexpr bool ONE = PASSES == 1;
   constexpr int NP = F16 ? 2 : 3;
   constexpr int HP = NP * 256;
   constexpr int FLUSH = 64;
@@ -341,14 +361,19 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   // (se*: the tile stored at the end of this iteration, loaded during the previous one; te*: the one after it)
   uint4 se0, se1, se2, te0, te1, te2;
   const int p1 = tid + 512, p2 = tid + 1024;
+  const int p0 = tid < 256 ? tid : HP + tid - 256;      // ONE: where the thread's plane-0 piece lives in the tile
 #define GW_ELOAD(ks_, E0_, E1_, E2_)                                                                     \
   {                                                                                                      \
     const long a_ = (ks_) >> 2, s_ = (ks_) & 3;                                                          \
     const uint4* h0 = Eq + ((a_ * 2 + 0) * 4 + s_) * HP;                                                 \
     const uint4* h1 = Eq + ((a_ * 2 + 1) * 4 + s_) * HP;                                                 \
-    E0_ = h0[tid];                                                                                       \
-    E1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                                \
-    if (NP == 3) E2_ = h1[p2 - HP];                                                                      \
+    if (ONE) {                       /* plane 0 of each half: one piece per thread */                      \
+      E0_ = tid < 256 ? h0[tid] : h1[tid - 256];                                                         \
+    } else {                                                                                             \
+      E0_ = h0[tid];                                                                                     \
+      E1_ = p1 < HP ? h0[p1] : h1[p1 - HP];                                                              \
+      if (NP == 3) E2_ = h1[p2 - HP];                                                                    \
+    }                                                                                                    \
   }
   // raw gZ tile pieces: float4 number gt + 256 i of the k-step's contiguous [32][128] tile, i < 4
   float4 r0, r1, r2, r3, s0, s1, s2, s3;
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
       split3_pair(g_.z * sg_, g_.w * sg_, x1.y, x2.y, x3.y);                                             \
     }                                                                                                    \
     *reinterpret_cast<uint2*>(&Gs[buf_][grp][0][off]) = x1;                                              \
-    *reinterpret_cast<uint2*>(&Gs[buf_][grp][1][off]) = x2;                                              \
+    if (!ONE) *reinterpret_cast<uint2*>(&Gs[buf_][grp][1][off]) = x2;                                    \
     if (PASSES >= 6) *reinterpret_cast<uint2*>(&Gs[buf_][grp][NP - 1][off]) = x3;                        \
   }
   // transposed fragment of plane pl_, column block nb_ of this wave: k = 8 kg + j  <->  slot 8 kg + j
@@ -462,8 +487,10 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
       P_ = mma16<F16>(F1_, Q3_, P_);                                                                     \
       P_ = mma16<F16>(F2_, Q2_, P_);                                                                     \
     }                                                                                                    \
-    P_ = mma16<F16>(F2_, Q1_, P_);                                                                       \
-    P_ = mma16<F16>(F1_, Q2_, P_);                                                                       \
+    if (!ONE) {                                                                                          \
+      P_ = mma16<F16>(F2_, Q1_, P_);                                                                     \
+      P_ = mma16<F16>(F1_, Q2_, P_);                                                                     \
+    }                                                                                                    \
     P_ = mma16<F16>(F1_, Q1_, P_);                                                                       \
   }
   // the workgroup's slab tile: rows = its 256 columns of gZ, 128 outputs each
@@ -487,8 +514,11 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
   }
   GW_DLOAD(ks0);
   GW_LOADS(ks0, se0, se1, se2, r0, r1, r2, r3, rk0, rk1, rk2, rk3, rm0, rm1, rm2, rm3);
-  Es[0][tid] = se0; Es[0][p1] = se1;
-  if (NP == 3) Es[0][p2] = se2;
+  if (ONE) { Es[0][p0] = se0; }
+  else {
+    Es[0][tid] = se0; Es[0][p1] = se1;
+    if (NP == 3) Es[0][p2] = se2;
+  }
   GW_S1(0, r0, rk0, rm0, 0, 1.f) GW_S1(1, r1, rk1, rm1, 0, 1.f) GW_S1(2, r2, rk2, rm2, 0, 1.f) GW_S1(3, r3, rk3, rm3, 0, 1.f)
   r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
   rk0 = rk1 = rk2 = rk3 = 0.f;
@@ -510,16 +540,19 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
     GW_LOADS(kl_, TE0, TE1, TE2, S0, S1, S2, S3, SK0, SK1, SK2, SK3, SM0, SM1, SM2, SM3);                \
     const bf16x8* es = reinterpret_cast<const bf16x8*>(&Es[buf_][lane]);                                 \
     /* this wave's two transposed gZ fragments (32 columns x 32 slots), three planes each */               \
-    bf16x8 qa1 = GW_TRREAD(buf_, 0, tr00, tr01), qa2 = GW_TRREAD(buf_, 1, tr00, tr01), qa3;              \
-    bf16x8 qb1 = GW_TRREAD(buf_, 0, tr10, tr11), qb2 = GW_TRREAD(buf_, 1, tr10, tr11), qb3;              \
+    bf16x8 qa1 = GW_TRREAD(buf_, 0, tr00, tr01), qa2, qa3;                                               \
+    bf16x8 qb1 = GW_TRREAD(buf_, 0, tr10, tr11), qb2, qb3;                                               \
+    if (!ONE) { qa2 = GW_TRREAD(buf_, 1, tr00, tr01); qb2 = GW_TRREAD(buf_, 1, tr10, tr11); }            \
     if (PASSES >= 6) { qa3 = GW_TRREAD(buf_, 2, tr00, tr01); qb3 = GW_TRREAD(buf_, 2, tr10, tr11); }     \
-    bf16x8 f1 = es[0], f2 = es[256], f3;                                                                 \
+    bf16x8 f1 = es[0], f2, f3;                                                                           \
+    if (!ONE) f2 = es[256];                                                                              \
     if (PASSES >= 6) f3 = es[512];                                                                       \
     _Pragma("unroll") for (int g = 0; g < 8; ++g) {      /* 16 outputs k = 16 g ...: e fragment g = (half, cb) */ \
       bf16x8 n1, n2, n3;                                                                                 \
       if (g < 7) {                                                                                       \
         const int o = ((g + 1) >> 2) * HP + ((g + 1) & 3) * 64;                                          \
-        n1 = es[o]; n2 = es[o + 256];                                                                    \
+        n1 = es[o];                                                                                      \
+        if (!ONE) n2 = es[o + 256];                                                                      \
         if (PASSES >= 6) n3 = es[o + 512];                                                               \
       }                                                                                                  \
       GW_MFMA1(f1, f2, f3, qa1, qa2, qa3, acc[2 * g + 0]);                                               \
@@ -530,7 +563,8 @@ __global__ __launch_bounds__(512, 2) void edge_gw_kernel(const float* __restrict
       GW_MFMA1(f1, f2, f3, qb1, qb2, qb3, acc[2 * g + 1]);                                               \
       if (g < 7) { f1 = n1; f2 = n2; f3 = n3; }                                                          \
     }                                                                                                    \
-    Es[(buf_) ^ 1][tid] = UE0; Es[(buf_) ^ 1][p1] = UE1; if (NP == 3) Es[(buf_) ^ 1][p2] = UE2;         \
+    if (ONE) { Es[(buf_) ^ 1][p0] = UE0; }                                                               \
+    else { Es[(buf_) ^ 1][tid] = UE0; Es[(buf_) ^ 1][p1] = UE1; if (NP == 3) Es[(buf_) ^ 1][p2] = UE2; } \
     if ((rel + 1) % FLUSH == 0 || (ks_) + 1 == ks1) {                                                    \
       const float sg = ((rel / FLUSH) & 1) ? -1.f : 1.f;                                                 \
       GW_FLUSH(first, sg);                                                                               \
@@ -596,7 +630,10 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
 #define GE_GO(P_, R_)                                                                                                 \
   hipLaunchKernelGGL((edge_ge_kernel<P_, R_>), dim3(grid), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq, ncb, \
                      out, ldo, scatter, E, accumulate, bias, amax, R_ ? *rc : none, HeadBatch{})
-  if (rc) { if (f16) GE_GO(2, true); else if (bilinear_mode() != 3) GE_GO(6, true); else GE_GO(3, true); }
+  // (the per-EDGE launch only -- rc: the rebuilt gZ rows -- and never in the fp16 mode, which has its own bf16 storage form)
+  const bool one = rc && !f16 && edge_mma_bf16() && bilinear_mode() != 3;
+  if (one) GE_GO(1, true);
+  else if (rc) { if (f16) GE_GO(2, true); else if (bilinear_mode() != 3) GE_GO(6, true); else GE_GO(3, true); }
   else { if (f16) GE_GO(2, false); else if (bilinear_mode() != 3) GE_GO(6, false); else GE_GO(3, false); }
 #undef GE_GO
   CGAT_LAUNCH_CHECK();
@@ -689,7 +726,9 @@ int edge_gw_launch(const float* gZ, long ldg, long gzb, const float* e, long lde
 #define GW_GO(P_, R_)                                                                                                  \
   hipLaunchKernelGGL((edge_gw_kernel<P_, R_>), dim3(S * (ncb / 2)), dim3(512), 0, stream, gZ, ldg, gzb,                \
                      (const uint4*)planes, slab, E, ncb, nsteps, S, gmax, emax, R_ ? *rc : none, gw_xcd_order())
-    if (rc) { if (f16) GW_GO(2, true); else if (bilinear_mode() != 3) GW_GO(6, true); else GW_GO(3, true); }
+    const bool one = rc && !f16 && edge_mma_bf16() && bilinear_mode() != 3;
+    if (one) GW_GO(1, true);
+    else if (rc) { if (f16) GW_GO(2, true); else if (bilinear_mode() != 3) GW_GO(6, true); else GW_GO(3, true); }
     else { if (f16) GW_GO(2, false); else if (bilinear_mode() != 3) GW_GO(6, false); else GW_GO(3, false); }
 #undef GW_GO
     CGAT_LAUNCH_CHECK();

@@ -232,6 +232,8 @@ struct EdgeRC {
   const int* dst;         // [E] destination node of slot t
   int H, Hd, HHd, nw;     // nw = W2 / 32
 };
+// edge storage mode 3 ("bf16-mma", layers.hip): the per-edge products over the rebuilt gZ rows run ONE bf16 pass
+bool edge_mma_bf16();
 // shapes the rebuilding kernels take: whole 128-column blocks inside one head, 256-column groups in the mask writer
 static inline bool edge_rc_shape(int Ce, int H, int Hd) { return Ce == 128 && H > 0 && Hd > 0 && Hd % 128 == 0; }
 // operand element (t, 128 a + j) at gZ[t * ldg + a * gzb + j]: (128, E*128) = column-blocked, (W2, 128) = row-major;

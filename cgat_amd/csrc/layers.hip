@@ -671,18 +671,21 @@ static int g_edge_storage = -1;
 static int edge_storage() {
   if (g_edge_storage < 0) {
     const char* e = getenv("CGAT_EDGE_STORAGE");
-    g_edge_storage = (e && !strcmp(e, "bf16")) ? 1 : (e && !strcmp(e, "f32+gz")) ? 2 : 0;
+    g_edge_storage = (e && !strcmp(e, "bf16")) ? 1 : (e && !strcmp(e, "f32+gz")) ? 2 : (e && !strcmp(e, "bf16-mma")) ? 3 : 0;
   }
   return g_edge_storage;
 }
-extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = (mode == 1 || mode == 2) ? mode : 0; }
+extern "C" void cgat_set_edge_storage(int32_t mode) { g_edge_storage = (mode >= 1 && mode <= 3) ? mode : 0; }
+// mode 3 ("bf16-mma"): bf16 storage of Z AND one-pass bf16 operands in the two per-edge backward products (edgebwd.hip)
+static bool edge_bf16_storage() { return edge_storage() == 1 || edge_storage() == 3; }
+bool edge_mma_bf16() { return edge_storage() == 3; }
 extern "C" int32_t cgat_get_edge_storage(void) { return edge_storage(); }
 // (f16x3: the K = 256 per-edge forward and the one-kernel segment backward; the 24-bit modes: the six-pass per-edge forward,
 // the weighted sum and the three-kernel segment backward, which exist at Hd == 256 only; the f32 mode has no bf16 storage.
 // A layer this predicate rejects makes cgat_nodes_attention_forward return CGAT_ERR_UNSUPPORTED under edge storage "bf16"
 // -- the forward refuses what the backward could not handle (Hd = 128 / 384 ran forward and failed in backward).)
 static bool attn_bf16(const AttnDims& d) {
-  if (!(edge_storage() == 1 && bilinear_mode() != 0 && bilinear_mode() != 3 && d.C == 128 && d.Ce == 128 &&
+  if (!(edge_bf16_storage() && bilinear_mode() != 0 && bilinear_mode() != 3 && d.C == 128 && d.Ce == 128 &&
         d.Hd % 128 == 0 && d.W2 % 256 == 0 && d.N > 0 && d.E > 0))
     return false;
   if (bilinear_mode() != 2 && !(d.Hd == 256 && d.Hd % 4 == 0)) return false;   // seg_bwd_msg / _att<true>: two 128-column blocks per head
@@ -749,7 +752,7 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   const bool fused_z = !c.dry && edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Pi, Pj, sv.Z, p->A_out_w);
   // Z stored as bf16 (edge-storage mode "bf16"): by edge_zx in the f16x3 mode, by the six-pass per-edge kernel otherwise
   const bool zb = attn_bf16(d) && (zx || (fused_z && bilinear_mode() != 2));
-  if (!c.dry && edge_storage() == 1 && !zb && d.N > 0 && d.E > 0) {
+  if (!c.dry && edge_bf16_storage() && !zb && d.N > 0 && d.E > 0) {
     cgat_set_error("nodes_attention_forward: edge storage \"bf16\" is set but this layer (C %d, Ce %d, H %d, Hd %d, arithmetic "
                    "mode %d) has no bf16 form -- refusing to run it in fp32 storage under that label", d.C, d.Ce, d.H, d.Hd,
                    bilinear_mode());
@@ -1016,7 +1019,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     const bool zb_6 = attn_bf16(d) && bilinear_mode() != 2 &&
                       edge_z_fast(d.Ce, d.W2, d.H, d.Hd, d.Ce, d.W2, d.W2, e, Gi, Gj, sv.Z, p->A_out_w);
     zb = zb_x || zb_6;
-    if (edge_storage() == 1 && !zb) {
+    if (edge_bf16_storage() && !zb) {
       cgat_set_error("nodes_attention_backward: edge storage \"bf16\" is set but this layer has no bf16 form");
       return CGAT_ERR_UNSUPPORTED;
     }

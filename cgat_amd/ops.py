@@ -1082,12 +1082,18 @@ def set_edge_storage(mode):
     (BASELINE configs[4]'s "bf16 activations": half the HBM bytes of the edge phase, tolerance 1e-2; logits, softmax
     statistics and all products unchanged).  Exists at C = Ce = 128 in every split arithmetic mode (f16x3c, bf16x6, f16x3);
     a scalar-attention layer without a bf16 form (other widths, the f32 mode) raises instead of silently running in fp32
-    storage."""
-    lib.cgat_set_edge_storage({"f32": 0, "bf16": 1, "f32+gz": 2}[mode])
+    storage.  "bf16-mma" (round 6, the 24-bit modes): bf16 storage AND bf16 OPERANDS in the two per-edge
+    BACKWARD products (grad edge_attr, grad W_e: ONE matrix pass on round-to-nearest bf16 images of the rebuilt gZ rows
+    and of the weight / edge rows, fp32 accumulation) -- BASELINE configs[4]'s "bf16 activations with MFMA edge-MLP",
+    tolerance 1e-2.  The forward product keeps its six passes: on bf16 operands the pre-activations move by ~3e-3 of
+    their scale, 0.3 % of the LeakyReLU derivatives land on the other side, and the gradients of edge_attr and of the
+    attention network's first layer came out 1.6 % ... 5.7 % off (tools/bf16mma_probe.py; measured 775 ms instead of 830
+    per 64 M-edge step) -- outside the mode's stated tolerance."""
+    lib.cgat_set_edge_storage({"f32": 0, "bf16": 1, "f32+gz": 2, "bf16-mma": 3}[mode])
 
 
 def get_edge_storage():
-    return {0: "f32", 1: "bf16", 2: "f32+gz"}[lib.cgat_get_edge_storage()]
+    return {0: "f32", 1: "bf16", 2: "f32+gz", 3: "bf16-mma"}[lib.cgat_get_edge_storage()]
 
 
 class _storage_of:

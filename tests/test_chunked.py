@@ -222,6 +222,23 @@ def test_config5_bf16_edge_storage_vs_oracle():
     assert worst <= 1e-2, worst
     assert rel(y16, y32.double().cpu()) > 1e-6          # the mode is on, in EVERY split arithmetic mode (round 5)
     assert rel(y32, yo.detach()) <= 1e-4
+    # "bf16-mma" (round 6, the 24-bit modes): bf16 OPERANDS in the two per-edge backward products as well (one matrix pass,
+    # fp32 accumulation) -- the same stated tolerance, the same forward, gradients that differ from the storage-only
+    # mode's (the mode is on)
+    if P.get_bilinear_mode() in ("f16x3c", "bf16x6"):
+        P.set_edge_storage("bf16-mma")
+        try:
+            ym, gm = run()
+        finally:
+            P.set_edge_storage("f32")
+        assert torch.equal(ym, y16)
+        worst_m, moved = 0.0, 0.0
+        for a, a16, r in zip(gm, g16, go):
+            den = max(float(r.abs().max()), 1e-3 * scale)
+            worst_m = max(worst_m, float((a.double().cpu() - r).abs().max()) / den)
+            moved = max(moved, float((a.double().cpu() - a16.double().cpu()).abs().max()) / den)
+        assert worst_m <= 1e-2, worst_m
+        assert moved > 1e-5, moved
 
 
 @pytest.mark.gpu
@@ -358,3 +375,49 @@ def test_rebuilt_gz_equals_stored_gz(K):
     scale = max(float(t.abs().max()) for t in a[1:])    # (a gradient that is zero by symmetry -- the logit bias under
     for k, (u, v) in enumerate(zip(a, c)):              # the softmax -- is rounding noise of the layer's scale)
         assert float((u - v).abs().max()) <= 1e-5 * max(float(u.abs().max()), 1e-2 * scale), k   # floor: 1e-7 of the scale
+
+
+@pytest.mark.gpu
+def test_config5_full_size_chunked_step():
+    """BASELINE configs[4] at FULL size: 50 000 crystals x 20 atoms x 64 neighbours = 64 000 000 edges through one
+    GATConvNodes layer, forward + backward, in closed chunks (<= 8 M edges each) with the config's bf16 edge storage and
+    bf16 per-edge backward operands ("bf16-mma").  No oracle can run this size; the properties checked: everything finite;
+    the LAST 3 crystals -- the tail of the last chunk -- give the same output rows (1e-3) and, to the mode's stated
+    tolerance (1e-2), the same input gradients as the 3 crystals evaluated alone; the layer really ran in more than one chunk."""
+    import cgat_amd as P
+    from cgat_amd import chunked, ops
+    if P.get_bilinear_mode() not in ("f16x3c", "bf16x6"):
+        pytest.skip("bf16-mma exists in the 24-bit modes")
+    dev = "cuda:0"
+    G, A, K, GS = 50000, 20, 64, 3
+    b, _ = P.synthetic_batch(G, A, K, seed=11)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    assert E == 64000000
+    ei = b.edge_index.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(12)
+    x, e, x0 = (torch.randn(n, 128, generator=gen, device=dev) for n in (N, E, N))
+    torch.manual_seed(1)
+    layer = P.GATConvNodes(128, 128, 128, 3, concat=True).to(dev)
+    n0, e0 = (G - GS) * A, (G - GS) * A * K
+    cot = torch.randn(GS * A, 128, generator=gen, device=dev)
+    validate = ops._validate_indices
+    ops.set_validate_indices(False)              # (two host round trips per chunk plan; the indices are ours)
+    P.set_edge_storage("bf16-mma")
+    try:
+        assert len(chunked.closed_chunks(ei, N, chunked.max_edges_per_pass())) >= 8
+        x.requires_grad_(True); e.requires_grad_(True)
+        y = layer(x, ei, e, x0)
+        gx, ge = torch.autograd.grad((y[n0:] * cot).sum(), [x, e])
+        assert torch.isfinite(y).all() and torch.isfinite(gx).all() and torch.isfinite(ge[e0:]).all()
+        assert float(gx[:n0].abs().max()) == 0.0 and float(ge[:e0].abs().max()) == 0.0     # nothing leaks out of the 3 crystals
+        xs, es = x[n0:].detach().clone().requires_grad_(True), e[e0:].detach().clone().requires_grad_(True)
+        ys = layer(xs, (ei[:, e0:] - n0).contiguous(), es, x0[n0:].contiguous())
+        gxs, ges = torch.autograd.grad((ys * cot).sum(), [xs, es])
+    finally:
+        P.set_edge_storage("f32")
+        ops.set_validate_indices(validate)
+    rel = lambda a, r: float((a - r).abs().max() / r.abs().max())
+    # (bf16 storage: a pre-activation within an fp32 ulp of a bf16 rounding boundary may round the other way in the
+    # other kernels the 60-row batch runs on -- the mode's own tolerance class, not 1e-5)
+    assert rel(y[n0:].detach(), ys.detach()) <= 1e-3
+    assert rel(gx[n0:], gxs) <= 1e-2 and rel(ge[e0:], ges) <= 1e-2

@@ -636,17 +636,24 @@ def test_million_edge_properties():
     assert maxnorm_rel(y_sub.cpu().numpy(), y[:n_sub].cpu().numpy()) <= 1e-5
 
 
-# parameter gradients are sums over all rows of the batch: inside the big batch the same terms are added in a different
-# tree (with exact zeros from the other crystals between them)
-STACK_LOCALITY_TOL = 2e-5
+# Gradients with the other crystals replaced: the same terms in the same summation trees, exact zeros elsewhere; only an
+# operand scale taken over a whole tensor (a power of two from its maximum) can differ between the two batches
+STACK_LOCALITY_TOL = 1e-5
 
 
 def test_million_edge_stack_fwd_bwd_locality():
     """BASELINE configs[2] at FULL size -- CGAtNet(200, 128, 4 layers, 3 heads), forward + backward, E = 1 000 080 --
-    through a property that needs no oracle run: crystals are independent (no edge and no composition pair crosses
-    them), so with a cotangent that is non-zero on the first 50 crystals only, their outputs, the gradient of their
-    inputs and EVERY parameter gradient must equal those of the 50 crystals evaluated alone (1e-5 of each tensor's
-    largest entry: the summation orders differ)."""
+    through properties that need no oracle run.  Crystals are independent (no edge and no composition pair crosses
+    them).  With a cotangent that is non-zero on the first 50 crystals only:
+      (a) REPLACING the other 4 117 crystals (new atoms, shells and compositions, same sizes) changes neither the 50
+          outputs, nor the gradient of their inputs, nor ANY of the 307 parameter gradients -- the same kernels sum the
+          same terms in the same trees, the other crystals contribute exact zeros; what may move is an operand scale
+          taken over a whole tensor (a few 1e-7);
+      (b) nothing leaks: the input gradient of the other crystals is exactly zero;
+      (c) the 50 outputs equal those of the 50 crystals evaluated ALONE (other kernels at that row count: 1e-5).
+    (The gradients of (c) are NOT compared: at 1 000 rows the dense layers run on other kernels, a pre-activation within
+    an ulp of zero lands on the other side in one of the two evaluations, and a LeakyReLU / ReLU derivative that flips
+    moves its row's gradients by 1e-3 .. 1e-2 -- the oracle comparisons force the derivative pattern for that reason.)"""
     import cgat_amd as P
     dev = "cuda:0"
     G, A, K, GS = 4167, 20, 12, 50
@@ -665,35 +672,56 @@ def test_million_edge_stack_fwd_bwd_locality():
         g = torch.autograd.grad((out[:GS] * cot).sum(), [bb.x] + list(params.values()), allow_unused=True)
         return out[:GS].detach(), g[0].detach(), [None if t is None else t.detach() for t in g[1:]]
 
-    y_big, gx_big, gp_big = run(b, roost)
-    # the first GS crystals alone: atoms, edges and composition rows of a crystal are contiguous blocks
+    y_a, gx_a, gp_a = run(b, roost)
+    # atoms, edges and composition rows of a crystal are contiguous blocks
     n_sub, e_sub = GS * A, GS * A * K
     w, fea, sidx, nidx, cidx = roost
     nc_sub = int((cidx < GS).sum())
     mc_sub = int((sidx < nc_sub).sum())
-    sub = P.GraphBatch(b.x[:n_sub].clone(), b.edge_index[:, :e_sub].clone(), b.edge_attr[:e_sub].clone(),
-                       b.batch[:n_sub].clone(), b.y[:GS].clone(), num_graphs=GS)
-    sub_roost = (w[:nc_sub].clone(), fea[:nc_sub].clone(), sidx[:mc_sub].clone(), nidx[:mc_sub].clone(), cidx[:nc_sub].clone())
-    y_sub, gx_sub, gp_sub = run(sub, sub_roost)
-    assert torch.isfinite(y_big).all()
-    assert maxnorm_rel(y_big.cpu().numpy(), y_sub.cpu().numpy()) <= 1e-5
-    assert maxnorm_rel(gx_big[:n_sub].cpu().numpy(), gx_sub.cpu().numpy()) <= 1e-5
-    assert float(gx_big[n_sub:].abs().max()) == 0.0          # nothing leaks into the other 4 117 crystals
-    worst = 0.0
-    case_scale = max(float(c.abs().max()) for c in gp_sub if c is not None)
-    for name, a, c in zip(params, gp_big, gp_sub):
-        assert (a is None) == (c is None), name
-        if a is None:
+    # (a) the same batch with every OTHER crystal replaced
+    b2, roost2 = P.synthetic_batch(G, A, K, seed=77)
+    x_b = torch.cat([b.x[:n_sub], b2.x[n_sub:]])
+    ea_b = torch.cat([b.edge_attr[:e_sub], b2.edge_attr[e_sub:]])
+    ei_b = torch.cat([b.edge_index[:, :e_sub], b2.edge_index[:, e_sub:]], dim=1)
+    bb = P.GraphBatch(x_b, ei_b, ea_b, b.batch.clone(), b.y.clone(), num_graphs=G)
+    w2, fea2 = w.clone(), fea.clone()
+    g2 = torch.Generator().manual_seed(78)
+    fea2[nc_sub:] = fea[nc_sub:][torch.randperm(fea.shape[0] - nc_sub, generator=g2)]     # other elements, same layout
+    y_b, gx_b, gp_b = run(bb, (w2, fea2, sidx, nidx, cidx))
+    assert torch.isfinite(y_a).all()
+    err_y = maxnorm_rel(y_b.cpu().numpy(), y_a.cpu().numpy())
+    err_gx = maxnorm_rel(gx_b[:n_sub].cpu().numpy(), gx_a[:n_sub].cpu().numpy())
+    leak = max(float(gx_a[n_sub:].abs().max()), float(gx_b[n_sub:].abs().max()))
+    worst, worst_name, bad = 0.0, "", []
+    case_scale = max(float(c.abs().max()) for c in gp_a if c is not None)
+    for name, a_, c in zip(params, gp_b, gp_a):
+        assert (a_ is None) == (c is None), name
+        if a_ is None:
             continue
         ref_max = float(c.abs().max())
-        abs_err = float((a - c).abs().max())
+        abs_err = float((a_ - c).abs().max())
         if ref_max <= NUM_ZERO * case_scale:       # zero in exact arithmetic (softmax shift invariance): rounding noise
-            assert abs_err <= ZERO_FLOOR * case_scale, (name, abs_err, ref_max)
+            if abs_err > ZERO_FLOOR * case_scale:
+                bad.append((name, abs_err, ref_max))
             continue
-        worst = max(worst, abs_err / ref_max)
-        assert abs_err <= STACK_LOCALITY_TOL * ref_max, (name, abs_err / ref_max)
-    _report([f"[4-layer stack fwd+bwd locality at E = 1 000 080] mode {_mode()}: 50 crystals inside the batch vs alone, "
-             f"{len(params)} parameter gradients, worst max-norm rel difference {worst:.2e}"])
+        if abs_err / ref_max > worst:
+            worst, worst_name = abs_err / ref_max, name
+        if abs_err > STACK_LOCALITY_TOL * ref_max:
+            bad.append((name, abs_err / ref_max))
+    # (c) the 50 crystals alone: forward
+    sub = P.GraphBatch(b.x[:n_sub].clone(), b.edge_index[:, :e_sub].clone(), b.edge_attr[:e_sub].clone(),
+                       b.batch[:n_sub].clone(), b.y[:GS].clone(), num_graphs=GS)
+    sub_roost = tuple(t.to(dev) for t in (w[:nc_sub].clone(), fea[:nc_sub].clone(), sidx[:mc_sub].clone(),
+                                          nidx[:mc_sub].clone(), cidx[:nc_sub].clone()))
+    with torch.no_grad():
+        y_sub = net(sub.to(dev), sub_roost)
+    err_alone = maxnorm_rel(y_sub.cpu().numpy(), y_a.cpu().numpy())
+    _report([f"[4-layer stack fwd+bwd locality at E = 1 000 080] mode {_mode()}: 50 crystals, the other 4 117 replaced: "
+             f"out {err_y:.2e}, grad x {err_gx:.2e} (largest entry outside the 50 crystals {leak:.1e}), {len(params)} "
+             f"parameter gradients, worst max-norm rel difference {worst:.2e} ({worst_name}); the 50 crystals alone: "
+             f"out {err_alone:.2e}"])
+    assert err_y <= 1e-6 and err_gx <= STACK_LOCALITY_TOL and leak == 0.0 and err_alone <= 1e-5, (err_y, err_gx, leak, err_alone)
+    assert not bad, bad
 
 
 @pytest.mark.gpu
