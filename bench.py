@@ -913,7 +913,10 @@ def main():
         # forward pass, once as the backward's per-chunk recomputation).  Flop per LAUNCH = flop per step / launches per
         # step, whatever the rows of a launch are (a chunk's share, one layer or the four batched ones): round 4 multiplied
         # a per-chunk launch by the whole batch's rows and printed a fraction of 4.3
-        contractions_per_step = {"bilinear_wgrad": 4, "bilinear_dual": 4, "bilinear_rows": 8 if stress else 4}
+        # (closed chunks since round 6: only the aggregate half is recomputed in backward -- cgat_amd/chunked.py
+        # ChunkedSplitLayerFn -- so the forward contraction runs once per step there too; CGAT_CHUNK_SPLIT=0: twice)
+        contractions_per_step = {"bilinear_wgrad": 4, "bilinear_dual": 4,
+                                 "bilinear_rows": 8 if (stress and os.environ.get("CGAT_CHUNK_SPLIT", "1") == "0") else 4}
         kpasses = {}                                       # matrix-core pass-equivalents per product, per kernel
         if mode == "f32":
             kernels = {"bilinear_wgrad": "bilinear_wgrad128_kernel", "bilinear_rows": "bilinear_rows128_kernel"}
@@ -1128,7 +1131,8 @@ def main():
             "config": {"workload": (f"one GATConvNodes layer (H_Net update) fwd+bwd, {args.graphs} crystals x {ATOMS} atoms x "
                                     f"{K_used} nbrs per rank: N={N}, E={E}, C=Ce={C_FEA}, H={HEADS}, scalar attention" +
                                     (f", closed chunks of <= {P.chunked.max_edges_per_pass()} edges with per-chunk "
-                                     "recomputation in backward (2 forward + 1 backward passes per step)" if stress else ""))
+                                     "recomputation of the per-edge attention in backward (2 attention forward + 1 hypernetwork forward + 1 "
+                                     "backward pass per step)" if stress else ""))
                        if layer_like else
                        (f"CGAtNet(200,128,4,msg_heads=3,update_edges=True) fwd+bwd of L1 loss, {args.graphs} crystals: "
                         f"N={N}, E={E}"),

@@ -130,3 +130,83 @@ class ChunkedLayerFn(torch.autograd.Function):
                     g_p[k] = g if g_p[k] is None else g_p[k].add_(g)
             del grads, yc
         return (None, None, g_x, g_e, g_x0, *g_p)
+
+
+class ChunkedSplitLayerFn(torch.autograd.Function):
+    """The same, for a layer whose single pass is aggregate (per-edge attention: 6 KB of saved pre-activations per edge)
+    followed by update (the hypernetwork: a few [rows, C] tensors per predicted layer).  Only the AGGREGATE half is
+    recomputed in backward; the update half runs once, in forward, with its (small) autograd state kept per chunk --
+    ~1.5 GB per 8 M-edge chunk at K = 64 -- so a step costs 2 aggregate passes + 1 update pass instead of 2 + 2 (the
+    hypernetwork's contractions were 200 ms of the 830 ms 64 M-edge step, a quarter of them the recomputation).
+    `agg(x, ei, e)` -> aggr [n, C]; `upd(aggr, x_0, x)` -> y [n, C]."""
+
+    @staticmethod
+    def forward(ctx, agg, upd, chunks, x, edge_attr, x_0, *params):
+        ctx.agg, ctx.chunks = agg, chunks
+        ctx.save_for_backward(x, edge_attr, x_0, *params)
+        ctx.upd_state = []
+        y = None
+        keep = any(ctx.needs_input_grad)              # inference: nothing to keep, the update runs without a graph too
+        for c in chunks:
+            with torch.no_grad():
+                aggr = agg(x[c.n0:c.n1], c.edge_index, edge_attr[c.e0:c.e1])
+                if not keep:
+                    yc = upd(aggr, x_0[c.n0:c.n1], x[c.n0:c.n1])
+                    if y is None:
+                        y = torch.empty(x.shape[0], yc.shape[1], dtype=yc.dtype, device=yc.device)
+                    y[c.n0:c.n1] = yc
+                    continue
+            with torch.enable_grad():
+                a = aggr.detach().requires_grad_(True)
+                xs = x[c.n0:c.n1].detach().requires_grad_(True)
+                x0s = x_0[c.n0:c.n1].detach().requires_grad_(True)
+                yc = upd(a, x0s, xs)
+            ctx.upd_state.append((a, xs, x0s, yc))
+            if y is None:
+                y = torch.empty(x.shape[0], yc.shape[1], dtype=yc.dtype, device=yc.device)
+            y[c.n0:c.n1] = yc.detach()
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, edge_attr, x_0, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g_x = torch.zeros_like(x) if need[3] else None
+        g_e = torch.empty_like(edge_attr) if need[4] else None
+        g_x0 = torch.zeros_like(x_0) if need[5] else None
+        g_p = [None] * len(params)
+
+        def add_params(grads):
+            for k, g in enumerate(grads):
+                if g is not None:
+                    g_p[k] = g if g_p[k] is None else g_p[k].add_(g)
+        for ci, c in enumerate(ctx.chunks):
+            a, xs_u, x0s_u, yc = ctx.upd_state[ci]
+            ctx.upd_state[ci] = None                                     # the chunk's update state is released here
+            gu = torch.autograd.grad(yc, [a, xs_u, x0s_u] + list(params), g_y[c.n0:c.n1], allow_unused=True)
+            g_aggr = gu[0]
+            add_params(gu[3:])
+            if g_x is not None and gu[1] is not None:
+                g_x[c.n0:c.n1] = gu[1]
+            if g_x0 is not None and gu[2] is not None:
+                g_x0[c.n0:c.n1] = gu[2]
+            del a, xs_u, x0s_u, yc
+            if g_aggr is None:                                            # (an update that ignores its aggregate)
+                if g_e is not None:
+                    g_e[c.e0:c.e1].zero_()
+                continue
+            with torch.enable_grad():
+                xs = x[c.n0:c.n1].detach().requires_grad_(True)
+                es = edge_attr[c.e0:c.e1].detach().requires_grad_(True)
+                aggr = ctx.agg(xs, c.edge_index, es)
+                ga = torch.autograd.grad(aggr, [xs, es] + list(params), g_aggr, allow_unused=True)
+            if g_x is not None and ga[0] is not None:
+                g_x[c.n0:c.n1] += ga[0]
+            if g_e is not None:
+                if ga[1] is not None:
+                    g_e[c.e0:c.e1] = ga[1]
+                else:
+                    g_e[c.e0:c.e1].zero_()
+            add_params(ga[2:])
+            del ga, gu, aggr
+        return (None, None, None, g_x, g_e, g_x0, *g_p)

@@ -305,6 +305,15 @@ class GATConvNodes(nn.Module):
             # beyond the per-pass budget (BASELINE configs[4]: 64 M edges): closed chunks of the graph, one at a time
             chunks = chunked.closed_chunks(edge_index, x.shape[0], chunked.max_edges_per_pass())
             if len(chunks) > 1:
+                drop = bool(self.dropout and self.training)
+                if (not self.vector_attention and not drop and not ops_overlap_enabled() and
+                        type(self).message is GATConvNodes.message and type(self).update is GATConvNodes.update and
+                        os.environ.get("CGAT_CHUNK_SPLIT", "1") != "0"):
+                    # aggregate (6 KB of saved state per edge) is recomputed per chunk in backward, update (the
+                    # hypernetwork: small state) is not: 2 + 1 passes instead of 2 + 2
+                    agg = lambda xs, ei, es: self._aggregate_fused(xs, es, get_plan(ei, xs.shape[0]))
+                    upd = lambda aggr, x0s, xs: self.update(aggr, x_0=x0s, x=xs, _mean_done=True)
+                    return chunked.ChunkedSplitLayerFn.apply(agg, upd, chunks, x, edge_attr, x_0, *self.parameters())
                 run = lambda xs, ei, es, x0s: self._propagate_one(ei, xs, es, x0s)
                 return chunked.ChunkedLayerFn.apply(run, chunks, x, edge_attr, x_0, *self.parameters())
         return self._propagate_one(edge_index, x, edge_attr, x_0)
