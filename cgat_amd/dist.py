@@ -118,9 +118,16 @@ class GradientAverager:
         self._sync = True
         self._handles = []
         self._reset()
+        self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
         if self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            try:                                       # (the CPU tests run this file without the HIP package)
+                from . import ops
+                self._ops = ops
+                ops.register_grad_sink(self._sink)
+            except Exception:
+                self._ops = None
 
     # -- bucket layout --------------------------------------------------------------------
     def _pack(self, idxs):
@@ -168,20 +175,23 @@ class GradientAverager:
         self._works = [None] * len(self.buckets)
         self._next = 0                                 # buckets [0, _next) have been launched
         self._used = [0] * len(self.params)
+        self._claimed = [False] * len(self.params)     # handed out as a gradient destination in this step (_sink)
         self._stale = [True] * len(self.params)        # the view holds last step's mean, not this step's sum
         self._in_finish = False
 
     # -- public ---------------------------------------------------------------------------
     def zero_grad(self):
-        """Zero every gradient and point `p.grad` at its bucket view (the fast path: autograd
-        then accumulates straight into the bucket)."""
-        for f in self.flat:
-            f.zero_()
+        """Drop every gradient.  The next backward leaves each gradient IN its bucket: this package's backward passes ask
+        for the destination of a parameter's gradient (cgat_amd.ops.register_grad_sink) and write it straight into the
+        bucket view, which autograd then installs as `p.grad` without a copy; a gradient that arrives in a tensor of its
+        own (any other module) is copied into its view by the hook -- one pass.  (Until round 6 this zero-filled the
+        buckets and installed the views up front, so that autograd ADDED every gradient into them: a fill, a read of the
+        gradient and a read-modify-write of the bucket per parameter, 0.44 ms per 38-MB layer step at world size 1.)"""
         if self.flat and self.flat[0].is_cuda:
             self._home = torch.cuda.current_stream(self.flat[0].device)    # (hooks may fire under another stream)
         for i, p in enumerate(self.params):
-            p.grad = self._view[id(p)]
-            self._stale[i] = False
+            p.grad = None
+            self._stale[i] = True
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -308,6 +318,24 @@ class GradientAverager:
         for h in self._handles:
             h.remove()
         self._handles = []
+        if getattr(self, "_ops", None) is not None:
+            self._ops.unregister_grad_sink(self._sink)
+
+    def _sink(self, w):
+        """Destination of the gradient of parameter `w` (cgat_amd.ops._param_grad): its bucket view -- a fresh alias, so
+        that autograd can take it over as p.grad without a copy -- while nothing has been accumulated into it in this
+        step (a second use of the parameter, or a later micro-batch under no_sync(), gets a tensor of its own and is
+        ADDED by autograd, as before)."""
+        i = self._by_ptr.get(w.data_ptr())
+        if i is None or self._used[i] or self._claimed[i]:
+            return None
+        p = self.params[i]
+        if p.grad is not None or w.numel() != p.numel() or w.dtype != p.dtype:
+            return None
+        # one claim per step: two backward nodes of one parameter may both run before its hook does (autograd sums their
+        # results in its input buffer first) -- the second must not overwrite the first's
+        self._claimed[i] = True
+        return self._view[id(p)].view(w.shape)
 
     # -- internals ------------------------------------------------------------------------
     def _adopt(self, i, p, arrived):
