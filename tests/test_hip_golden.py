@@ -745,14 +745,26 @@ def test_beyond_int32_element_counts():
 
     def run(xs, eis, es, x0s, sl):
         xs, es = xs.clone().requires_grad_(True), es.clone().requires_grad_(True)
-        y = m(xs, eis, es, x0s)
+        with P.debug.record_masks(m) as masks:           # the LeakyReLU derivative pattern the backward will use
+            y = m(xs, eis, es, x0s)
         gx, ge = torch.autograd.grad((y[sl] * cot).sum(), [xs, es])
-        return y[sl].detach(), gx[sl].detach(), ge
+        return y[sl].detach(), gx[sl].detach(), ge, masks
 
-    y_big, gx_big, ge_big = run(x, ei, e, x0, slice(n0, N))
-    y_sub, gx_sub, ge_sub = run(x[n0:].contiguous(), (ei[:, e0:] - n0).contiguous(), e[e0:].contiguous(),
-                                x0[n0:].contiguous(), slice(0, 50 * A))
+    y_big, gx_big, ge_big, mk_big = run(x, ei, e, x0, slice(n0, N))
+    y_sub, gx_sub, ge_sub, mk_sub = run(x[n0:].contiguous(), (ei[:, e0:] - n0).contiguous(), e[e0:].contiguous(),
+                                        x0[n0:].contiguous(), slice(0, 50 * A))
     assert torch.isfinite(y_big).all()
     assert maxnorm_rel(y_big.cpu().numpy(), y_sub.cpu().numpy()) <= 1e-5
-    assert maxnorm_rel(gx_big.cpu().numpy(), gx_sub.cpu().numpy()) <= 1e-5
-    assert maxnorm_rel(ge_big[e0:].cpu().numpy(), ge_sub.cpu().numpy()) <= 1e-5
+    # The 1 000-atom batch runs its dense layers on other kernels than the 140 000-atom one (csrc/rowprog.hip below 2 048
+    # rows): a pre-activation within an ulp of zero can land on the other side, and ONE flipped LeakyReLU derivative moves
+    # its row's gradients by 1e-4 .. 1e-3 (measured in the f32 and f16x3 modes: 1-2 of 18 M entries; none in the 24-bit
+    # modes).  With identical derivative patterns the gradients agree to 1e-5; with a handful of flips the comparison
+    # still catches what this test is about -- a wrapped 32-bit offset is an O(1) error.
+    flips = 0
+    for k in mk_big:
+        for a_, b_ in zip(mk_big[k], mk_sub[k]):
+            flips += int((a_[-b_.shape[0]:] != b_).sum())
+    assert flips <= 8, flips
+    gtol = 1e-5 if flips == 0 else 5e-3
+    assert maxnorm_rel(gx_big.cpu().numpy(), gx_sub.cpu().numpy()) <= gtol
+    assert maxnorm_rel(ge_big[e0:].cpu().numpy(), ge_sub.cpu().numpy()) <= gtol
