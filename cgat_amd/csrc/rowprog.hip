@@ -218,7 +218,13 @@ __device__ __forceinline__ void rp_tile(const RowOp& op, int task, int lane, int
     }
   };
 
-  // this wave's k groups: kpart, kpart + ksplit, ...
+  // this wave's k groups: kpart, kpart + ksplit, ...; the loads of the next DEPTH - 1 groups are issued before the one
+  // being multiplied.  What the ISA shows (round 6): the loads sit under uniform conditions, so hipcc waits vmcnt(0)
+  // before every group's first matrix instruction -- the groups requested together share ONE round trip, the steady state
+  // pays one per group.  Measured alternatives, none better at these sizes: unconditional requests with clamped indices
+  // (counted waits, but a K = 128 product re-requests its last group 7 times: single products 8 -> 22 us); a condition-
+  // free steady loop with a conditional drain (300-600 spilled registers across the inlined variants); batches of DEPTH
+  // groups requested, awaited and multiplied together (the same times within 5 %).
   const int ng_all = (K + GK - 1) / GK;
   const int ng = active ? (ng_all - kpart + ksplit - 1) / ksplit : 0;
   auto gidx = [&](int g) { return kpart + g * ksplit; };
