@@ -5,7 +5,7 @@
 # tools/counter_summary.py and a copy into profiles/ happen on the authoring side (tools/publish_profiles.sh).
 # Every rocprofv3 command has the program directly after `--`.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/${1:-r05final}
+O=$R/gpurun_out/${1:-r06final}
 mkdir -p $O
 python3 $R/tools/tree_id.py > $O/tree_id.txt
 cd /tmp; export TMPDIR=/tmp
@@ -21,12 +21,15 @@ done
 CGAT_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $O/pmc_mfma.log 2>&1
 python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass > $O/bench_stress.json 2> $O/bench_stress.err
 python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass --edge-storage bf16 > $O/bench_stress_bf16.json 2> $O/bench_stress_bf16.err
+python3 $R/bench.py --workload stress --steps 2 --warmup 1 --no-exclusive-pass --edge-storage bf16-mma > $O/bench_stress_bf16mma.json 2> $O/bench_stress_bf16mma.err
 # BASELINE configs[4]'s "rocprof roofline run": kernel statistics and HBM counters of one stress step (fp32 and bf16 storage)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stress_stats -- python3 $R/bench.py --workload stress --steps 1 --warmup 1 --no-exclusive-pass > $O/stress_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stress_bf16_stats -- python3 $R/bench.py --workload stress --steps 1 --warmup 1 --no-exclusive-pass --edge-storage bf16 > $O/stress_bf16_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stress_bf16mma_stats -- python3 $R/bench.py --workload stress --steps 1 --warmup 1 --no-exclusive-pass --edge-storage bf16-mma > $O/stress_bf16mma_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/stress_pmc_$c -- python3 $R/bench.py --workload stress --steps 1 --warmup 0 --no-exclusive-pass > $O/stress_pmc_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/stress_bf16_pmc_$c -- python3 $R/bench.py --workload stress --steps 1 --warmup 0 --no-exclusive-pass --edge-storage bf16 > $O/stress_bf16_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/stress_bf16mma_pmc_$c -- python3 $R/bench.py --workload stress --steps 1 --warmup 0 --no-exclusive-pass --edge-storage bf16-mma > $O/stress_bf16mma_pmc_$c.log 2>&1
 done
 python3 $R/bench.py --workload train --steps 8 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err
 python3 $R/bench.py --workload stack --steps 5 --warmup 2 --no-cpu-baseline --no-exclusive-pass --hipgraph > $O/bench_stack.json 2> $O/bench_stack.err
@@ -48,4 +51,5 @@ python3 bench.py --steps 10 --warmup 3 $Q > $O/bench_norccl.json 2> $O/bench_nor
 CGAT_DIST_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --workload train --steps 8 --warmup 3 > $O/bench_train_rccl1.json 2> $O/bench_train_rccl1.err
 # the N > 1 code path on the one GPU this box has (both ranks on cuda:0, gloo instead of RCCL: functional evidence only)
 CGAT_DIST_BACKEND=gloo CGAT_DIST_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-exclusive-pass > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
+python3 tools/abi_call_census.py 64 > $O/census64.txt 2>&1
 tail -c 400 $O/bench.json
