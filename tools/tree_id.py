@@ -19,7 +19,11 @@ def stamp(collection_dir=None):
     """'<git describe> (source tree <id>)' for the working tree, checked against the id the collection recorded."""
     cur = tree_id()
     try:
-        desc = subprocess.check_output(["git", "-C", ROOT, "describe", "--always", "--dirty"], text=True).strip()
+        desc = subprocess.check_output(["git", "-C", ROOT, "describe", "--always"], text=True).strip()
+        # dirty = uncommitted changes to the SOURCES the id covers (profiles / docs written while publishing do not count)
+        dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--"] + list(PATTERNS), text=True).strip()
+        if dirty:
+            desc += "-dirty"
     except Exception:
         desc = "no-git"
     s = f"{desc} (source tree {cur}"
