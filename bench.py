@@ -1058,9 +1058,11 @@ def main():
                             "traffic": cbytes, "traffic_source": csrc if cbytes else None,
                             # headline batch: one launch of each kernel per step -> bytes of the step over the tag's time in
                             # the step; stress: one chunk's launches over the mean duration of one launch of each kernel
-                            "frac_from_counters": (round(cbytes / ((ms_t / n_t * len(kn) if per_launch else ms_t / args.steps)
+                            # (a tag counts timed SCOPES -- one per group of per-edge launches, e.g. the three segment-backward
+                            # kernels are one scope -- and the counter bytes are the sum over the group's kernels)
+                            "frac_from_counters": (round(cbytes / ((ms_t / n_t if per_launch else ms_t / args.steps)
                                                                    * 1e-3) / 8e12, 4)
-                                                   if cbytes and (per_launch or n_t / args.steps == len(kn)) else None),
+                                                   if cbytes and (per_launch or n_t / args.steps == 1) else None),
                             "launches_per_step": n_t / args.steps,
                             "avg_launch_ms": round(ms_t / n_t, 4), "ms_per_step": round(ms_t / args.steps, 3),
                             "algorithmic_bytes_per_launch": int(nbytes / (n_t / args.steps))}

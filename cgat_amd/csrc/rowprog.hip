@@ -463,9 +463,12 @@ int rowprog_max_rows() {
   }
   return g_rp_max_rows;
 }
+// (K bounded too: a reduction over the BATCH -- a bias or weight gradient, K = 83 340 atoms with M = 3 outputs -- is 8 wave
+// tiles walking the whole batch: 0.72 ms in the 1 M-edge layer step where the split-K engine takes 0.05; found in the
+// round's own kernel statistics)
 bool rowprog_gemm_ok(const GemmParams& p) {
-  return p.M >= 1 && p.N >= 1 && p.K >= 1 && p.M <= rowprog_max_rows() && p.N <= 4096 && !p.a_rgather && !p.a_block &&
-         !p.b_kgather && !p.c_scatter && !p.add1 && !p.add2 && !p.a_outer && !p.b_outer;
+  return p.M >= 1 && p.N >= 1 && p.K >= 1 && p.M <= rowprog_max_rows() && p.N <= 4096 && p.K <= 2 * rowprog_max_rows() &&
+         !p.a_rgather && !p.a_block && !p.b_kgather && !p.c_scatter && !p.add1 && !p.add2 && !p.a_outer && !p.b_outer;
 }
 void rowprog_op_from_gemm(const GemmParams& p, cgat_rowprog_op* o) {
   memset(o, 0, sizeof(*o));
