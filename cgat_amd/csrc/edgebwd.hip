@@ -640,6 +640,21 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   return CGAT_OK;
 }
 
+// out[t, :] (+)= sum over the ncb 128-column blocks of x[t, :] times an ALREADY prepared six-pass image (block a at
+// Wq + a * 24576 floats, odd blocks negated: prepare_T_bf16_launch / _heads_launch with alternate = 1) -- the per-node
+// second layer of the message network, whose H per-head weights are not one affine operand (layers.hip)
+int edge_ge_prepared_launch(const float* x, long ldx, const void* Wq, int ncb, float* out, long ldo, int rows,
+                            int accumulate, hipStream_t stream) {
+  if (rows <= 0) return CGAT_OK;
+  CGAT_PROF("rows_ge", stream);
+  const EdgeRC none = {};
+  hipLaunchKernelGGL((edge_ge_kernel<6, false>), dim3(cdiv(rows, 256)), dim3(512), 0, stream, x, ldx, 128l, (const uint4*)Wq,
+                     ncb, out, ldo, (const int*)nullptr, rows, accumulate, (const float*)nullptr, (const float*)nullptr, none,
+                     HeadBatch{});
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // `heads` products y_h = x_h W_h^T + b_h (x_h = x + h * s_x: W2 columns of a wider matrix; W_h = W + h * s_w: [128, W2]
 // row-major with leading dimension W2, contiguous; y_h = y + h * s_y) in three launches instead of 4-5 per head: the
 // heads' weight maxima and fp16 planes through the batched preparation of the contraction kernels (bilinear.hip), then

@@ -251,6 +251,8 @@ bool edge_ge_heads_fast(int heads, int W2, long ldx, long ldy, long ldw, const v
 int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const float* W, long s_w, const float* bias,
                          long s_bias, float* y, long ldy, long s_y, int E, int W2, float* ws, hipStream_t stream,
                          const float* amax);
+int edge_ge_prepared_launch(const float* x, long ldx, const void* Wq, int ncb, float* out, long ldo, int rows,
+                            int accumulate, hipStream_t stream);   // six-pass image made by the caller (odd blocks negated)
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
                    float* out, long ldo, const int* scatter, int E, int accumulate, const float* bias,
                    hipStream_t stream,

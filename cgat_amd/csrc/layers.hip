@@ -783,7 +783,25 @@ static int attn_forward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_para
   // H * Hd / 128 accumulating launches of the dense-layer kernel (K = 128 each; the generic f32 GEMM tile took 0.1 ms
   // per head) and 1/H is applied by the bias product that closes the sum.
   const bool out_fast = bilinear_mode() != 0 && d.C == 128 && d.Hd % 128 == 0;
-  for (int h = 0; h < d.H; ++h) {
+  // Round 6: ONE K = H * Hd launch instead (the 24-bit modes, more rows than the small-row programs take): the H per-head
+  // weights are not one affine operand, but their six-pass images -- one batched image launch, head h's blocks behind
+  // head h - 1's -- are exactly the contiguous operand of the K = W2 -> 128 kernel (edgebwd.hip).  Saves five passes over
+  // aggr (42 MB read + written each at 83 340 atoms) and four launches.
+  const int ncb_h = d.Hd / 128;
+  const bool out_one = out_fast && (bilinear_mode() == 4 || bilinear_mode() == 6) && d.N > rowprog_max_rows() &&
+                       d.H <= TPREP_MAX && (ncb_h % 2) == 0;      // (even: the per-head block parity is the global one)
+  const size_t out_img_bytes = (size_t)d.H * ncb_h * 24576 * sizeof(float);
+  if (out_one) c.need(out_img_bytes);
+  bool out_done = false;
+  if (out_one && !c.dry && c.scratch_bytes >= out_img_bytes &&
+      edge_ge_fast(128, d.HHd, d.HHd, 128, d.C, sv.S, aggr) && (((uintptr_t)p->M_out_w) & 15) == 0) {
+    // operand (a = block of head h, b = column in block, c = output) = M_out_w[h * C * Hd + c * Hd + 128 a + b]
+    CGAT_TRY(prepare_T_bf16_heads_launch(p->M_out_w, c.scratch, ncb_h, 128, 1, d.Hd, /*alternate=*/1, d.H, (long)d.C * d.Hd,
+                                         (long)ncb_h * 24576, c.s));
+    CGAT_TRY(edge_ge_prepared_launch(sv.S, d.HHd, c.scratch, d.H * ncb_h, aggr, d.C, d.N, 0, c.s));
+    out_done = true;
+  }
+  for (int h = 0; h < d.H && !out_done; ++h) {
     if (out_fast) {
       for (int j = 0; j < d.Hd / 128; ++j) {
         GemmParams g = gemm_params(d.N, d.C, 128, sv.S + (size_t)h * d.Hd + 128 * j, d.HHd,
@@ -954,6 +972,7 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
   if (out_fast) {
     c.need(rows_dw128_batch_ws_bytes(d.H * (d.Hd / 128), d.N));
     c.need(linear128_ws_bytes(d.Hd));
+    c.need((size_t)d.H * linear128_heads_image_floats(d.Hd) * sizeof(float));
     DwBatchDesc b;
     memset(&b, 0, sizeof(b));
     b.rows = d.N; b.ldg = d.C; b.ldx = d.HHd; b.ldo = d.Hd;
@@ -965,11 +984,19 @@ static int attn_backward_impl(Ctx& c, const cgat_plan* plan, const cgat_attn_par
     if (c.dry || (d.N > 0 && linear128_fast(d.C, d.Hd, d.C, d.HHd, gas, gS) && rows_dw128_batch_fast(b) &&
                   c.scratch_bytes >= rows_dw128_batch_ws_bytes(b.n, d.N))) {
       RUN(scale_launch(g_aggr, invH, gas, (long)d.N * d.C, c.s));
-      for (int h = 0; h < d.H; ++h) {   // gS[:,h,:] = gas @ fc_out_M[h]
-        GemmParams g = gemm_params(d.N, d.Hd, d.C, gas, d.C, p->M_out_w + (size_t)h * d.C * d.Hd, d.Hd,
-                                   gS + (size_t)h * d.Hd, d.HHd);
-        g.b_kmajor = 1;
-        CGAT_TRY(c.gemm(g));
+      const size_t gs_img_bytes = (size_t)d.H * linear128_heads_image_floats(d.Hd) * sizeof(float);
+      if (!c.dry && (bilinear_mode() == 4 || bilinear_mode() == 6) && d.N > rowprog_max_rows() && d.H > 1 &&
+          c.scratch_bytes >= gs_img_bytes && (((uintptr_t)p->M_out_w) & 15) == 0) {
+        // all heads in one launch pair (round 6): head h reads the same gas, its weight at + h * C * Hd, writes gS + h * Hd
+        CGAT_TRY(linear128_heads_launch(d.H, gas, d.C, 0, p->M_out_w, 1, d.Hd, (long)d.C * d.Hd, nullptr, 0, CGAT_ACT_NONE, 0, gS,
+                                        d.HHd, d.Hd, d.N, c.scratch, c.s, d.Hd, nullptr, 0, 0, nullptr));
+      } else {
+        for (int h = 0; h < d.H; ++h) {   // gS[:,h,:] = gas @ fc_out_M[h]
+          GemmParams g = gemm_params(d.N, d.Hd, d.C, gas, d.C, p->M_out_w + (size_t)h * d.C * d.Hd, d.Hd,
+                                     gS + (size_t)h * d.Hd, d.HHd);
+          g.b_kmajor = 1;
+          CGAT_TRY(c.gemm(g));
+        }
       }
       RUN(rows_dw128_batch_launch(b, c.scratch, c.scratch_bytes, c.s));   // grad fc_out_M[h] = gas^T S[:,h,:]
       out_done = true;

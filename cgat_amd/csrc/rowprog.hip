@@ -25,6 +25,11 @@
 // ran on before round 6 summed 32 exact products per rounding.)  No operand splitting, no prepared weight images: at
 // <= 2048 rows the weights are read once, straight from HBM into registers (a 16 x 64 wave tile needs no LDS staging,
 // cdna_hip_programming.md "M <= 16 decode weights" row).  Fixed task -> wave mapping: bitwise reproducible.
+// What bounds a LARGE product here is the fp64 matrix rate itself: tools/mfma_f64_rate.hip measures 146 cycles per
+// v_mfma_f64_16x16x4_f64 and SIMD = 34 TFLOP/s for the chip (the f32-input 16x16x4 form: 104-111), and a 1 280 x 128 x
+// 2 560 product (0.84 GFLOP: the input gradient of a 5-head first layer at 64 crystals) takes 53 us = half of that
+// whatever the load schedule (tools/rowprog_longk_probe.py: deeper k splits, batched requests: 48-65 us).  Programs are
+// for products whose cost is their kernel boundaries; rowprog_gemm_ok() bounds rows and K accordingly.
 #include <stdlib.h>
 #include <string.h>
 

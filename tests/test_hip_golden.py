@@ -216,6 +216,25 @@ def test_nodes_layer_vs_oracle_random_init(first):
 
 
 @pytest.mark.gpu
+def test_nodes_layer_vs_oracle_above_small_row_limit():
+    """The same layer at 150 crystals (N = 3000, E = 36 000): more rows than the small-row programs take (2048), so the
+    node side runs the large-batch kernels -- among them the ONE K = H * Hd launch for the per-head second layer of the
+    message network and the heads-batched launch of its input gradients (layers.hip, round 6) -- forward and every
+    gradient against the oracle."""
+    import cgat_amd as P
+    from oracle import cgat_oracle as O
+    b, _ = P.synthetic_batch(150, 20, 12, seed=5)
+    g = torch.Generator().manual_seed(6)
+    N, E = b.num_nodes, b.edge_index.shape[1]
+    assert N > 2048
+    inputs = {"x": torch.randn(N, 128, generator=g), "edge_index": b.edge_index,
+              "edge_attr": torch.randn(E, 128, generator=g), "x_0": torch.randn(N, 128, generator=g)}
+    call = lambda m, i: m(i["x"], i["edge_index"], i["edge_attr"], i["x_0"])
+    _compare_with_oracle(lambda: P.GATConvNodes(128, 128, 128, 3, concat=True),
+                         lambda: O.GATConvNodes(128, 128, 128, 3, concat=True), inputs, call)
+
+
+@pytest.mark.gpu
 def test_vector_attention_layer_vs_oracle_random_init():
     """vector_attention=True (the reference harness' shipped default) at the BASELINE widths: the
     operand-split first layer (edge_hidden op on the split-bf16 kernels) + channel-wise softmax against the oracle."""
