@@ -46,8 +46,8 @@ python3 $R/bench.py --workload train --graphs 64 --steps 20 --warmup 5 > $O/benc
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stack64_stats -- python3 $R/bench.py --workload stack --graphs 64 --steps 10 --warmup 2 $Q > $O/stack64_stats.log 2>&1
 # the gradient all-reduce path over a ONE-RANK RCCL communicator (CGAT_DIST_FORCE=1): what every rank of an N > 1 run does
 cd $R
-CGAT_DIST_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 10 --warmup 3 $Q > $O/bench_rccl1.json 2> $O/bench_rccl1.err
-python3 bench.py --steps 10 --warmup 3 $Q > $O/bench_norccl.json 2> $O/bench_norccl.err
+CGAT_DIST_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 $Q > $O/bench_rccl1.json 2> $O/bench_rccl1.err
+python3 bench.py --steps 20 --warmup 5 $Q > $O/bench_norccl.json 2> $O/bench_norccl.err
 CGAT_DIST_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --workload train --steps 8 --warmup 3 > $O/bench_train_rccl1.json 2> $O/bench_train_rccl1.err
 # the N > 1 code path on the one GPU this box has (both ranks on cuda:0, gloo instead of RCCL: functional evidence only)
 CGAT_DIST_BACKEND=gloo CGAT_DIST_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-exclusive-pass > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err
