@@ -640,6 +640,39 @@ int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_
   return CGAT_OK;
 }
 
+// K-split form of the product above for FEW row tiles beside a long K (round 6; the harness' shipped batch: g_edge_attr at
+// 30 720 edges is 120 workgroups walking 20 column blocks, the node-side input gradients at 1 280 atoms 5 workgroups --
+// or, as small-row programs, 0.84 GFLOP on the fp64 matrix instruction: 100-160 us a launch).  The column blocks are dealt
+// to S groups (grid.y), group s multiplies its blocks into slab s ([E, 128] each, at slabs + s * E * 128, scattered rows as
+// `out` would be); the caller adds the slabs in group order (sum_slabs_launch).  A group holds an EVEN number of blocks,
+// so that a block's position in its group has the parity of its position in the row (the sign alternation above).
+// Returns the number of groups a launch of this shape takes; 1 = not worth it / not available (then use edge_ge_launch).
+int edge_ge_ksplit_groups(int E, int W2) {
+  if (bilinear_mode() != 4 && bilinear_mode() != 6) return 1;
+  const int ncb = W2 / 128, tiles = cdiv(E, 256);
+  if (W2 % 128 != 0 || E < 1024 || tiles >= 192) return 1;     // (the reference's fixtures stay on the unsplit forms)
+  int best = 1;
+  for (int S = 2; S <= ncb; ++S)
+    if (ncb % S == 0 && ((ncb / S) & 1) == 0) { best = S; if (tiles * S >= 192) break; }
+  return best;
+}
+int edge_ge_ksplit_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
+                          float* slabs, const int* scatter, int E, int S, hipStream_t stream) {
+  if (E <= 0) return CGAT_OK;
+  const int ncb = W2 / 128;
+  CGAT_CHECK_ARG(S >= 1 && ncb % S == 0 && (S == 1 || ((ncb / S) & 1) == 0) && (bilinear_mode() == 4 || bilinear_mode() == 6),
+                 "edge_ge_ksplit: %d groups of %d column blocks", S, ncb);
+  CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * s_col, s_col, s_out, /*alternate=*/1, stream));
+  CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);
+  const EdgeRC none = {};
+  const int ncb_g = ncb / S;
+  const HeadBatch hb = {(long)ncb_g * gzb, (long)ncb_g * 6144, 0, (long)E * 128, 0, 0};
+  hipLaunchKernelGGL((edge_ge_kernel<6, false>), dim3(cdiv(E, 256), S), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq,
+                     ncb_g, slabs, 128l, scatter, E, 0, (const float*)nullptr, (const float*)nullptr, none, hb);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 // out[t, :] (+)= sum over the ncb 128-column blocks of x[t, :] times an ALREADY prepared six-pass image (block a at
 // Wq + a * 24576 floats, odd blocks negated: prepare_T_bf16_launch / _heads_launch with alternate = 1) -- the per-node
 // second layer of the message network, whose H per-head weights are not one affine operand (layers.hip)

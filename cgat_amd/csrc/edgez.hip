@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   Z += (long)blockIdx.y * hb.out;
   if (Pi) Pi += (long)blockIdx.y * hb.bias;
   if (dact) dact += (long)blockIdx.y * hb.dact;
+  if (ADDS) Pj += (long)blockIdx.y * hb.add2;
   constexpr bool F16 = PASSES == 2;             // two fp16 planes, three passes (mfma_bf16.h): rows scaled per row,
   constexpr int NP = F16 ? 2 : 3;               // the weight per 128-column block (wmax behind the planes)
   constexpr int CH16 = NP * 4 * 64;             // 16-byte pieces per chunk = 12 KB (8 KB)
@@ -1214,10 +1215,19 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
     return CGAT_OK;
   }
   const int grid = cdiv(E, 128);
+  // Few rows beside many column blocks -- at the harness' shipped batch the per-node projections are 10 workgroups and the
+  // per-edge first layer of a vector-attention layer 240, each walking 20 blocks (149 / 180 us per launch, 2.4 ms of an
+  // 18-ms step) -- : the column blocks are dealt to grid.y groups (round 6).  A workgroup then splits its rows once per group
+  // (64 KB, L2-resident) and walks ncb / G blocks; every block is computed as before: bit-identical.  The 24-bit modes
+  // without logits (the fp16 image keeps its scale behind the LAST block).
+  int G = 1;
+  if ((bilinear_mode() == 4 || bilinear_mode() == 6) && !z_bf16 && !a_out) G = z_col_groups(grid, ncb);
+  const int ncb_g = ncb / G;
+  const HeadBatch hbz = {0, (long)ncb_g * 6144, (long)ncb_g * 128, (long)ncb_g * 128, 0, (long)ncb_g * 128};
 #define EZ_GO(P_, A_)                                                                                                \
-  hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, \
+  hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid, G), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb_g, \
                      Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr, 0l, \
-                     HeadBatch{})
+                     G > 1 ? hbz : HeadBatch{})
   const bool adds = Pj != nullptr;
   if (bilinear_mode() == 2) { if (adds) EZ_GO(2, true); else EZ_GO(2, false); }
   else if (bilinear_mode() != 3 && z_bf16)
@@ -1254,11 +1264,15 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   else CGAT_TRY(prepare_T_bf16_launch(W, ws, ncb, 128 * so, sk, so, 0, stream));
   CGAT_PROF("linear128", stream);
   const int grid = cdiv(rows, 128);
+  // (column blocks over grid.y when the row tiles leave CUs idle: edge_z_launch above)
+  const int G = (bilinear_mode() == 4 || bilinear_mode() == 6) ? z_col_groups(grid, ncb) : 1;
+  const int ncb_g = ncb / G;
+  const HeadBatch hbz = {0, (long)ncb_g * 6144, (long)ncb_g * 128, (long)ncb_g * 128, (long)ncb_g * 128, 0};
 #define L128_GO(P_)                                                                                                   \
-  hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid), dim3(256), 0, stream, in, ldi, (const int*)nullptr,      \
-                     (const uint4*)ws, ncb, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
+  hipLaunchKernelGGL((edge_z_kernel<P_, false>), dim3(grid, G), dim3(256), 0, stream, in, ldi, (const int*)nullptr,   \
+                     (const uint4*)ws, ncb_g, bias, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, 0l, \
                      out, ldo, rows, (const float*)nullptr, (const float*)nullptr, 1, 1, (float*)nullptr, act, accumulate, \
-                     omax, dact, ld_dact, HeadBatch{})
+                     omax, dact, ld_dact, G > 1 ? hbz : HeadBatch{})
   if (bilinear_mode() == 2) L128_GO(2); else if (bilinear_mode() != 3) L128_GO(6); else L128_GO(3);
 #undef L128_GO
   CGAT_LAUNCH_CHECK();

@@ -154,7 +154,17 @@ int prepare_W_f16_heads_launch(const float* src, void* dst, int NA, long sa, lon
 // w in 16-byte pieces): all zero = the single-operand launch
 struct HeadBatch {
   long in, w, bias, out, dact;
+  long add2;   // edge_z_kernel: offset of the second gathered table (column groups of the per-edge first layer)
 };
+// column blocks of a [rows, 128 ncb] product dealt to grid.y groups when the row tiles alone leave CUs idle: the number
+// of groups (a divisor of ncb; 1 = no split)
+static inline int z_col_groups(int row_tiles, int ncb) {
+  int G = 1;
+  if (row_tiles >= 512) return 1;
+  for (int g = 2; g <= ncb; ++g)
+    if (ncb % g == 0) { G = g; if ((long)row_tiles * G >= 512) break; }
+  return G;
+}
 size_t linear128_heads_image_floats(int n_out);
 int linear128_heads_launch(int heads, const float* in, long ldi, long s_in, const float* W, long so, long sk, long s_w,
                            const float* bias, long s_bias, int act, int accumulate, float* out, long ldo, long s_out, int rows,
@@ -251,6 +261,9 @@ bool edge_ge_heads_fast(int heads, int W2, long ldx, long ldy, long ldw, const v
 int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const float* W, long s_w, const float* bias,
                          long s_bias, float* y, long ldy, long s_y, int E, int W2, float* ws, hipStream_t stream,
                          const float* amax);
+int edge_ge_ksplit_groups(int E, int W2);   // K-split form for few row tiles: groups a launch takes (1: use edge_ge_launch)
+int edge_ge_ksplit_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
+                          float* slabs, const int* scatter, int E, int S, hipStream_t stream);   // S slabs [E,128]; caller sums
 int edge_ge_prepared_launch(const float* x, long ldx, const void* Wq, int ncb, float* out, long ldo, int rows,
                             int accumulate, hipStream_t stream);   // six-pass image made by the caller (odd blocks negated)
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
@@ -302,6 +315,7 @@ int mix_bwd_launch(const float* g, const float* a, const float* b, const float* 
                    float* gd, long n, void* ws, size_t ws_bytes, hipStream_t s);
 int scale_launch(const float* x, float alpha, float* out, long n, hipStream_t s);   // out = alpha * x
 int axpy_launch(float* y, const float* x, float alpha, long n, hipStream_t s);  // y += alpha*x
+int sum_slabs_launch(const float* slabs, int n, long stride, float* out, long count, hipStream_t s);   // out = 0.f + slab 0 + slab 1 + ...
 int copy2d_launch(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t s);
 struct Copy2DJob { const float* src; long lds; float* dst; long ldd; int rows, cols; };
 struct Copy2DJobs { Copy2DJob job[4]; int n; };

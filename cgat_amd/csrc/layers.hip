@@ -866,9 +866,21 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // node-side products of the operand split: g_x = Gi W_i + Gj W_j,  grad W_i = Gi^T x,  grad W_j = Gj^T x.
   // Same shapes as the two edge kernels (K = 1536 -> 128 outputs per row; K = rows -> 1536 x 128): reuse them on
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
+  // (K-split forms of the two K = W2 -> 128 products at few row tiles, edgebwd.hip: slabs in the scratch region)
+  const int Sx = (!ns && d.C == 128) ? edge_ge_ksplit_groups(d.N, d.W2) : 1;
+  const int Se = (!rc && !scales && d.Ce == 128) ? edge_ge_ksplit_groups(d.E, d.W2) : 1;
+  if (Sx > 1) c.need((size_t)2 * Sx * d.N * 128 * sizeof(float));
+  if (Se > 1) c.need((size_t)Se * d.E * 128 * sizeof(float));
   if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
       ((((uintptr_t)Gj) | ((uintptr_t)x)) & 15) == 0 && d.N <= d.E) {
-    if (d.N <= rowprog_max_rows()) {
+    if (Sx > 1 && c.scratch_bytes >= (size_t)2 * Sx * d.N * 128 * sizeof(float)) {
+      // g_x = Gi W_i + Gj W_j as 2 Sx slabs, added in order (round 6: 2 x 100 us of fp64 small-row products -> 3 launches)
+      float* sl = (float*)c.scratch;
+      RUN(edge_ge_ksplit_launch(Gi, d.W2, 128, Wcat, d.D, 1, Wq, d.W2, sl, nullptr, d.N, Sx, c.s));
+      RUN(edge_ge_ksplit_launch(Gj, d.W2, 128, Wcat + d.C + d.Ce, d.D, 1, Wq, d.W2, sl + (size_t)Sx * d.N * 128, nullptr, d.N,
+                                Sx, c.s));
+      RUN(sum_slabs_launch(sl, 2 * Sx, (long)d.N * 128, g_x, (long)d.N * 128, c.s));
+    } else if (d.N <= rowprog_max_rows()) {
       // a few hundred atoms: the 256-row tiles of the per-edge kernel are 5 workgroups walking K = 1536 (91 us a launch
       // at 1 280 atoms); as 16 x 16 wave tiles with the k range dealt over a workgroup's waves the chip is full
       GemmParams g = gemm_params(d.N, d.C, d.W2, Gi, d.W2, Wcat, d.D, g_x, d.C);
@@ -906,7 +918,12 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   if (!c.dry && rc)
     CGAT_CHECK_ARG(edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) && edge_gw_fast(d.Ce, d.W2, gz_ld, gzb, gZ) && have_Gi,
                    "nodes_attention_backward: the rebuilt-gZ path needs the split per-edge kernels");
-  if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
+  if (!c.dry && Se > 1 && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) &&
+      c.scratch_bytes >= (size_t)Se * d.E * 128 * sizeof(float)) {
+    float* sl = (float*)c.scratch;
+    RUN(edge_ge_ksplit_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, sl, plan->dst_perm, d.E, Se, c.s));
+    RUN(sum_slabs_launch(sl, Se, (long)d.E * 128, g_e, (long)d.E * 128, c.s));
+  } else if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
     RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
                        scales, rc));
   } else {
@@ -1494,7 +1511,6 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   float* g_hin = c.take<float>(rw);
   float* g_u = c.take<float>((size_t)p->n_hyper * rw);   // one per predicted layer: all dT run in ONE launch at the end
   float* gvin_buf[2] = {c.take<float>(rw), c.take<float>(rw)};
-  float* g_t = c.take<float>(rw);
   const bool batch_w = W == 128 && p->n_hyper * (p->n_fc + 2) <= WPREP_MAX;
   // the fused trunk chain (chain.hip) leaves every trunk layer's pre-activation gradient behind, so the weight
   // gradients of all dense layers of all predicted layers can wait for ONE batched launch at the end (rowsdw.hip):
@@ -1502,6 +1518,17 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
   const bool chain_ok = batch_w && wprep_image_floats() != 0 && p->n_fc >= 1 && p->n_fc <= CHAIN_MAX;
   const bool defer_dw = chain_ok && p->n_hyper * (p->n_fc + 2) <= DW_BATCH_MAX;
   const int nfc1 = p->n_fc > 0 ? p->n_fc : 1;
+  // At a few thousand rows (the harness' shipped batch: 1 280 atoms) a trunk chain is 10 workgroups, and the four chains of
+  // a backward pass -- one per predicted layer, each 57 us, none feeding another: they feed the weight gradients and the
+  // SUM g_hin -- were 1.1 ms of an 18-ms step.  There they wait for ONE batched launch behind the loop (round 6): every
+  // predicted layer keeps its own g_t and writes its g_hin term to a slab; the slabs are added in the order the
+  // accumulating chains ran in (bit-identical).
+  const bool chain_batch = chain_ok && defer_dw && rows <= 8192 && p->n_hyper > 1 && p->n_hyper <= CHAIN_BATCH_MAX &&
+                           bilinear_mode() != 2;
+  float* g_t_all = c.take<float>((chain_batch ? (size_t)p->n_hyper : 1) * rw);
+  float* ghin_slabs = chain_batch ? c.take<float>((size_t)p->n_hyper * rw) : nullptr;
+  ChainDesc pending[CHAIN_BATCH_MAX];
+  int n_pending = 0, n_slabs = 0;
   const HnetSideLayout SL = hnet_side_layout(rows, p);
   float* g_pre_all = (side && defer_dw) ? (c.dry ? nullptr : (float*)((char*)side->ws + SL.gpre))
                                         : c.take<float>((size_t)(defer_dw ? p->n_hyper : 1) * nfc1 * rw);
@@ -1574,6 +1601,7 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       gu = gu_buf;
     }
     float* g_vin = (l == 0) ? g_v : gvin_buf[l & 1];  // gradient wrt this layer's input
+    float* g_t = c.dry ? nullptr : g_t_all + (chain_batch ? (size_t)l * rw : 0);
     const float* vin = (l == 0) ? v : sv.vin(l);
     const float* z = c.dry ? nullptr : sv.act(l, p->n_fc - 1);
     // ---- head parameter gradients ----
@@ -1648,14 +1676,25 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
         if (sl > 0) {
           cl.dact = sv.act(l, sl - 1); cl.ld_dact = W; cl.dact_type = CGAT_ACT_TANH;
           cl.out = g_pre + (size_t)(sl - 1) * rw; cl.ld_out = W;
+        } else if (chain_batch) {
+          cl.out = ghin_slabs + (size_t)n_slabs * rw; cl.ld_out = W;   // (summed behind the loop, in this order)
         } else {
           cl.out = g_hin; cl.ld_out = W; cl.accumulate = 1;   // every predicted layer's trunk reads the same hyper input
         }
         ok = ok && cl.W;
       }
       ok = ok && mlp_chain128_fast(cd);
+      // (batched: a weight gradient that cannot wait for the batched launch would read g_pre before the chain has run)
+      bool can_wait = chain_batch;
+      for (int s2 = nf - 1; s2 >= 0 && can_wait; --s2)
+        can_wait = rows_dw128_fast(g_pre + (size_t)s2 * rw, W, (s2 == 0) ? hin : sv.act(l, s2 - 1), W, nullptr, 0) &&
+                   dwb.n + nf <= DW_BATCH_MAX;
+      if (ok && chain_batch && !can_wait) {
+        cd.layer[nf - 1].out = g_hin; cd.layer[nf - 1].accumulate = 1;
+      }
       if (ok) {
-        CGAT_TRY(mlp_chain128_launch(cd, c.s));
+        if (chain_batch && can_wait) { pending[n_pending++] = cd; ++n_slabs; }
+        else CGAT_TRY(mlp_chain128_launch(cd, c.s));
         for (int s2 = nf - 1; s2 >= 0; --s2) {
           const float* tin = (s2 == 0) ? hin : sv.act(l, s2 - 1);
           const float* gp = g_pre + (size_t)s2 * rw;
@@ -1690,6 +1729,14 @@ static int hnet_backward_impl(Ctx& c, int rows, const cgat_hnet_params* p, const
       CGAT_TRY(c.gemm(g));
     }
     gout = g_vin;
+  }
+  if (n_pending > 0) {
+    CGAT_TRY(mlp_chain128_batch_launch(pending, n_pending, c.s));
+    if (n_pending == p->n_hyper) {
+      RUN(sum_slabs_launch(ghin_slabs, n_slabs, (long)rw, g_hin, (long)rw, c.s));   // (g_hin was zero: 0.f + c_last + ... + c_0)
+    } else {      // some layer took the accumulating route: add the slabs to what it left
+      for (int z = 0; z < n_slabs; ++z) RUN(axpy_launch(g_hin, ghin_slabs + (size_t)z * rw, 1.f, (long)rw, c.s));
+    }
   }
   if (p->damping) {
     CGAT_TRY(c.mix_bwd(g_hin, h0, v, p->damping, g_h0, g_v, gr->damping, (long)rw));

@@ -327,6 +327,22 @@ int copy2d_multi_launch(const Copy2DJobs& j, hipStream_t s) {
 // previous replay had left in the reused block, atomicMax compared against them, the operand scale came out wrong and the
 // step returned NaN -- replay 0 and every eager run were fine.  The same zeroing as a kernel node replays bit-identically
 // (tests/test_capture.py).
+// out[i] = sum_z slabs[z * stride + i], z = 0 .. n-1 in that order, starting from 0.f (what n accumulating passes over a
+// zero-filled buffer produce, bit for bit)
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int n, long stride, float* __restrict__ out, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int z = 0; z < n; ++z) s += slabs[(long)z * stride + i];
+  out[i] = s;
+}
+int sum_slabs_launch(const float* slabs, int n, long stride, float* out, long count, hipStream_t s) {
+  if (count <= 0) return CGAT_OK;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3(cdiv(count, 256)), dim3(256), 0, s, slabs, n, stride, out, count);
+  CGAT_LAUNCH_CHECK();
+  return CGAT_OK;
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
