@@ -488,6 +488,7 @@ int rowdot_launch(const float* x, long ldx, int act, const float* v, long ldv, c
 // grouped pass the plan's permutation instead of gathering), U of them in flight; no atomics, fixed summation order.
 // ---------------------------------------------------------------------------------------
 #define AP_U 4
+#define AP_W 8     // rows whose logits are in flight together in the maximum / normaliser passes
 template <bool PER_F>   // PER_F: one logit column per feature (fw == 1); else fw % 4 == 0
 __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __restrict__ a, int aF, int fw,
                                                                 const float* __restrict__ mult,
@@ -500,14 +501,22 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
   const int r0 = rowptr[s], r1 = rowptr[s + 1];
   for (int f = 4 * threadIdx.x; f < F; f += 4 * blockDim.x) {
     const int ac = PER_F ? f : f / fw;
+    // (the logits of AP_W rows are requested together in the two passes below: one row per round trip made a segment of
+    // 24 neighbours 48 dependent L2 latencies -- 77 us per launch at 1 280 atoms; same operations in the same order)
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    for (int r = r0; r < r1; ++r) {
-      const long row = ridx ? (long)ridx[r] : (long)r;
-      if (PER_F) {
-        const float4 v = *reinterpret_cast<const float4*>(a + row * aF + ac);
-        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-      } else {
-        mx.x = fmaxf(mx.x, a[row * aF + ac]);
+    for (int r = r0; r < r1; r += AP_W) {
+      float4 v[AP_W];
+#pragma unroll
+      for (int u = 0; u < AP_W; ++u) {
+        const int rs = r + u < r1 ? r + u : r1 - 1;
+        const long row = ridx ? (long)ridx[rs] : (long)rs;
+        if (PER_F) v[u] = *reinterpret_cast<const float4*>(a + row * aF + ac);
+        else v[u].x = a[row * aF + ac];
+      }
+#pragma unroll
+      for (int u = 0; u < AP_W; ++u) {       // (a clamped repeat of the last row leaves a maximum unchanged)
+        mx.x = fmaxf(mx.x, v[u].x);
+        if (PER_F) { mx.y = fmaxf(mx.y, v[u].y); mx.z = fmaxf(mx.z, v[u].z); mx.w = fmaxf(mx.w, v[u].w); }
       }
     }
     if (!PER_F) mx.y = mx.z = mx.w = mx.x;
@@ -521,14 +530,27 @@ __global__ __launch_bounds__(1024) void seg_attnpool_fwd_kernel(const float* __r
     // row on it, g_a = sum_f alpha g (m - out), and a rounding error of `out` would be common to all rows of the segment.
     // The segment's denominator sum + eps goes to `inv_out` (backward divides by it again: the same alpha).
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0; r < r1; ++r) {
-      const long rr = ridx ? (long)ridx[r] : (long)r;
-      const float w = mult ? mult[rr] : 1.f;
-      if (PER_F) {
-        const float4 v = *reinterpret_cast<const float4*>(a + rr * aF + ac);
-        z.x += expf(v.x - mx.x) * w; z.y += expf(v.y - mx.y) * w; z.z += expf(v.z - mx.z) * w; z.w += expf(v.w - mx.w) * w;
-      } else {
-        z.x += expf(a[rr * aF + ac] - mx.x) * w;
+    for (int r = r0; r < r1; r += AP_W) {
+      float4 v[AP_W];
+      float wv[AP_W];
+#pragma unroll
+      for (int u = 0; u < AP_W; ++u) {
+        const int rs = r + u < r1 ? r + u : r1 - 1;
+        const long rr = ridx ? (long)ridx[rs] : (long)rs;
+        wv[u] = mult ? mult[rr] : 1.f;
+        if (PER_F) v[u] = *reinterpret_cast<const float4*>(a + rr * aF + ac);
+        else v[u].x = a[rr * aF + ac];
+      }
+#pragma unroll
+      for (int u = 0; u < AP_W; ++u) {
+        if (r + u < r1) {
+          if (PER_F) {
+            z.x += expf(v[u].x - mx.x) * wv[u]; z.y += expf(v[u].y - mx.y) * wv[u];
+            z.z += expf(v[u].z - mx.z) * wv[u]; z.w += expf(v[u].w - mx.w) * wv[u];
+          } else {
+            z.x += expf(v[u].x - mx.x) * wv[u];
+          }
+        }
       }
     }
     if (!PER_F) z.y = z.z = z.w = z.x;
@@ -625,13 +647,28 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
     // low part of the forward's fp64 sum (see the forward kernel): m - out = (m - out_hi) - out_lo
     const float4 ol = out_lo ? *reinterpret_cast<const float4*>(out_lo + (long)s * F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 go = *reinterpret_cast<const float4*>(g_out + (long)s * F + f);
-    for (int rs = r0; rs < r1; ++rs) {
-      const long r = ridx ? (long)ridx[rs] : (long)rs;
-      const float w = mult ? mult[r] : 1.f;
-      float4 av;
-      if (PER_F) av = *reinterpret_cast<const float4*>(a + r * aF + ac);
-      else { av.x = a[r * aF + ac]; av.y = av.z = av.w = av.x; }
-      const float4 mv = *reinterpret_cast<const float4*>(m + r * ldm + f);
+    for (int rb = r0; rb < r1; rb += AP_U) {
+     // (the operands of AP_U rows requested together, round 6: one row per round trip before; same operations per row)
+     float4 avv[AP_U], mvv[AP_U];
+     float wvv[AP_U];
+     long rrv[AP_U];
+#pragma unroll
+     for (int u = 0; u < AP_U; ++u) {
+       const int rc_ = rb + u < r1 ? rb + u : r1 - 1;
+       rrv[u] = ridx ? (long)ridx[rc_] : (long)rc_;
+       wvv[u] = mult ? mult[rrv[u]] : 1.f;
+       if (PER_F) avv[u] = *reinterpret_cast<const float4*>(a + rrv[u] * aF + ac);
+       else avv[u].x = a[rrv[u] * aF + ac];
+       mvv[u] = *reinterpret_cast<const float4*>(m + rrv[u] * ldm + f);
+     }
+#pragma unroll
+     for (int u = 0; u < AP_U; ++u) {
+      if (rb + u >= r1) break;                  // (uniform over the workgroup: no lane skips a shuffle another executes)
+      const long r = rrv[u];
+      const float w = wvv[u];
+      float4 av = avv[u];
+      if (!PER_F) av.y = av.z = av.w = av.x;
+      const float4 mv = mvv[u];
       float4 al;
       al.x = (expf(av.x - mx.x) * w) / inv.x;    // `inv` holds the segment's denominator sum + eps (see the forward)
       if (PER_F) { al.y = (expf(av.y - mx.y) * w) / inv.y; al.z = (expf(av.z - mx.z) * w) / inv.z; al.w = (expf(av.w - mx.w) * w) / inv.w; }
@@ -658,6 +695,7 @@ __global__ __launch_bounds__(1024) void seg_attnpool_bwd_kernel(const float* __r
           if (g_mult) g_mult[r] = q;
         }
       }
+     }
     }
   }
 }
