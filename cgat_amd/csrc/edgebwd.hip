@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
   const float* ga = gZ + rca * ldg + 8 * kg;     // + a * gzb + 32 s
   const float* gb = gZ + rcb * ldg + 8 * kg;
   const int nk = ncb * 4;
+  const int ks0 = RC ? (int)((long)blockIdx.y * hb.ks0) : 0;
   // RC: per-row bases of the ingredients
   const unsigned* mka = nullptr; const unsigned* mkb = nullptr;
   const float *gsa = nullptr, *gsb = nullptr, *caA = nullptr, *cbA = nullptr, *caM = nullptr, *cbM = nullptr;
@@ -111,14 +112,15 @@ __global__ __launch_bounds__(512, 2) void edge_ge_kernel(const float* __restrict
 #define GE_ALOAD(ks_, A0_, A1_, B0_, B1_, CA_, CB_, MA_, MB_)                                            \
   {                                                                                                      \
     if constexpr (RC) {                                                                                  \
-      const int c0_ = 32 * (ks_);                      /* first column of the k-step (uniform) */           \
+      const int kk_ = (ks_) + ks0;                     /* k-step within the whole row (K groups, grid.y) */  \
+      const int c0_ = 32 * kk_;                        /* first column of the k-step (uniform) */           \
       const bool isA_ = c0_ < rc.HHd;                                                                    \
       const int cc_ = isA_ ? c0_ : c0_ - rc.HHd, h_ = cc_ / rc.Hd;                                       \
       const float4* pa = reinterpret_cast<const float4*>(isA_ ? rc.wA + cc_ + 8 * kg : gsa + cc_);      \
       const float4* pb = reinterpret_cast<const float4*>(isA_ ? rc.wA + cc_ + 8 * kg : gsb + cc_);      \
       A0_ = pa[0]; A1_ = pa[1]; B0_ = pb[0]; B1_ = pb[1];                                                \
       CA_ = (isA_ ? caA : caM)[h_]; CB_ = (isA_ ? cbA : cbM)[h_];                                        \
-      MA_ = mka[ks_]; MB_ = mkb[ks_];                                                                    \
+      MA_ = mka[kk_]; MB_ = mkb[kk_];                                                                    \
     } else {                                                                                             \
       const long off = (long)((ks_) >> 2) * gzb + 32 * ((ks_) & 3);                                      \
       const float4* pa = reinterpret_cast<const float4*>(ga + off);                                      \
@@ -657,7 +659,7 @@ int edge_ge_ksplit_groups(int E, int W2) {
   return best;
 }
 int edge_ge_ksplit_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
-                          float* slabs, const int* scatter, int E, int S, hipStream_t stream) {
+                          float* slabs, const int* scatter, int E, int S, hipStream_t stream, const EdgeRC* rc) {
   if (E <= 0) return CGAT_OK;
   const int ncb = W2 / 128;
   CGAT_CHECK_ARG(S >= 1 && ncb % S == 0 && (S == 1 || ((ncb / S) & 1) == 0) && (bilinear_mode() == 4 || bilinear_mode() == 6),
@@ -666,9 +668,13 @@ int edge_ge_ksplit_launch(const float* gZ, long ldg, long gzb, const float* We, 
   CGAT_PROF(scatter ? "edge_ge" : "rows_ge", stream);
   const EdgeRC none = {};
   const int ncb_g = ncb / S;
-  const HeadBatch hb = {(long)ncb_g * gzb, (long)ncb_g * 6144, 0, (long)E * 128, 0, 0};
-  hipLaunchKernelGGL((edge_ge_kernel<6, false>), dim3(cdiv(E, 256), S), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq,
-                     ncb_g, slabs, 128l, scatter, E, 0, (const float*)nullptr, (const float*)nullptr, none, hb);
+  const HeadBatch hb = {(long)ncb_g * gzb, (long)ncb_g * 6144, 0, (long)E * 128, 0, 0, (long)ncb_g * 4};
+  if (rc)     // the rows rebuilt from their ingredients (struct EdgeRC): a group's k-steps start at ks0
+    hipLaunchKernelGGL((edge_ge_kernel<6, true>), dim3(cdiv(E, 256), S), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq,
+                       ncb_g, slabs, 128l, scatter, E, 0, (const float*)nullptr, (const float*)nullptr, *rc, hb);
+  else
+    hipLaunchKernelGGL((edge_ge_kernel<6, false>), dim3(cdiv(E, 256), S), dim3(512), 0, stream, gZ, ldg, gzb, (const uint4*)Wq,
+                       ncb_g, slabs, 128l, scatter, E, 0, (const float*)nullptr, (const float*)nullptr, none, hb);
   CGAT_LAUNCH_CHECK();
   return CGAT_OK;
 }

@@ -155,6 +155,7 @@ int prepare_W_f16_heads_launch(const float* src, void* dst, int NA, long sa, lon
 struct HeadBatch {
   long in, w, bias, out, dact;
   long add2;   // edge_z_kernel: offset of the second gathered table (column groups of the per-edge first layer)
+  long ks0;    // edge_ge_kernel<., RC>: k-steps in front of a K group (the rebuilt rows are indexed by k-step, not by pointer)
 };
 // column blocks of a [rows, 128 ncb] product dealt to grid.y groups when the row tiles alone leave CUs idle: the number
 // of groups (a divisor of ncb; 1 = no split)
@@ -263,7 +264,8 @@ int edge_ge_heads_launch(int heads, const float* x, long ldx, long s_x, const fl
                          const float* amax);
 int edge_ge_ksplit_groups(int E, int W2);   // K-split form for few row tiles: groups a launch takes (1: use edge_ge_launch)
 int edge_ge_ksplit_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,
-                          float* slabs, const int* scatter, int E, int S, hipStream_t stream);   // S slabs [E,128]; caller sums
+                          float* slabs, const int* scatter, int E, int S, hipStream_t stream,
+                          const EdgeRC* rc = nullptr);   // S slabs [E,128]; caller sums
 int edge_ge_prepared_launch(const float* x, long ldx, const void* Wq, int ncb, float* out, long ldo, int rows,
                             int accumulate, hipStream_t stream);   // six-pass image made by the caller (odd blocks negated)
 int edge_ge_launch(const float* gZ, long ldg, long gzb, const float* We, long s_col, long s_out, float* Wq, int W2,

@@ -868,7 +868,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   // the row-major Gi/Gj when the node width is 128, generic GEMMs otherwise
   // (K-split forms of the two K = W2 -> 128 products at few row tiles, edgebwd.hip: slabs in the scratch region)
   const int Sx = (!ns && d.C == 128) ? edge_ge_ksplit_groups(d.N, d.W2) : 1;
-  const int Se = (!rc && !scales && d.Ce == 128) ? edge_ge_ksplit_groups(d.E, d.W2) : 1;
+  const int Se = (!scales && d.Ce == 128 && !(rc && edge_mma_bf16())) ? edge_ge_ksplit_groups(d.E, d.W2) : 1;
   if (Sx > 1) c.need((size_t)2 * Sx * d.N * 128 * sizeof(float));
   if (Se > 1) c.need((size_t)Se * d.E * 128 * sizeof(float));
   if (!c.dry && d.N > 0 && edge_ge_fast(d.C, d.W2, d.W2, 128, d.C, Gi, g_x) && edge_gw_fast(d.C, d.W2, d.W2, 128, Gi) &&
@@ -921,7 +921,7 @@ static int edge_first_layer_backward_tail(Ctx& c, const cgat_plan* plan, const A
   if (!c.dry && Se > 1 && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e) &&
       c.scratch_bytes >= (size_t)Se * d.E * 128 * sizeof(float)) {
     float* sl = (float*)c.scratch;
-    RUN(edge_ge_ksplit_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, sl, plan->dst_perm, d.E, Se, c.s));
+    RUN(edge_ge_ksplit_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, sl, plan->dst_perm, d.E, Se, c.s, rc));
     RUN(sum_slabs_launch(sl, Se, (long)d.E * 128, g_e, (long)d.E * 128, c.s));
   } else if (!c.dry && edge_ge_fast(d.Ce, d.W2, gz_ld, gzb, d.Ce, gZ, g_e)) {
     RUN(edge_ge_launch(gZ, gz_ld, gzb, Wcat + d.C, d.D, 1, Wq, d.W2, g_e, d.Ce, plan->dst_perm, d.E, 0, nullptr, c.s,
