@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
   f32x4 part[8], partn[ALT ? 8 : 1];
   float dot_a = 0.f, dot_b = 0.f, omx = 0.f;
   const int ncbA = a_out ? H * cb_per_head : 0;      // column blocks that belong to the attention network
+  const int cb0 = (int)((long)blockIdx.y * hb.ks0);  // column blocks in front of this column group (whole heads; 0: no groups)
+  if (wA) wA += (long)cb0 * 128;
   for (int cb = 0; cb < ncb; ++cb) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
       }
       // ---- epilogue of the 64-column slice: z = part + Pi[dst] + Pj[src]; store; logits ----
       const int col0 = cb * 128 + half * 64 + 4 * kg;
-      const bool isA = cb < ncbA;
+      const bool isA = cb + cb0 < ncbA;
       float4 hia[DEEP ? 4 : 1], hja[DEEP ? 4 : 1], hib[DEEP ? 4 : 1], hjb[DEEP ? 4 : 1];
       if constexpr (DEEP) {                          // every gather of the slice before its first store
 #pragma unroll
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void edge_z_kernel(const float* __restrict_
         }
       }
       if (isA && half == 1 && (cb + 1) % cb_per_head == 0) {   // a head is complete: reduce over the 4 lane groups
-        const int h = cb / cb_per_head;
+        const int h = (cb + cb0) / cb_per_head;
         float da = dot_a, db = dot_b;
         da += __shfl_xor(da, 16, 64); da += __shfl_xor(da, 32, 64);
         db += __shfl_xor(db, 16, 64); db += __shfl_xor(db, 32, 64);
@@ -1166,6 +1168,11 @@ static bool edge_z6w_on() {   // CGAT_EDGE_Z6W=0: the 128-row form of the six-pa
   static const bool on = [] { const char* e = getenv("CGAT_EDGE_Z6W"); return !(e && e[0] == '0'); }();
   return on;
 }
+// CGAT_Z_COL_GROUPS=0: no column groups over grid.y at few row tiles (A/B switch of the bit-identity test, like CGAT_EDGE_Z6W)
+static int z_groups(int row_tiles, int ncb, int unit = 1) {
+  static const bool on = [] { const char* e = getenv("CGAT_Z_COL_GROUPS"); return !(e && e[0] == '0'); }();
+  return on ? z_col_groups(row_tiles, ncb, unit) : 1;
+}
 static bool edge_zc_on() {
   static const bool on = [] { const char* e = getenv("CGAT_EDGE_ZC"); return e && e[0] == '1'; }();
   return on;
@@ -1202,8 +1209,12 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   else CGAT_TRY(prepare_T_bf16_launch(We, Wq, ncb, 128 * ldw, 1, ldw, 0, stream));
   CGAT_PROF(Pj ? "edge_z" : "edge_proj", stream);   // the per-edge launch / the per-node projections
   // the six-pass per-edge launch on 256-row workgroups (edge_z6w_kernel: same arithmetic, bit-identical results)
+  // (below 128 of its 256-row tiles -- the harness' shipped batch: 60 workgroups walking 12 blocks, 119 us -- the 128-row
+  // kernel with its column blocks dealt to grid.y groups fills the chip instead: bit-identical arithmetic, see below)
+  const int unit_z = a_out ? Hd / 128 : 1;
+  const bool few_rows = !z_bf16 && cdiv(E, 256) < 128 && z_groups(cdiv(E, 128), ncb, unit_z) > 1;
   if ((bilinear_mode() == 4 || bilinear_mode() == 6) && Pj != nullptr && perm && (act == CGAT_ACT_NONE || act == CGAT_ACT_LEAKY) &&
-      !(omax && a_out) && edge_z6w_on() &&   // (the running maximum shares a register with the logits)
+      !(omax && a_out) && edge_z6w_on() && !few_rows &&   // (the running maximum shares a register with the logits)
       (!a_out || (long)H * Hd <= 2048) && n_add_rows > 0 && (long)n_add_rows * 4 * ld_add < (1l << 32)) {
     if (z_bf16)
       hipLaunchKernelGGL(edge_z6w_kernel<true>, dim3(cdiv(E, 256)), dim3(512), 0, stream, e, lde, perm, (const uint4*)Wq, ncb, Pi,
@@ -1220,10 +1231,12 @@ int edge_z_launch(const float* e, long lde, const int* perm, const float* We, lo
   // 18-ms step) -- : the column blocks are dealt to grid.y groups (round 6).  A workgroup then splits its rows once per group
   // (64 KB, L2-resident) and walks ncb / G blocks; every block is computed as before: bit-identical.  The 24-bit modes
   // without logits (the fp16 image keeps its scale behind the LAST block).
+  // With logits (a_out) a group holds whole heads: a head's logit is the sum over ITS column blocks only, and the group
+  // carries the number of blocks in front of it (head index, fc_out_A's weight row).
   int G = 1;
-  if ((bilinear_mode() == 4 || bilinear_mode() == 6) && !z_bf16 && !a_out) G = z_col_groups(grid, ncb);
+  if ((bilinear_mode() == 4 || bilinear_mode() == 6) && !z_bf16) G = z_groups(grid, ncb, a_out ? Hd / 128 : 1);
   const int ncb_g = ncb / G;
-  const HeadBatch hbz = {0, (long)ncb_g * 6144, (long)ncb_g * 128, (long)ncb_g * 128, 0, (long)ncb_g * 128};
+  const HeadBatch hbz = {0, (long)ncb_g * 6144, (long)ncb_g * 128, (long)ncb_g * 128, 0, (long)ncb_g * 128, (long)ncb_g};
 #define EZ_GO(P_, A_)                                                                                                \
   hipLaunchKernelGGL((edge_z_kernel<P_, A_>), dim3(grid, G), dim3(256), 0, stream, e, lde, perm, (const uint4*)Wq, ncb_g, \
                      Pi, dsti, Pj, srci, ld_add, Z, ldz, E, wA, bA, H, Hd / 128, a_out, act, 0, omax, (const float*)nullptr, 0l, \
@@ -1265,7 +1278,7 @@ int linear128_launch(const float* in, long ldi, const float* W, long so, long sk
   CGAT_PROF("linear128", stream);
   const int grid = cdiv(rows, 128);
   // (column blocks over grid.y when the row tiles leave CUs idle: edge_z_launch above)
-  const int G = (bilinear_mode() == 4 || bilinear_mode() == 6) ? z_col_groups(grid, ncb) : 1;
+  const int G = (bilinear_mode() == 4 || bilinear_mode() == 6) ? z_groups(grid, ncb) : 1;
   const int ncb_g = ncb / G;
   const HeadBatch hbz = {0, (long)ncb_g * 6144, (long)ncb_g * 128, (long)ncb_g * 128, (long)ncb_g * 128, 0};
 #define L128_GO(P_)                                                                                                   \

@@ -155,15 +155,17 @@ int prepare_W_f16_heads_launch(const float* src, void* dst, int NA, long sa, lon
 struct HeadBatch {
   long in, w, bias, out, dact;
   long add2;   // edge_z_kernel: offset of the second gathered table (column groups of the per-edge first layer)
-  long ks0;    // edge_ge_kernel<., RC>: k-steps in front of a K group (the rebuilt rows are indexed by k-step, not by pointer)
+  long ks0;    // edge_ge_kernel<., RC>: k-steps in front of a K group (the rebuilt rows are indexed by k-step, not by pointer);
+               // edge_z_kernel with logits: column blocks in front of a column group (head index, fc_out_A's weight)
 };
 // column blocks of a [rows, 128 ncb] product dealt to grid.y groups when the row tiles alone leave CUs idle: the number
 // of groups (a divisor of ncb; 1 = no split)
-static inline int z_col_groups(int row_tiles, int ncb) {
+// (unit: column blocks that must stay in one group -- a head's blocks when the launch also forms that head's logits)
+static inline int z_col_groups(int row_tiles, int ncb, int unit = 1) {
   int G = 1;
-  if (row_tiles >= 512) return 1;
+  if (row_tiles >= 512 || unit < 1) return 1;
   for (int g = 2; g <= ncb; ++g)
-    if (ncb % g == 0) { G = g; if ((long)row_tiles * G >= 512) break; }
+    if (ncb % g == 0 && (ncb / g) % unit == 0) { G = g; if ((long)row_tiles * G >= 512) break; }
   return G;
 }
 size_t linear128_heads_image_floats(int n_out);

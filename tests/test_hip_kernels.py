@@ -837,13 +837,18 @@ def test_per_edge_forward_wide_tile_is_bit_identical(mode, storage):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for form in ("1", "0"):
+    # "1" / "0": the 256-row and the 128-row kernel, column groups off; "groups": the library's own choice at this size --
+    # 58 of the 256-row tiles, i.e. the 128-row kernel with its column blocks dealt to grid.y groups of whole heads
+    # (round 6, edgez.hip: the logits of a head come from its own group only)
+    for form, env in (("1", {"CGAT_EDGE_Z6W": "1", "CGAT_Z_COL_GROUPS": "0"}),
+                      ("0", {"CGAT_EDGE_Z6W": "0", "CGAT_Z_COL_GROUPS": "0"}), ("groups", {})):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "edgez_worker.py"), mode, storage, "61"],
-                           capture_output=True, text=True, timeout=600, env=dict(os.environ, CGAT_EDGE_Z6W=form))
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         got[form] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][-1][7:])
     assert got["1"]["E"] % 256 != 0 and len(got["1"]["saved"]) >= 1
     assert got["1"] == got["0"], (got["1"], got["0"])
+    assert got["groups"] == got["1"], (got["groups"], got["1"])
 
 
 @pytest.mark.gpu
